@@ -1,0 +1,199 @@
+/*
+ * mvf_gpu.h — C ABI of libmvf_gpu.so: MI355X (gfx950) brute-force top-k
+ * similarity search over one MVF vector space.
+ *
+ * WHAT IT REPLACES.  The reference has no FFI for this path; the scan is the
+ * inline loop `find_top_k_similar` (reference examples/similarity_search.rs:
+ * 140-176): per row VectorSpace::get_vector (src/vectors/vector_space.rs:
+ * 101-142) -> Vector::as_f32 (src/vectors/vector.rs:71-92) -> scalar distance
+ * (similarity_search.rs:152-157) -> BinaryHeap (:159-168) -> sort (:172-173).
+ * This library replaces that whole loop.  The hand-off is what
+ * VectorSpace::map_vector_range(0, total) (vector_space.rs:155-188) +
+ * VectorSlice::as_ptr (src/vectors/mem.rs:75-77) already expose: base
+ * pointer, row stride, row count, DataType; plus dimension()/distance_metric().
+ * INTEGRATION.md shows the Rust `extern "C"` block a maintainer would add.
+ *
+ * CONVENTIONS
+ *  - every call returns enum mvf_status (mvf_status.h), 0 = OK; a thread-local
+ *    detail string is kept for the last failure (mvfgpu_last_error_message).
+ *  - dtype / metric arguments use the schema's codes (schema/types.fbs).
+ *  - a corpus handle is one ROW-RANGE SHARD resident on ONE GPU; it is
+ *    immutable after creation, owned by the library, freed by
+ *    mvfgpu_corpus_destroy.  Multi-GPU = one handle per GPU (one process per
+ *    GPU under torch.distributed/RCCL, or several handles in one process) and
+ *    a merge of the per-shard results (mvfgpu_merge_topk_*).
+ *  - searches on one handle may be issued from several threads; they are
+ *    serialised on the handle's scratch space internally.
+ *  - there is NO CPU fallback: without a gfx950 device every compute entry
+ *    point returns MVF_ERR_DEVICE.
+ *
+ * SEMANTICS (the reference only pins L2 over f32/f16)
+ *  - L2: sqrt(sum (q-x)^2), k smallest.  InnerProduct: sum q*x, k largest.
+ *    Cosine: dot/(|q||x|), 0 when a norm is 0, k largest.
+ *  - Float32/Float16 spaces take f32 queries (f16 widened exactly, as
+ *    Vector::as_f32).  Int8/UInt8 spaces take queries of the space's own
+ *    dtype; sums are exact i32 (dimension <= 33025), bit-exact vs the CPU.
+ *  - results are sorted best-first, ties by ascending row index, NaN last;
+ *    when k > rows the tail is padded with index UINT64_MAX and score
+ *    +inf (L2) / -inf (InnerProduct, Cosine).
+ */
+#ifndef MVF_GPU_H
+#define MVF_GPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#include "mvf_status.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mvfgpu_corpus mvfgpu_corpus;
+
+#define MVFGPU_MAX_K 1024u        /* largest k a search accepts */
+#define MVFGPU_MAX_INT_DIM 33025u /* d*255^2 < 2^31 */
+
+typedef struct mvfgpu_corpus_info {
+    uint64_t rows;        /* rows in this shard */
+    uint64_t index_base;  /* global index of the shard's first row */
+    uint32_t dimension;
+    uint32_t pitch_bytes; /* device row pitch: dimension*elem_size rounded up to 16 */
+    uint8_t data_type;    /* enum mvf_data_type */
+    uint8_t reserved[3];
+    int32_t device;
+    uint64_t device_bytes; /* HBM held by the handle (rows + norms + scratch) */
+} mvfgpu_corpus_info;
+
+typedef struct mvfgpu_timing {
+    /* HIP-event times of the last search on the handle, milliseconds.
+     * Recorded only while mvfgpu_set_profiling(corpus, 1) is in effect. */
+    float scan_ms;     /* the dominant kernel: streaming or MFMA scan */
+    float select_ms;   /* candidate merge / top-k kernels */
+    float total_ms;    /* first launch -> last launch of the search */
+    uint32_t scan_kernel; /* 1 = streaming (K1), 2 = MFMA batched (K2) */
+    uint32_t scan_launches;
+    uint64_t scan_bytes; /* algorithmic bytes read by the scan launches */
+    uint64_t scan_flops; /* algorithmic flops (2*nq*rows*dim) */
+} mvfgpu_timing;
+
+/* ---- library / device ---------------------------------------------------- */
+
+/* Number of visible GPUs (0 and MVF_OK when there is none). */
+int mvfgpu_device_count(int* out_count);
+const char* mvfgpu_strerror(int status);
+/* Detail of the calling thread's last failure ("" if none). */
+const char* mvfgpu_last_error_message(void);
+
+/* ---- corpus -------------------------------------------------------------- */
+
+/*
+ * Upload `n` rows to HBM on `device`.
+ *   rows         : host pointer, any alignment (an mmap'd MVF block starts at
+ *                  file offset 4 — src/builder.rs:421); BORROWED for the call
+ *                  only, the mapping may be dropped afterwards.
+ *   stride_bytes : bytes between consecutive rows; must be >= dimension *
+ *                  elem_size.  The reference always passes dimension*elem_size
+ *                  (VectorSlice stride, vector_space.rs:177,187).
+ *   index_base   : added to every returned index (global row of rows[0]); 0
+ *                  for an unsharded space.
+ * Errors: MVF_ERR_BUILD for a data type other than Float32/Float16/Int8/UInt8
+ * ("Unsupported vector data type", vector_space.rs:126); MVF_ERR_INVALID_
+ * ARGUMENT for dimension 0, NULL rows with n > 0, n >= 2^32-1 rows per shard;
+ * MVF_ERR_DEVICE for HIP failures (incl. out of memory).
+ */
+int mvfgpu_corpus_create(const void* rows, uint64_t n, uint32_t dimension,
+                         uint8_t data_type, uint64_t stride_bytes, int device,
+                         uint64_t index_base, mvfgpu_corpus** out);
+
+/*
+ * Generate rows [row0, row0+n) of the synthetic corpus on the device
+ * (counter-based: element (r,c) = f(seed, r*dimension + c), DESIGN.md §6 —
+ * the CPU oracle regenerates any row).  index_base = row0.
+ */
+int mvfgpu_corpus_create_synthetic(uint64_t n, uint32_t dimension,
+                                   uint8_t data_type, uint64_t seed,
+                                   uint64_t row0, int device,
+                                   mvfgpu_corpus** out);
+
+void mvfgpu_corpus_destroy(mvfgpu_corpus* corpus);
+int mvfgpu_corpus_get_info(const mvfgpu_corpus* corpus, mvfgpu_corpus_info* out);
+
+/* Copy `count` rows starting at local row `first` back to the host, tightly
+ * packed (dimension*elem_size per row) — the device-side get_vector
+ * (vector_space.rs:101-142); MVF_ERR_INDEX_OUT_OF_BOUNDS past the end. */
+int mvfgpu_corpus_read_rows(const mvfgpu_corpus* corpus, uint64_t first,
+                            uint64_t count, void* out_rows);
+
+/* ---- search -------------------------------------------------------------- */
+
+/*
+ * Replaces find_top_k_similar (similarity_search.rs:140-176) for a batch.
+ *   queries    : host, row-major [nq][dimension], contiguous; query_dtype
+ *                must be Float32 for Float32/Float16 spaces and the space's
+ *                dtype for Int8/UInt8 spaces (else MVF_ERR_BUILD).
+ *   query_dim  : length of each query; != corpus dimension ->
+ *                MVF_ERR_DIMENSION_MISMATCH (the reference's zip silently
+ *                truncates, similarity_search.rs:154; we refuse).
+ *   out_scores : host [nq][k] f32, out_indices: host [nq][k] u64 (the
+ *                reference's ScoredVector.index is u64, :16), both
+ *                caller-owned.  out_raw (nullable): [nq][k] exact i32 of
+ *                L2 (sum of squared differences) / InnerProduct for Int8/UInt8
+ *                spaces, 0 otherwise.
+ * Blocking: returns after the results are on the host.
+ */
+int mvfgpu_search(const mvfgpu_corpus* corpus, uint8_t metric,
+                  const void* queries, uint8_t query_dtype, uint32_t query_dim,
+                  uint32_t nq, uint32_t k, float* out_scores,
+                  uint64_t* out_indices, int32_t* out_raw);
+
+/*
+ * Same search with queries and outputs RESIDENT ON THE CORPUS' DEVICE,
+ * asynchronous on `hip_stream` (a hipStream_t; NULL = the default stream).
+ * This is the timed region of bench.py and the producer of the per-shard
+ * lists that RCCL all-gathers.  d_raw may be NULL.
+ */
+int mvfgpu_search_device(const mvfgpu_corpus* corpus, uint8_t metric,
+                         const void* d_queries, uint8_t query_dtype,
+                         uint32_t query_dim, uint32_t nq, uint32_t k,
+                         float* d_scores, uint64_t* d_indices, int32_t* d_raw,
+                         void* hip_stream);
+
+/*
+ * Merge `nlists` per-shard results, each [nq][k] sorted best-first with
+ * UINT64_MAX padding, laid out [nlists][nq][k], into the global [nq][k]
+ * ordered by (score order, global index).  data_type tells whether `raw`
+ * carries the exact integer score (Int8/UInt8 with L2/InnerProduct).
+ * _host: plain host buffers, no GPU needed.  _device: device buffers on
+ * `device` (e.g. the output of an RCCL all-gather), async on hip_stream.
+ */
+int mvfgpu_merge_topk_host(const float* scores, const uint64_t* indices,
+                           const int32_t* raw, uint32_t nlists, uint32_t nq,
+                           uint32_t k, uint8_t metric, uint8_t data_type,
+                           float* out_scores, uint64_t* out_indices,
+                           int32_t* out_raw);
+int mvfgpu_merge_topk_device(const float* d_scores, const uint64_t* d_indices,
+                             const int32_t* d_raw, uint32_t nlists, uint32_t nq,
+                             uint32_t k, uint8_t metric, uint8_t data_type,
+                             float* d_out_scores, uint64_t* d_out_indices,
+                             int32_t* d_out_raw, int device, void* hip_stream);
+
+/* ---- utilities ----------------------------------------------------------- */
+
+/* Fill a device buffer [nq][dimension] with synthetic queries (query dtype of
+ * `data_type`: f32 for Float32/Float16 spaces, else the int type). */
+int mvfgpu_synth_queries_device(void* d_queries, uint32_t nq, uint32_t dimension,
+                                uint8_t data_type, uint64_t seed, int device,
+                                void* hip_stream);
+
+int mvfgpu_set_profiling(mvfgpu_corpus* corpus, int enabled);
+int mvfgpu_last_timing(const mvfgpu_corpus* corpus, mvfgpu_timing* out);
+
+/* Force a scan path for A/B measurements and tests: 0 = automatic,
+ * 1 = streaming kernel (K1) for every nq, 2 = MFMA batched kernel (K2). */
+int mvfgpu_set_scan_path(mvfgpu_corpus* corpus, int path);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

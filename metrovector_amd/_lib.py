@@ -1,0 +1,91 @@
+"""ctypes loaders for the two in-tree native libraries.
+
+  libmvf_gpu.so   — HIP kernels + the C ABI of include/mvf_gpu.h (the drop-in
+                    boundary a Rust caller would bind)
+  libmvf_host.so  — C++ MVF reader/writer (include/mvf_file.h)
+
+There is no Python or CPU fallback for the search path: if libmvf_gpu.so is
+missing the import of anything that needs it raises, loudly.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+GPU_LIB_PATH = os.path.join(_HERE, "libmvf_gpu.so")
+HOST_LIB_PATH = os.path.join(_HERE, "libmvf_host.so")
+
+_gpu = None
+_host = None
+
+
+class CorpusInfo(C.Structure):
+    _fields_ = [("rows", C.c_uint64), ("index_base", C.c_uint64), ("dimension", C.c_uint32),
+                ("pitch_bytes", C.c_uint32), ("data_type", C.c_uint8), ("reserved", C.c_uint8 * 3),
+                ("device", C.c_int32), ("device_bytes", C.c_uint64)]
+
+
+class Timing(C.Structure):
+    _fields_ = [("scan_ms", C.c_float), ("select_ms", C.c_float), ("total_ms", C.c_float),
+                ("scan_kernel", C.c_uint32), ("scan_launches", C.c_uint32), ("scan_bytes", C.c_uint64),
+                ("scan_flops", C.c_uint64)]
+
+
+def _preload_torch_hip() -> None:
+    # torch ships its own libamdhip64.so (same SONAME as /opt/rocm's).  Loading
+    # torch FIRST makes libmvf_gpu.so bind to that copy, so both share one HIP
+    # runtime (device pointers, streams).  Loading order reversed would put two
+    # runtimes in one process.
+    try:
+        import torch  # noqa: F401
+    except Exception:  # torch is plumbing, not a requirement of the library
+        pass
+
+
+def gpu() -> C.CDLL:
+    """libmvf_gpu.so, or an ImportError naming the build command."""
+    global _gpu
+    if _gpu is not None:
+        return _gpu
+    if not os.path.exists(GPU_LIB_PATH):
+        raise ImportError(
+            f"{GPU_LIB_PATH} is missing — build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C metrovector_amd/csrc`.  metrovector_amd has no CPU fallback for the search path.")
+    _preload_torch_hip()
+    lib = C.CDLL(GPU_LIB_PATH)
+    vp, u64, u32, u8, i32 = C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint8, C.c_int
+    pp = C.POINTER(C.c_void_p)
+    lib.mvfgpu_device_count.argtypes = [C.POINTER(C.c_int)]
+    lib.mvfgpu_strerror.restype = C.c_char_p
+    lib.mvfgpu_strerror.argtypes = [i32]
+    lib.mvfgpu_last_error_message.restype = C.c_char_p
+    lib.mvfgpu_last_error_message.argtypes = []
+    lib.mvfgpu_corpus_create.argtypes = [vp, u64, u32, u8, u64, i32, u64, pp]
+    lib.mvfgpu_corpus_create_synthetic.argtypes = [u64, u32, u8, u64, u64, i32, pp]
+    lib.mvfgpu_corpus_destroy.restype = None
+    lib.mvfgpu_corpus_destroy.argtypes = [vp]
+    lib.mvfgpu_corpus_get_info.argtypes = [vp, C.POINTER(CorpusInfo)]
+    lib.mvfgpu_corpus_read_rows.argtypes = [vp, u64, u64, vp]
+    lib.mvfgpu_search.argtypes = [vp, u8, vp, u8, u32, u32, u32, vp, vp, vp]
+    lib.mvfgpu_search_device.argtypes = [vp, u8, vp, u8, u32, u32, u32, vp, vp, vp, vp]
+    lib.mvfgpu_merge_topk_host.argtypes = [vp, vp, vp, u32, u32, u32, u8, u8, vp, vp, vp]
+    lib.mvfgpu_merge_topk_device.argtypes = [vp, vp, vp, u32, u32, u32, u8, u8, vp, vp, vp, i32, vp]
+    lib.mvfgpu_synth_queries_device.argtypes = [vp, u32, u32, u8, u64, i32, vp]
+    lib.mvfgpu_set_profiling.argtypes = [vp, i32]
+    lib.mvfgpu_last_timing.argtypes = [vp, C.POINTER(Timing)]
+    lib.mvfgpu_set_scan_path.argtypes = [vp, i32]
+    for name in ("mvfgpu_device_count", "mvfgpu_corpus_create", "mvfgpu_corpus_create_synthetic",
+                 "mvfgpu_corpus_get_info", "mvfgpu_corpus_read_rows", "mvfgpu_search", "mvfgpu_search_device",
+                 "mvfgpu_merge_topk_host", "mvfgpu_merge_topk_device", "mvfgpu_synth_queries_device",
+                 "mvfgpu_set_profiling", "mvfgpu_last_timing", "mvfgpu_set_scan_path"):
+        getattr(lib, name).restype = C.c_int
+    _gpu = lib
+    return lib
+
+
+def gpu_check(status: int) -> None:
+    if status != 0:
+        from .errors import raise_for_status
+        msg = gpu().mvfgpu_last_error_message().decode("utf-8", "replace")
+        raise_for_status(status, msg or gpu().mvfgpu_strerror(status).decode())

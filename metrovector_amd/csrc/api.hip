@@ -1,0 +1,632 @@
+// api.hip — the C ABI of libmvf_gpu.so (include/mvf_gpu.h).
+//
+// Host-side orchestration only: validation in the reference's error
+// vocabulary (src/errors.rs:8-40), HBM residency of one row-range shard,
+// kernel sequencing on the caller's HIP stream.  No CPU compute path exists
+// here: without a device every compute entry point fails with MVF_ERR_DEVICE.
+
+#include "../../include/mvf_gpu.h"
+
+#include "aux_kernels.h"
+#include "mvf_common.h"
+#include "scan_stream.h"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+using namespace mvf;
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int status, const std::string& msg) {
+    g_last_error = msg;
+    return status;
+}
+
+#define HIP_TRY(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t e__ = (expr);                                                               \
+        if (e__ != hipSuccess)                                                                 \
+            return fail(MVF_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e__));   \
+    } while (0)
+
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = false;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        ok = hipSetDevice(dev) == hipSuccess;
+    }
+    ~DeviceGuard() {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    hipError_t reserve(size_t need) {
+        if (need <= bytes) return hipSuccess;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+        hipError_t e = hipMalloc(&p, need);
+        if (e == hipSuccess) bytes = need;
+        return e;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+};
+
+}  // namespace
+
+struct mvfgpu_corpus {
+    int device = 0;
+    uint64_t n = 0, index_base = 0;
+    uint32_t dim = 0, pitch = 0, V = 0, J = 0;
+    int G = 64;
+    uint8_t dtype = 0;
+    unsigned char* d_rows = nullptr;
+    size_t rows_bytes = 0;
+    int num_cus = 256;
+
+    mutable std::mutex mu;       // guards the scratch + timing state
+    mutable std::mutex host_mu;  // serialises the host-buffer API's device mirrors
+    mutable DevBuf cand, stage[2];        // scratch of the search pipeline
+    mutable DevBuf h_q, h_s, h_i, h_r;    // device mirrors for the host-buffer API
+    mutable hipStream_t own_stream = nullptr;
+    mutable hipEvent_t ev_done = nullptr;
+    mutable hipStream_t last_stream = nullptr;
+    mutable bool has_done = false;
+
+    bool profiling = false;
+    int scan_path = 0;
+    mutable hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+    mutable mvfgpu_timing timing{};
+};
+
+namespace {
+
+void choose_group(uint32_t V, int* G_out, uint32_t* J_out) {
+    // lanes per row: the widest of {64,16,4,1} whose lane utilisation is within 80 % of the best
+    const int cand[4] = {64, 16, 4, 1};
+    double best = 0;
+    for (int g : cand) {
+        uint32_t j = (V + g - 1) / g;
+        best = std::max(best, (double)V / ((double)j * g));
+    }
+    for (int g : cand) {
+        uint32_t j = (V + g - 1) / g;
+        if ((double)V / ((double)j * g) >= 0.8 * best) {
+            *G_out = g;
+            *J_out = j;
+            return;
+        }
+    }
+}
+
+int init_common(mvfgpu_corpus* c) {
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, c->device));
+    c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    HIP_TRY(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming));
+    for (auto& e : c->ev) HIP_TRY(hipEventCreate(&e));
+    return MVF_OK;
+}
+
+int validate_shape(uint64_t n, uint32_t dim, uint8_t dtype) {
+    if (elem_size(dtype) == 0)
+        return fail(MVF_ERR_BUILD, "Unsupported vector data type");  // reference src/vectors/vector_space.rs:126
+    if (dim == 0) return fail(MVF_ERR_INVALID_ARGUMENT, "dimension must be > 0");
+    if (is_int_dtype(dtype) && dim > MVFGPU_MAX_INT_DIM)
+        return fail(MVF_ERR_BUILD, "Int8/UInt8 dimension exceeds the exact-i32 bound (33025)");
+    if (n >= 0xFFFFFFFFull) return fail(MVF_ERR_INVALID_ARGUMENT, "a shard holds at most 2^32-2 rows");
+    return MVF_OK;
+}
+
+int alloc_rows(mvfgpu_corpus* c) {
+    c->pitch = (c->dim * elem_size(c->dtype) + 15u) & ~15u;
+    c->V = c->pitch / 16;
+    choose_group(c->V, &c->G, &c->J);
+    c->rows_bytes = (size_t)c->n * c->pitch;
+    if (c->rows_bytes) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_rows), c->rows_bytes));
+    return MVF_OK;
+}
+
+hipError_t scan_launch(uint8_t dtype, const ScanParams& p, int metric, int G, int nqv, dim3 grid, size_t lds,
+                       hipStream_t s) {
+    switch (dtype) {
+    case MVF_DTYPE_FLOAT32: return scan_stream_launch_dt0(p, metric, G, nqv, grid, lds, s);
+    case MVF_DTYPE_FLOAT16: return scan_stream_launch_dt1(p, metric, G, nqv, grid, lds, s);
+    case MVF_DTYPE_INT8: return scan_stream_launch_dt2(p, metric, G, nqv, grid, lds, s);
+    default: return scan_stream_launch_dt3(p, metric, G, nqv, grid, lds, s);
+    }
+}
+
+const void* scan_kernel(uint8_t dtype, int metric, int G, int nqv) {
+    switch (dtype) {
+    case MVF_DTYPE_FLOAT32: return scan_stream_kernel_ptr_dt0(metric, G, nqv);
+    case MVF_DTYPE_FLOAT16: return scan_stream_kernel_ptr_dt1(metric, G, nqv);
+    case MVF_DTYPE_INT8: return scan_stream_kernel_ptr_dt2(metric, G, nqv);
+    default: return scan_stream_kernel_ptr_dt3(metric, G, nqv);
+    }
+}
+
+// Reduce [nqv][lists][kcap] sorted lists to the final [nqv][k] results.
+int run_merges(const mvfgpu_corpus* c, const uint64_t* lists, uint32_t nlists, uint32_t nqv, uint32_t k,
+               uint32_t kcap, uint8_t metric, float* d_scores, uint64_t* d_indices, int32_t* d_raw,
+               hipStream_t s) {
+    const uint32_t F = std::max(2u, kMergeMaxEntries / kcap);
+    const uint64_t* in = lists;
+    uint32_t lists_in = nlists;
+    int pp = 0;
+    for (;;) {
+        const uint32_t groups = lists_in == 0 ? 1 : (lists_in + F - 1) / F;
+        MergeParams mp{};
+        mp.in = in;
+        mp.lists_in = lists_in;
+        mp.kcap = kcap;
+        mp.F = F;
+        mp.P = next_pow2(std::max(2u, std::min(F, std::max(1u, lists_in)) * kcap));
+        if (groups == 1) {
+            mp.k = k;
+            mp.metric = metric;
+            mp.dtype = c->dtype;
+            mp.index_base = c->index_base;
+            mp.out_scores = d_scores;
+            mp.out_indices = d_indices;
+            mp.out_raw = d_raw;
+            HIP_TRY(launch_merge_lists(mp, 1, nqv, true, s));
+            return MVF_OK;
+        }
+        HIP_TRY(c->stage[pp].reserve((size_t)nqv * groups * kcap * 8));
+        mp.out = static_cast<uint64_t*>(c->stage[pp].p);
+        HIP_TRY(launch_merge_lists(mp, groups, nqv, false, s));
+        in = mp.out;
+        lists_in = groups;
+        pp ^= 1;
+    }
+}
+
+int search_stream_path(const mvfgpu_corpus* c, uint8_t metric, const void* d_queries, uint32_t nq, uint32_t k,
+                       float* d_scores, uint64_t* d_indices, int32_t* d_raw, hipStream_t s) {
+    const uint32_t kcap = next_pow2(k);
+    const int G = c->G;
+    const uint32_t chunk_rows = scan_chunk_rows(G);
+    const uint32_t nchunks = (uint32_t)((c->n + chunk_rows - 1) / chunk_rows);
+    const uint32_t pmax = next_pow2(k + chunk_rows);
+
+    mvfgpu_timing tm{};
+    tm.scan_kernel = 1;
+    float scan_ms = 0, select_ms = 0;
+    bool first = true;
+
+    for (uint32_t q0 = 0; q0 < nq;) {
+        int nqv = (nq - q0) >= 2 ? 4 : 1;
+        size_t lds = scan_lds_bytes(c->dtype, G, c->J, nqv, pmax);
+        if (nqv == 4 && lds > 150 * 1024) {
+            nqv = 1;
+            lds = scan_lds_bytes(c->dtype, G, c->J, nqv, pmax);
+        }
+        if (lds > 160 * 1024) return fail(MVF_ERR_BUILD, "dimension too large for the streaming kernel's LDS query tile");
+        const uint32_t nq_here = std::min<uint32_t>(nqv, nq - q0);
+
+        uint32_t nblocks = 0;
+        if (nchunks > 0) {
+            const void* kfn = scan_kernel(c->dtype, metric, G, nqv);
+            if (lds > 48 * 1024)
+                HIP_TRY(hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            int occ = 0;
+            HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kfn, 256, lds));
+            if (occ < 1) occ = 1;
+            nblocks = std::min<uint32_t>(nchunks, (uint32_t)occ * (uint32_t)c->num_cus);
+            HIP_TRY(c->cand.reserve((size_t)nq_here * nblocks * kcap * 8));
+
+            ScanParams sp{};
+            sp.rows = c->d_rows;
+            sp.queries = d_queries;
+            sp.cand = static_cast<uint64_t*>(c->cand.p);
+            sp.n = (uint32_t)c->n;
+            sp.pitch = c->pitch;
+            sp.dim = c->dim;
+            sp.V = c->V;
+            sp.J = c->J;
+            sp.q0 = q0;
+            sp.nq_total = nq;
+            sp.k = k;
+            sp.kcap = kcap;
+            sp.pmax = pmax;
+            sp.chunk_rows = chunk_rows;
+            sp.nchunks = nchunks;
+            if (c->profiling && first) HIP_TRY(hipEventRecord(c->ev[0], s));
+            HIP_TRY(scan_launch(c->dtype, sp, metric, G, nqv, dim3(nblocks), lds, s));
+            if (c->profiling && first) HIP_TRY(hipEventRecord(c->ev[1], s));
+            tm.scan_launches++;
+            tm.scan_bytes += (uint64_t)c->n * c->dim * elem_size(c->dtype);
+            tm.scan_flops += 2ull * nq_here * c->n * c->dim;
+        }
+        int rc = run_merges(c, static_cast<const uint64_t*>(c->cand.p), nblocks, nq_here, k, kcap, metric,
+                            d_scores + (size_t)q0 * k, d_indices + (size_t)q0 * k,
+                            d_raw ? d_raw + (size_t)q0 * k : nullptr, s);
+        if (rc != MVF_OK) return rc;
+        if (c->profiling && first) {
+            HIP_TRY(hipEventRecord(c->ev[2], s));
+            HIP_TRY(hipEventSynchronize(c->ev[2]));
+            if (nchunks > 0) {
+                HIP_TRY(hipEventElapsedTime(&scan_ms, c->ev[0], c->ev[1]));
+                HIP_TRY(hipEventElapsedTime(&select_ms, c->ev[1], c->ev[2]));
+            }
+        }
+        first = false;
+        q0 += nq_here;
+    }
+    if (c->profiling) {
+        // scan_ms / select_ms are those of the FIRST launch group (one group when nq <= 4)
+        tm.scan_ms = scan_ms;
+        tm.select_ms = select_ms;
+        tm.total_ms = scan_ms + select_ms;
+        c->timing = tm;
+    }
+    return MVF_OK;
+}
+
+int check_query_args(const mvfgpu_corpus* c, uint8_t metric, const void* queries, uint8_t query_dtype,
+                     uint32_t query_dim, uint32_t nq, uint32_t k, const void* out_scores, const void* out_indices) {
+    if (!c) return fail(MVF_ERR_INVALID_ARGUMENT, "corpus is NULL");
+    if (metric != MVF_METRIC_L2 && metric != MVF_METRIC_INNER_PRODUCT && metric != MVF_METRIC_COSINE)
+        return fail(MVF_ERR_INVALID_ARGUMENT, "unsupported distance metric code " + std::to_string(metric));
+    if (nq == 0) return fail(MVF_ERR_INVALID_ARGUMENT, "nq must be > 0");
+    if (k == 0 || k > MVFGPU_MAX_K) return fail(MVF_ERR_INVALID_ARGUMENT, "k must be in 1..1024");
+    if (!queries || !out_scores || !out_indices) return fail(MVF_ERR_INVALID_ARGUMENT, "NULL buffer");
+    const uint8_t want = is_int_dtype(c->dtype) ? c->dtype : (uint8_t)MVF_DTYPE_FLOAT32;
+    if (query_dtype != want)
+        return fail(MVF_ERR_BUILD, "query data type must be Float32 for Float32/Float16 spaces and the space's own type for Int8/UInt8");
+    if (query_dim != c->dim) {
+        g_last_error = "Dimension mismatch: expected " + std::to_string(c->dim) + ", got " + std::to_string(query_dim);
+        return MVF_ERR_DIMENSION_MISMATCH;  // reference src/errors.rs:24
+    }
+    return MVF_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mvfgpu_device_count(int* out_count) {
+    if (!out_count) return fail(MVF_ERR_INVALID_ARGUMENT, "out_count is NULL");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        n = 0;
+    }
+    *out_count = n;
+    return MVF_OK;
+}
+
+const char* mvfgpu_strerror(int status) {
+    switch (status) {
+    case MVF_OK: return "ok";
+    case MVF_ERR_IO: return "I/O error";
+    case MVF_ERR_INVALID_FORMAT: return "Invalid file format";
+    case MVF_ERR_UNSUPPORTED_VERSION: return "Unsupported version";
+    case MVF_ERR_SPACE_NOT_FOUND: return "Vector space not found";
+    case MVF_ERR_INDEX_OUT_OF_BOUNDS: return "Index out of bounds";
+    case MVF_ERR_DIMENSION_MISMATCH: return "Dimension mismatch";
+    case MVF_ERR_INVALID_VECTOR_TYPE: return "Invalid vector type";
+    case MVF_ERR_CORRUPTED_DATA: return "Corrupted data";
+    case MVF_ERR_EXTENSION: return "Extension error";
+    case MVF_ERR_BUILD: return "Build error";
+    case MVF_ERR_DEVICE: return "Device error";
+    case MVF_ERR_INVALID_ARGUMENT: return "Invalid argument";
+    default: return "unknown status";
+    }
+}
+
+const char* mvfgpu_last_error_message(void) { return g_last_error.c_str(); }
+
+int mvfgpu_corpus_create(const void* rows, uint64_t n, uint32_t dimension, uint8_t data_type,
+                         uint64_t stride_bytes, int device, uint64_t index_base, mvfgpu_corpus** out) {
+    if (!out) return fail(MVF_ERR_INVALID_ARGUMENT, "out is NULL");
+    *out = nullptr;
+    int rc = validate_shape(n, dimension, data_type);
+    if (rc != MVF_OK) return rc;
+    const uint64_t row_bytes = (uint64_t)dimension * elem_size(data_type);
+    if (n > 0 && !rows) return fail(MVF_ERR_INVALID_ARGUMENT, "rows is NULL");
+    if (n > 0 && stride_bytes < row_bytes)
+        return fail(MVF_ERR_CORRUPTED_DATA, "Invalid stride alignment");  // cf. reference src/vectors/mem.rs:53-59
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+        (void)hipGetLastError();
+        return fail(MVF_ERR_DEVICE, "no HIP device available (libmvf_gpu has no CPU fallback)");
+    }
+    if (device < 0 || device >= ndev) return fail(MVF_ERR_INVALID_ARGUMENT, "device index out of range");
+    DeviceGuard guard(device);
+    if (!guard.ok) return fail(MVF_ERR_DEVICE, "hipSetDevice failed");
+
+    auto* c = new mvfgpu_corpus();
+    c->device = device;
+    c->n = n;
+    c->dim = dimension;
+    c->dtype = data_type;
+    c->index_base = index_base;
+    rc = init_common(c);
+    if (rc == MVF_OK) rc = alloc_rows(c);
+    if (rc == MVF_OK && n > 0) {
+        hipError_t e = hipSuccess;
+        if (stride_bytes == c->pitch) {
+            e = hipMemcpy(c->d_rows, rows, c->rows_bytes, hipMemcpyHostToDevice);
+        } else {
+            if (c->pitch != row_bytes) e = hipMemset(c->d_rows, 0, c->rows_bytes);  // zero the 16-B padding
+            const uint64_t step = 1u << 20;  // rows per 2-D copy
+            for (uint64_t r0 = 0; r0 < n && e == hipSuccess; r0 += step) {
+                const uint64_t h = std::min(step, n - r0);
+                e = hipMemcpy2D(c->d_rows + r0 * c->pitch, c->pitch,
+                                static_cast<const unsigned char*>(rows) + r0 * stride_bytes, stride_bytes, row_bytes, h,
+                                hipMemcpyHostToDevice);
+            }
+        }
+        if (e != hipSuccess) rc = fail(MVF_ERR_DEVICE, std::string("row upload: ") + hipGetErrorString(e));
+    }
+    if (rc != MVF_OK) {
+        mvfgpu_corpus_destroy(c);
+        return rc;
+    }
+    *out = c;
+    return MVF_OK;
+}
+
+int mvfgpu_corpus_create_synthetic(uint64_t n, uint32_t dimension, uint8_t data_type, uint64_t seed, uint64_t row0,
+                                   int device, mvfgpu_corpus** out) {
+    if (!out) return fail(MVF_ERR_INVALID_ARGUMENT, "out is NULL");
+    *out = nullptr;
+    int rc = validate_shape(n, dimension, data_type);
+    if (rc != MVF_OK) return rc;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+        (void)hipGetLastError();
+        return fail(MVF_ERR_DEVICE, "no HIP device available (libmvf_gpu has no CPU fallback)");
+    }
+    if (device < 0 || device >= ndev) return fail(MVF_ERR_INVALID_ARGUMENT, "device index out of range");
+    DeviceGuard guard(device);
+    if (!guard.ok) return fail(MVF_ERR_DEVICE, "hipSetDevice failed");
+    auto* c = new mvfgpu_corpus();
+    c->device = device;
+    c->n = n;
+    c->dim = dimension;
+    c->dtype = data_type;
+    c->index_base = row0;
+    rc = init_common(c);
+    if (rc == MVF_OK) rc = alloc_rows(c);
+    if (rc == MVF_OK && n > 0) {
+        hipError_t e = launch_synth_rows(c->d_rows, n, dimension, c->pitch, data_type, seed, row0, c->own_stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->own_stream);
+        if (e != hipSuccess) rc = fail(MVF_ERR_DEVICE, std::string("synthetic fill: ") + hipGetErrorString(e));
+    }
+    if (rc != MVF_OK) {
+        mvfgpu_corpus_destroy(c);
+        return rc;
+    }
+    *out = c;
+    return MVF_OK;
+}
+
+void mvfgpu_corpus_destroy(mvfgpu_corpus* c) {
+    if (!c) return;
+    {
+        DeviceGuard guard(c->device);
+        (void)hipDeviceSynchronize();
+        if (c->d_rows) (void)hipFree(c->d_rows);
+        c->cand.release();
+        c->stage[0].release();
+        c->stage[1].release();
+        c->h_q.release();
+        c->h_s.release();
+        c->h_i.release();
+        c->h_r.release();
+        if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+        if (c->ev_done) (void)hipEventDestroy(c->ev_done);
+        for (auto& e : c->ev)
+            if (e) (void)hipEventDestroy(e);
+    }
+    delete c;
+}
+
+int mvfgpu_corpus_get_info(const mvfgpu_corpus* c, mvfgpu_corpus_info* out) {
+    if (!c || !out) return fail(MVF_ERR_INVALID_ARGUMENT, "NULL argument");
+    std::memset(out, 0, sizeof(*out));
+    out->rows = c->n;
+    out->index_base = c->index_base;
+    out->dimension = c->dim;
+    out->pitch_bytes = c->pitch;
+    out->data_type = c->dtype;
+    out->device = c->device;
+    std::lock_guard<std::mutex> lk(c->mu);
+    out->device_bytes = c->rows_bytes + c->cand.bytes + c->stage[0].bytes + c->stage[1].bytes + c->h_q.bytes +
+                        c->h_s.bytes + c->h_i.bytes + c->h_r.bytes;
+    return MVF_OK;
+}
+
+int mvfgpu_corpus_read_rows(const mvfgpu_corpus* c, uint64_t first, uint64_t count, void* out_rows) {
+    if (!c || (!out_rows && count)) return fail(MVF_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (first + count > c->n || first + count < first) {
+        g_last_error = "Index out of bounds: " + std::to_string(first + count) + " >= " + std::to_string(c->n);
+        return MVF_ERR_INDEX_OUT_OF_BOUNDS;  // reference src/vectors/vector_space.rs:156-161
+    }
+    if (count == 0) return MVF_OK;
+    DeviceGuard guard(c->device);
+    const uint64_t row_bytes = (uint64_t)c->dim * elem_size(c->dtype);
+    HIP_TRY(hipMemcpy2D(out_rows, row_bytes, c->d_rows + first * c->pitch, c->pitch, row_bytes, count,
+                        hipMemcpyDeviceToHost));
+    return MVF_OK;
+}
+
+int mvfgpu_search_device(const mvfgpu_corpus* c, uint8_t metric, const void* d_queries, uint8_t query_dtype,
+                         uint32_t query_dim, uint32_t nq, uint32_t k, float* d_scores, uint64_t* d_indices,
+                         int32_t* d_raw, void* hip_stream) {
+    int rc = check_query_args(c, metric, d_queries, query_dtype, query_dim, nq, k, d_scores, d_indices);
+    if (rc != MVF_OK) return rc;
+    DeviceGuard guard(c->device);
+    if (!guard.ok) return fail(MVF_ERR_DEVICE, "hipSetDevice failed");
+    hipStream_t s = static_cast<hipStream_t>(hip_stream);
+    std::lock_guard<std::mutex> lk(c->mu);
+    // the scratch buffers are stream-ordered: a call on another stream waits for the previous one
+    if (c->has_done && c->last_stream != s) HIP_TRY(hipStreamWaitEvent(s, c->ev_done, 0));
+    rc = search_stream_path(c, metric, d_queries, nq, k, d_scores, d_indices, d_raw, s);
+    if (rc != MVF_OK) return rc;
+    HIP_TRY(hipEventRecord(c->ev_done, s));
+    c->has_done = true;
+    c->last_stream = s;
+    return MVF_OK;
+}
+
+int mvfgpu_search(const mvfgpu_corpus* c, uint8_t metric, const void* queries, uint8_t query_dtype,
+                  uint32_t query_dim, uint32_t nq, uint32_t k, float* out_scores, uint64_t* out_indices,
+                  int32_t* out_raw) {
+    int rc = check_query_args(c, metric, queries, query_dtype, query_dim, nq, k, out_scores, out_indices);
+    if (rc != MVF_OK) return rc;
+    DeviceGuard guard(c->device);
+    if (!guard.ok) return fail(MVF_ERR_DEVICE, "hipSetDevice failed");
+    const size_t qbytes = (size_t)nq * c->dim * (is_int_dtype(c->dtype) ? 1 : 4);
+    const size_t nres = (size_t)nq * k;
+    void *dq, *ds, *di, *dr;
+    std::lock_guard<std::mutex> host_lk(c->host_mu);
+    {
+        std::lock_guard<std::mutex> lk(c->mu);
+        // wait for any in-flight user of the mirrors before (re)allocating them
+        if (c->has_done) HIP_TRY(hipEventSynchronize(c->ev_done));
+        HIP_TRY(c->h_q.reserve(qbytes));
+        HIP_TRY(c->h_s.reserve(nres * 4));
+        HIP_TRY(c->h_i.reserve(nres * 8));
+        HIP_TRY(c->h_r.reserve(nres * 4));
+        dq = c->h_q.p;
+        ds = c->h_s.p;
+        di = c->h_i.p;
+        dr = c->h_r.p;
+        HIP_TRY(hipMemcpyAsync(dq, queries, qbytes, hipMemcpyHostToDevice, c->own_stream));
+    }
+    rc = mvfgpu_search_device(c, metric, dq, query_dtype, query_dim, nq, k, static_cast<float*>(ds),
+                              static_cast<uint64_t*>(di), static_cast<int32_t*>(dr), c->own_stream);
+    if (rc != MVF_OK) return rc;
+    HIP_TRY(hipMemcpyAsync(out_scores, ds, nres * 4, hipMemcpyDeviceToHost, c->own_stream));
+    HIP_TRY(hipMemcpyAsync(out_indices, di, nres * 8, hipMemcpyDeviceToHost, c->own_stream));
+    if (out_raw) HIP_TRY(hipMemcpyAsync(out_raw, dr, nres * 4, hipMemcpyDeviceToHost, c->own_stream));
+    HIP_TRY(hipStreamSynchronize(c->own_stream));
+    return MVF_OK;
+}
+
+int mvfgpu_merge_topk_host(const float* scores, const uint64_t* indices, const int32_t* raw, uint32_t nlists,
+                           uint32_t nq, uint32_t k, uint8_t metric, uint8_t data_type, float* out_scores,
+                           uint64_t* out_indices, int32_t* out_raw) {
+    if (!scores || !indices || !out_scores || !out_indices) return fail(MVF_ERR_INVALID_ARGUMENT, "NULL buffer");
+    if (metric != MVF_METRIC_L2 && metric != MVF_METRIC_INNER_PRODUCT && metric != MVF_METRIC_COSINE)
+        return fail(MVF_ERR_INVALID_ARGUMENT, "unsupported distance metric code");
+    if (nlists == 0 || nq == 0 || k == 0) return fail(MVF_ERR_INVALID_ARGUMENT, "nlists, nq and k must be > 0");
+    const bool use_raw = key_is_raw(data_type, metric) && raw != nullptr;
+    struct Ent {
+        uint32_t key;
+        uint64_t idx;
+        size_t slot;
+    };
+    std::vector<Ent> ents;
+    ents.reserve((size_t)nlists * k);
+    for (uint32_t q = 0; q < nq; q++) {
+        ents.clear();
+        for (uint32_t l = 0; l < nlists; l++)
+            for (uint32_t j = 0; j < k; j++) {
+                const size_t s = ((size_t)l * nq + q) * k + j;
+                if (indices[s] == ~0ull) continue;  // padding
+                ents.push_back({use_raw ? key_from_raw(raw[s], metric) : key_from_score(scores[s], metric), indices[s], s});
+            }
+        const size_t keep = std::min<size_t>(k, ents.size());
+        std::partial_sort(ents.begin(), ents.begin() + keep, ents.end(), [](const Ent& a, const Ent& b) {
+            return a.key < b.key || (a.key == b.key && a.idx < b.idx);
+        });
+        for (uint32_t j = 0; j < k; j++) {
+            const size_t o = (size_t)q * k + j;
+            if (j < keep) {
+                out_scores[o] = scores[ents[j].slot];
+                out_indices[o] = ents[j].idx;
+                if (out_raw) out_raw[o] = raw ? raw[ents[j].slot] : 0;
+            } else {
+                out_scores[o] = pad_score(metric);
+                out_indices[o] = ~0ull;
+                if (out_raw) out_raw[o] = 0;
+            }
+        }
+    }
+    return MVF_OK;
+}
+
+int mvfgpu_merge_topk_device(const float* d_scores, const uint64_t* d_indices, const int32_t* d_raw, uint32_t nlists,
+                             uint32_t nq, uint32_t k, uint8_t metric, uint8_t data_type, float* d_out_scores,
+                             uint64_t* d_out_indices, int32_t* d_out_raw, int device, void* hip_stream) {
+    if (!d_scores || !d_indices || !d_out_scores || !d_out_indices) return fail(MVF_ERR_INVALID_ARGUMENT, "NULL buffer");
+    if (metric != MVF_METRIC_L2 && metric != MVF_METRIC_INNER_PRODUCT && metric != MVF_METRIC_COSINE)
+        return fail(MVF_ERR_INVALID_ARGUMENT, "unsupported distance metric code");
+    if (nlists == 0 || nq == 0 || k == 0) return fail(MVF_ERR_INVALID_ARGUMENT, "nlists, nq and k must be > 0");
+    const uint32_t P = next_pow2(std::max(2u, nlists * k));
+    if (P > kMergeMaxEntries) return fail(MVF_ERR_INVALID_ARGUMENT, "nlists * k exceeds 8192");
+    DeviceGuard guard(device);
+    if (!guard.ok) return fail(MVF_ERR_DEVICE, "hipSetDevice failed");
+    ShardMergeParams p{};
+    p.scores = d_scores;
+    p.indices = d_indices;
+    p.raw = d_raw;
+    p.nlists = nlists;
+    p.nq = nq;
+    p.k = k;
+    p.P = P;
+    p.metric = metric;
+    p.dtype = data_type;
+    p.out_scores = d_out_scores;
+    p.out_indices = d_out_indices;
+    p.out_raw = d_out_raw;
+    HIP_TRY(launch_merge_shards(p, static_cast<hipStream_t>(hip_stream)));
+    return MVF_OK;
+}
+
+int mvfgpu_synth_queries_device(void* d_queries, uint32_t nq, uint32_t dimension, uint8_t data_type, uint64_t seed,
+                                int device, void* hip_stream) {
+    if (!d_queries) return fail(MVF_ERR_INVALID_ARGUMENT, "NULL buffer");
+    if (elem_size(data_type) == 0) return fail(MVF_ERR_BUILD, "Unsupported vector data type");
+    DeviceGuard guard(device);
+    if (!guard.ok) return fail(MVF_ERR_DEVICE, "hipSetDevice failed");
+    const uint8_t qd = is_int_dtype(data_type) ? data_type : (uint8_t)MVF_DTYPE_FLOAT32;
+    HIP_TRY(launch_synth_packed(d_queries, (uint64_t)nq * dimension, qd, seed, static_cast<hipStream_t>(hip_stream)));
+    return MVF_OK;
+}
+
+int mvfgpu_set_profiling(mvfgpu_corpus* c, int enabled) {
+    if (!c) return fail(MVF_ERR_INVALID_ARGUMENT, "corpus is NULL");
+    std::lock_guard<std::mutex> lk(c->mu);
+    c->profiling = enabled != 0;
+    return MVF_OK;
+}
+
+int mvfgpu_last_timing(const mvfgpu_corpus* c, mvfgpu_timing* out) {
+    if (!c || !out) return fail(MVF_ERR_INVALID_ARGUMENT, "NULL argument");
+    std::lock_guard<std::mutex> lk(c->mu);
+    *out = c->timing;
+    return MVF_OK;
+}
+
+int mvfgpu_set_scan_path(mvfgpu_corpus* c, int path) {
+    if (!c) return fail(MVF_ERR_INVALID_ARGUMENT, "corpus is NULL");
+    if (path < 0 || path > 2) return fail(MVF_ERR_INVALID_ARGUMENT, "path must be 0, 1 or 2");
+    std::lock_guard<std::mutex> lk(c->mu);
+    c->scan_path = path;
+    return MVF_OK;
+}
+
+}  // extern "C"

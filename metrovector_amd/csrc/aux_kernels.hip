@@ -1,0 +1,206 @@
+// aux_kernels.hip — K3 (candidate-list merge + result formatting), the
+// cross-shard merge C1's device half, and the synthetic generators.
+//
+// K3 replaces the tail of reference examples/similarity_search.rs:172-173
+// (heap.into_iter().collect(); sort_by(score)) — here a bitonic sort of u64
+// composites (order key << 32 | local row) in LDS.
+
+#include "aux_kernels.h"
+#include "mvf_common.h"
+
+#include <hip/hip_fp16.h>
+
+namespace mvf {
+namespace {
+
+__device__ __forceinline__ void bitonic_sort_u64(uint64_t* buf, uint32_t P, int tid, int nthreads) {
+    for (uint32_t size = 2; size <= P; size <<= 1) {
+        for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
+            for (uint32_t t = tid; t < (P >> 1); t += nthreads) {
+                uint32_t i = 2 * t - (t & (stride - 1));
+                uint32_t j = i + stride;
+                bool up = (i & size) == 0;
+                uint64_t a = buf[i], b = buf[j];
+                if ((a > b) == up) {
+                    buf[i] = b;
+                    buf[j] = a;
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+__device__ __forceinline__ void write_result(uint64_t comp, uint32_t o, const MergeParams& p) {
+    const uint32_t key = (uint32_t)(comp >> 32);
+    if (comp == kPadComposite) {
+        p.out_scores[o] = pad_score(p.metric);
+        p.out_indices[o] = ~0ull;
+        if (p.out_raw) p.out_raw[o] = 0;
+        return;
+    }
+    float s;
+    int32_t raw = 0;
+    if (key_is_raw(p.dtype, p.metric)) {
+        raw = raw_from_key(key, p.metric);
+        s = p.metric == MVF_METRIC_L2 ? sqrtf((float)raw) : (float)raw;
+    } else {
+        s = score_from_key(key, p.metric);
+    }
+    p.out_scores[o] = s;
+    p.out_indices[o] = p.index_base + (uint32_t)comp;
+    if (p.out_raw) p.out_raw[o] = raw;
+}
+
+// grid (groups_out, nq); block 256; dynamic LDS P*8.
+// in: [q][lists_in][kcap] sorted composites; block g merges lists [g*F, (g+1)*F).
+template <bool FINAL>
+__global__ void __launch_bounds__(256) merge_lists_kernel(MergeParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint64_t* buf = reinterpret_cast<uint64_t*>(smem);
+    const int tid = threadIdx.x;
+    const uint32_t g = blockIdx.x, q = blockIdx.y;
+    const uint32_t l0 = g * p.F;
+    const uint32_t nl = min(p.F, p.lists_in - l0);
+    const uint32_t total = nl * p.kcap;
+    const uint64_t* src = p.in + ((size_t)q * p.lists_in + l0) * p.kcap;
+    for (uint32_t i = tid; i < p.P; i += 256) buf[i] = i < total ? src[i] : kPadComposite;
+    __syncthreads();
+    if (nl > 1 || !FINAL) bitonic_sort_u64(buf, p.P, tid, 256);
+    if constexpr (FINAL) {
+        for (uint32_t i = tid; i < p.k; i += 256) write_result(buf[i], q * p.k + i, p);
+    } else {
+        uint64_t* dst = p.out + ((size_t)q * gridDim.x + g) * p.kcap;
+        for (uint32_t i = tid; i < p.kcap; i += 256) dst[i] = buf[i];
+    }
+}
+
+// Cross-shard merge of formatted results: entries are (key u32, global idx u64)
+// with the source slot as payload.  grid (nq); block 256.
+__global__ void __launch_bounds__(256) merge_shards_kernel(ShardMergeParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint64_t* idx = reinterpret_cast<uint64_t*>(smem);          // [P]
+    uint32_t* key = reinterpret_cast<uint32_t*>(idx + p.P);     // [P]
+    uint32_t* slot = key + p.P;                                 // [P]
+    const int tid = threadIdx.x;
+    const uint32_t q = blockIdx.x;
+    const uint32_t total = p.nlists * p.k;
+    const bool use_raw = key_is_raw(p.dtype, p.metric) && p.raw != nullptr;
+    for (uint32_t i = tid; i < p.P; i += 256) {
+        uint64_t id = ~0ull;
+        uint32_t ky = kNanKey, sl = 0;
+        if (i < total) {
+            const uint32_t l = i / p.k, j = i % p.k;
+            sl = (l * p.nq + q) * p.k + j;
+            id = p.indices[sl];
+            if (id != ~0ull) ky = use_raw ? key_from_raw(p.raw[sl], p.metric) : key_from_score(p.scores[sl], p.metric);
+        }
+        idx[i] = id;
+        key[i] = ky;
+        slot[i] = sl;
+    }
+    __syncthreads();
+    for (uint32_t size = 2; size <= p.P; size <<= 1) {
+        for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
+            for (uint32_t t = tid; t < (p.P >> 1); t += 256) {
+                uint32_t i = 2 * t - (t & (stride - 1));
+                uint32_t j = i + stride;
+                bool up = (i & size) == 0;
+                uint32_t ka = key[i], kb = key[j];
+                uint64_t ia = idx[i], ib = idx[j];
+                bool gt = ka > kb || (ka == kb && ia > ib);
+                if (gt == up) {
+                    key[i] = kb; key[j] = ka;
+                    idx[i] = ib; idx[j] = ia;
+                    uint32_t sa = slot[i]; slot[i] = slot[j]; slot[j] = sa;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    for (uint32_t i = tid; i < p.k; i += 256) {
+        const uint32_t o = q * p.k + i;
+        if (idx[i] == ~0ull) {
+            p.out_scores[o] = pad_score(p.metric);
+            p.out_indices[o] = ~0ull;
+            if (p.out_raw) p.out_raw[o] = 0;
+        } else {
+            p.out_scores[o] = p.scores[slot[i]];
+            p.out_indices[o] = idx[i];
+            if (p.out_raw) p.out_raw[o] = p.raw ? p.raw[slot[i]] : 0;
+        }
+    }
+}
+
+// One thread per 16-B device vector: (row, v) -> up to 16/ES elements.
+__global__ void synth_rows_kernel(unsigned char* rows, uint64_t nvec, uint32_t V, uint32_t dim, uint32_t pitch,
+                                  uint8_t dtype, uint64_t base, uint64_t row0) {
+    const uint32_t es = elem_size(dtype);
+    const uint32_t epv = 16 / es;
+    for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < nvec; t += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t r = t / V;
+        const uint32_t v = (uint32_t)(t % V);
+        uint32_t w[4] = {0, 0, 0, 0};
+        for (uint32_t e = 0; e < epv; e++) {
+            const uint32_t c = v * epv + e;
+            if (c >= dim) break;
+            const uint64_t u = mix64(base + (r + row0) * dim + c);
+            if (dtype == MVF_DTYPE_FLOAT32) {
+                w[e] = __float_as_uint(synth_f32(u));
+            } else if (dtype == MVF_DTYPE_FLOAT16) {
+                const uint32_t h = __half_as_ushort(__float2half_rn(synth_f32(u)));
+                w[e >> 1] |= h << (16 * (e & 1));
+            } else {
+                w[e >> 2] |= (uint32_t)(uint8_t)(u >> 56) << (8 * (e & 3));
+            }
+        }
+        *reinterpret_cast<uint4*>(rows + r * pitch + (size_t)v * 16) = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+}
+
+// Tightly packed elements (queries): one thread per element.
+__global__ void synth_packed_kernel(void* out, uint64_t nelem, uint8_t dtype, uint64_t base) {
+    for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < nelem; t += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t u = mix64(base + t);
+        if (dtype == MVF_DTYPE_FLOAT32) reinterpret_cast<float*>(out)[t] = synth_f32(u);
+        else if (dtype == MVF_DTYPE_FLOAT16) reinterpret_cast<__half*>(out)[t] = __float2half_rn(synth_f32(u));
+        else reinterpret_cast<uint8_t*>(out)[t] = (uint8_t)(u >> 56);
+    }
+}
+
+}  // namespace
+
+hipError_t launch_merge_lists(const MergeParams& p, uint32_t groups_out, uint32_t nq, bool final_stage, hipStream_t s) {
+    dim3 grid(groups_out, nq);
+    const size_t lds = (size_t)p.P * 8;
+    if (final_stage) hipLaunchKernelGGL(merge_lists_kernel<true>, grid, dim3(256), lds, s, p);
+    else hipLaunchKernelGGL(merge_lists_kernel<false>, grid, dim3(256), lds, s, p);
+    return hipGetLastError();
+}
+
+hipError_t launch_merge_shards(const ShardMergeParams& p, hipStream_t s) {
+    const size_t lds = (size_t)p.P * 16;
+    hipLaunchKernelGGL(merge_shards_kernel, dim3(p.nq), dim3(256), lds, s, p);
+    return hipGetLastError();
+}
+
+hipError_t launch_synth_rows(unsigned char* rows, uint64_t n, uint32_t dim, uint32_t pitch, uint8_t dtype,
+                             uint64_t seed, uint64_t row0, hipStream_t s) {
+    const uint32_t V = pitch / 16;
+    const uint64_t nvec = n * V;
+    if (nvec == 0) return hipSuccess;
+    const uint64_t blocks = (nvec + 255) / 256;
+    hipLaunchKernelGGL(synth_rows_kernel, dim3((unsigned)(blocks < 65536 ? blocks : 65536)), dim3(256), 0, s, rows, nvec,
+                       V, dim, pitch, dtype, mix64(seed), row0);
+    return hipGetLastError();
+}
+
+hipError_t launch_synth_packed(void* out, uint64_t nelem, uint8_t dtype, uint64_t seed, hipStream_t s) {
+    if (nelem == 0) return hipSuccess;
+    const uint64_t blocks = (nelem + 255) / 256;
+    hipLaunchKernelGGL(synth_packed_kernel, dim3((unsigned)(blocks < 65536 ? blocks : 65536)), dim3(256), 0, s, out,
+                       nelem, dtype, mix64(seed));
+    return hipGetLastError();
+}
+
+}  // namespace mvf

@@ -1,0 +1,48 @@
+// scan_stream.h — launch interface of K1 (scan_stream.inc).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mvf {
+
+struct ScanParams {
+    const unsigned char* rows;  // device rows, `pitch` bytes apart, 16-B aligned
+    const void* queries;        // device [nq_total][dim]: f32, or the space's int type
+    uint64_t* cand;             // out: [launch queries][gridDim.x][kcap] sorted composites
+    uint32_t n;                 // rows in the shard
+    uint32_t pitch;             // bytes per device row (multiple of 16)
+    uint32_t dim;
+    uint32_t V;                 // pitch / 16
+    uint32_t J;                 // ceil(V / G): 16-B steps per lane per row
+    uint32_t q0;                // first query handled by this launch
+    uint32_t nq_total;
+    uint32_t k;
+    uint32_t kcap;              // next_pow2(k): entries per emitted list
+    uint32_t pmax;              // next_pow2(k + chunk_rows): LDS buffer entries per query
+    uint32_t chunk_rows;
+    uint32_t nchunks;
+};
+
+// nqv: queries per launch, 1 or 4
+#define MVF_DECL_SCAN(dt)                                                                          \
+    hipError_t scan_stream_launch_dt##dt(const ScanParams& p, int metric, int G, int nqv, dim3 grid, \
+                                         size_t lds, hipStream_t s);                               \
+    const void* scan_stream_kernel_ptr_dt##dt(int metric, int G, int nqv);
+MVF_DECL_SCAN(0)
+MVF_DECL_SCAN(1)
+MVF_DECL_SCAN(2)
+MVF_DECL_SCAN(3)
+#undef MVF_DECL_SCAN
+
+// rows per chunk for a lane-group width G (multiple of the 16*64/G rows a block covers per step)
+inline uint32_t scan_chunk_rows(int G) { return G == 1 ? 1024u : 512u; }
+
+// bytes of dynamic LDS the kernel carves
+inline size_t scan_lds_bytes(int dtype, int G, uint32_t J, int nqv, uint32_t pmax) {
+    const uint32_t qb = (dtype == 0) ? 16u : (dtype == 1) ? 32u : 16u;
+    size_t q = ((size_t)nqv * J * G * qb + 15u) & ~(size_t)15u;
+    return q + (size_t)nqv * pmax * 8u + (size_t)nqv * 32u;
+}
+
+}  // namespace mvf
