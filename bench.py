@@ -1,0 +1,217 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the MVF brute-force similarity-search path.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+Workload (BASELINE.json configs[1]): 10M x 768 Float32, cosine, ONE query,
+top-100 — the HBM-bound streaming scan.  A "step" = one search of the whole
+resident corpus: query already on the device, kernels + on-device top-k,
+results left on the device.  Corpus upload / generation is outside the timed
+region (it is done once; DESIGN.md §7 gives the PCIe-inclusive figure).
+
+N > 1 is WEAK scaling: every rank holds its own 10M-row shard of an N*10M-row
+corpus (row range sharding, metrovector_amd/sharded.py); a step adds the RCCL
+all-gather of the per-shard top-k and the merge.  value = all rows of all
+ranks * nq / time.
+
+One JSON line on rank 0; `roofline` prices the streaming-scan kernel against
+8 TB/s HBM3E using HIP events recorded on the kernel's own stream during the
+timed steps; `cpu_baseline` times the oracle's faithful single-thread
+restatement of the reference loop on a bounded sample.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+SEED = 0x4D564631  # "MVF1"
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--rows", type=int, default=10_000_000, help="rows per GPU")
+    ap.add_argument("--dim", type=int, default=768)
+    ap.add_argument("--dtype", type=int, default=0, help="schema DataType code (0 f32, 1 f16, 2 i8, 3 u8)")
+    ap.add_argument("--metric", type=int, default=2, help="schema DistanceMetric code (0 L2, 1 dot, 2 cosine)")
+    ap.add_argument("--queries", type=int, default=1)
+    ap.add_argument("--k", type=int, default=100)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-recall", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-baseline budget")
+    return ap.parse_args()
+
+
+def cpu_baseline(args, oracle):
+    """Faithful single-thread restatement of the reference loop
+    (examples/similarity_search.rs:140-176: per-row address math, as_f32
+    alloc+decode, strict serial f32 L2 + sqrt, BinaryHeap) on a bounded
+    sample of the same corpus.  The reference computes L2 only, so the CPU
+    leg is L2 whatever --metric says; its cost per row is the same."""
+    if args.dtype not in (0, 1):
+        return None
+    chunk = 250_000
+    buf = np.empty((chunk, args.dim), oracle.NP_DTYPE[args.dtype])
+    q = oracle.synth_queries(SEED + 1, 1, args.dim, args.dtype)[0]
+    rows_done, spent = 0, 0.0
+    while spent < args.cpu_seconds and rows_done < args.rows:
+        n = min(chunk, args.rows - rows_done)
+        rows = oracle.synth_rows(SEED, rows_done, n, args.dim, args.dtype, out=buf)
+        t0 = time.perf_counter()
+        oracle.find_top_k_similar_faithful(rows, n, args.dim, args.dtype, q, args.k, False)
+        spent += time.perf_counter() - t0
+        rows_done += n
+    return {"value": rows_done / spent, "unit": "distance-ops/s", "cores": 1, "kind": "port",
+            "sample": f"first {rows_done} rows of the same synthetic corpus, dim {args.dim}, L2 (the only metric the "
+                      f"reference computes), k={args.k}, oracle faithful restatement single-threaded, {spent:.1f} s of CPU work"}
+
+
+def oracle_topk_full(args, oracle, q):
+    """Exact oracle top-k over the whole N=1 corpus, streamed in chunks (OpenMP)."""
+    chunk = 250_000
+    buf = np.empty((chunk, args.dim), oracle.NP_DTYPE[args.dtype])
+    S, I = [], []
+    for r0 in range(0, args.rows, chunk):
+        n = min(chunk, args.rows - r0)
+        rows = oracle.synth_rows(SEED, r0, n, args.dim, args.dtype, out=buf)
+        sc, idx, _ = oracle.search(rows, args.dtype, args.metric, q, args.k, index_base=r0)
+        S.append(sc)
+        I.append(idx)
+    sc, idx, _ = oracle.merge_topk(np.stack(S), np.stack(I), None, args.metric, 0 if args.dtype in (0, 1) else args.dtype)
+    return sc, idx
+
+
+def main():
+    args = parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N with N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+
+    import torch
+    import torch.distributed as dist
+    from metrovector_amd import gpu as G
+    from metrovector_amd.sharded import ShardedSearcher
+
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU: metrovector_amd has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    # ---- resident corpus shard (untimed) -----------------------------------------
+    row0 = rank * args.rows
+    t0 = time.perf_counter()
+    corpus = G.GpuCorpus.synthetic(args.rows, args.dim, args.dtype, SEED, row0=row0, device=local_rank)
+    gen_s = time.perf_counter() - t0
+    searcher = ShardedSearcher(corpus)
+    qcode = G.query_dtype_code(args.dtype)
+    qdt = {0: torch.float32, 2: torch.int8, 3: torch.uint8}[qcode]
+    dq = torch.empty((args.queries, args.dim), dtype=qdt, device=f"cuda:{local_rank}")
+    from metrovector_amd import _lib
+    _lib.gpu_check(_lib.gpu().mvfgpu_synth_queries_device(dq.data_ptr(), args.queries, args.dim, args.dtype, SEED + 1,
+                                                          local_rank, None))
+    torch.cuda.synchronize()
+
+    def step():
+        return searcher.search(dq, args.k, args.metric)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    corpus.set_profiling(True)  # records HIP events around the scan kernel; never waits inside a step
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    tm = corpus.last_timing()
+    corpus.set_profiling(False)
+
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        total_rows = args.rows * world
+        ops = float(args.queries) * total_rows * args.steps
+        es = {0: 4, 1: 2, 2: 1, 3: 1}[args.dtype]
+        dtname = {0: "f32", 1: "f16", 2: "i8", 3: "u8"}[args.dtype]
+        mname = {0: "L2", 1: "dot", 2: "cosine"}[args.metric]
+        result = {
+            "metric": "distance-ops/sec",
+            "value": ops / elapsed,
+            "unit": "distance-ops/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": dtname,
+            "data": "synthetic",
+            "config": {"workload": f"{args.rows // 1_000_000}M x {args.dim} {dtname} {mname}, {args.queries} query, "
+                                   f"top-{args.k}, per GPU (BASELINE.json configs[1] at --gpus 1)",
+                       "rows_per_gpu": args.rows, "dim": args.dim, "queries": args.queries, "k": args.k,
+                       "metric": mname, "sharding": f"row-range x{world}" if world > 1 else "none"},
+        }
+        # ---- roofline of the dominant kernel (rank 0's shard) ---------------------------
+        alg_bytes = float(args.rows) * args.dim * es  # N*d*es per launch
+        if tm.samples and tm.scan_ms_avg > 0:
+            ach = alg_bytes / (tm.scan_ms_avg * 1e-3) / 1e9
+            result["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                  "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                                  "kernel": "scan_stream_kernel", "kernel_ms_avg": tm.scan_ms_avg,
+                                  "select_ms_avg": tm.select_ms_avg, "launches_timed": tm.samples,
+                                  "algorithmic_bytes_per_launch": alg_bytes}
+        result["corpus_generation_s"] = gen_s
+
+        if world == 1:
+            from oracle import mvf_oracle as oracle
+            oracle.build()
+            q = dq.cpu().numpy()
+            if not args.no_recall and args.queries <= 4:
+                t1 = time.perf_counter()
+                osc, oidx = oracle_topk_full(args, oracle, q)
+                gi = out[1].cpu().numpy().view(np.uint64)
+                hits = sum(len(set(a.tolist()) & set(b.tolist())) for a, b in zip(gi, oidx))
+                result["recall_at_k"] = hits / oidx.size
+                result["recall_oracle_s"] = time.perf_counter() - t1
+            if not args.no_cpu_baseline:
+                cb = cpu_baseline(args, oracle)
+                if cb:
+                    result["cpu_baseline"] = cb
+        print(json.dumps(result), flush=True)
+
+    corpus.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

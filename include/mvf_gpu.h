@@ -66,15 +66,20 @@ typedef struct mvfgpu_corpus_info {
 } mvfgpu_corpus_info;
 
 typedef struct mvfgpu_timing {
-    /* HIP-event times of the last search on the handle, milliseconds.
-     * Recorded only while mvfgpu_set_profiling(corpus, 1) is in effect. */
-    float scan_ms;     /* the dominant kernel: streaming or MFMA scan */
-    float select_ms;   /* candidate merge / top-k kernels */
-    float total_ms;    /* first launch -> last launch of the search */
+    /* HIP-event times of searches on the handle, milliseconds.  Events are
+     * recorded (never waited for) on the search's own stream while
+     * mvfgpu_set_profiling(corpus, 1) is in effect; mvfgpu_last_timing waits
+     * for the newest and reads them back. */
+    float scan_ms;     /* newest search: the dominant kernel (streaming or MFMA scan) */
+    float select_ms;   /* newest search: candidate select / top-k kernels */
+    float total_ms;    /* newest search: scan_ms + select_ms */
+    float scan_ms_avg;   /* mean over the (up to 64) newest profiled searches */
+    float select_ms_avg;
+    uint32_t samples;    /* searches averaged */
     uint32_t scan_kernel; /* 1 = streaming (K1), 2 = MFMA batched (K2) */
-    uint32_t scan_launches;
-    uint64_t scan_bytes; /* algorithmic bytes read by the scan launches */
-    uint64_t scan_flops; /* algorithmic flops (2*nq*rows*dim) */
+    uint32_t scan_launches; /* scan launches of one search (timing covers the first) */
+    uint64_t scan_bytes; /* algorithmic bytes one scan launch reads */
+    uint64_t scan_flops; /* algorithmic flops of one scan launch (2*nq*rows*dim) */
 } mvfgpu_timing;
 
 /* ---- library / device ---------------------------------------------------- */

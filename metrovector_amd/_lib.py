@@ -28,6 +28,7 @@ class CorpusInfo(C.Structure):
 
 class Timing(C.Structure):
     _fields_ = [("scan_ms", C.c_float), ("select_ms", C.c_float), ("total_ms", C.c_float),
+                ("scan_ms_avg", C.c_float), ("select_ms_avg", C.c_float), ("samples", C.c_uint32),
                 ("scan_kernel", C.c_uint32), ("scan_launches", C.c_uint32), ("scan_bytes", C.c_uint64),
                 ("scan_flops", C.c_uint64)]
 
@@ -82,6 +83,84 @@ def gpu() -> C.CDLL:
         getattr(lib, name).restype = C.c_int
     _gpu = lib
     return lib
+
+
+class DataBlock(C.Structure):
+    _fields_ = [("offset", C.c_uint64), ("size", C.c_uint64), ("compression", C.c_uint8),
+                ("compressed_size", C.c_uint64), ("checksum", C.c_uint32)]
+
+
+class CVectorSpace(C.Structure):
+    _fields_ = [("reader", C.c_void_p), ("index", C.c_uint32), ("name", C.c_void_p), ("name_len", C.c_uint32),
+                ("dimension", C.c_uint32), ("total_vectors", C.c_uint64), ("vector_type", C.c_uint8),
+                ("distance_metric", C.c_uint8), ("data_type", C.c_uint8), ("index_type", C.c_uint8),
+                ("vectors_block_index", C.c_uint32), ("vector_ids_block_index", C.c_uint32),
+                ("has_sparse_metadata", C.c_uint8), ("has_tombstones", C.c_uint8)]
+
+
+class CVectorSlice(C.Structure):
+    _fields_ = [("data", C.c_void_p), ("stride", C.c_uint64), ("count", C.c_uint64), ("data_type", C.c_uint8)]
+
+
+def host() -> C.CDLL:
+    """libmvf_host.so (C++ MVF reader/writer)."""
+    global _host
+    if _host is not None:
+        return _host
+    if not os.path.exists(HOST_LIB_PATH):
+        raise ImportError(f"{HOST_LIB_PATH} is missing — build it with `make -C metrovector_amd/csrc host`")
+    lib = C.CDLL(HOST_LIB_PATH)
+    vp, u64, u32, u8, i32 = C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint8, C.c_int
+    pp = C.POINTER(C.c_void_p)
+    lib.mvf_last_error_message.restype = C.c_char_p
+    lib.mvf_strerror.restype = C.c_char_p
+    lib.mvf_strerror.argtypes = [i32]
+    lib.mvf_reader_open.argtypes = [C.c_char_p, pp]
+    lib.mvf_reader_open_bytes.argtypes = [vp, u64, pp]
+    lib.mvf_reader_close.restype = None
+    lib.mvf_reader_close.argtypes = [vp]
+    lib.mvf_reader_version.argtypes = [vp, C.POINTER(C.c_uint16)]
+    lib.mvf_reader_num_vector_spaces.argtypes = [vp, C.POINTER(u64)]
+    lib.mvf_reader_vector_space_name.argtypes = [vp, u64, pp, C.POINTER(u32)]
+    lib.mvf_reader_vector_space.argtypes = [vp, C.c_char_p, C.POINTER(CVectorSpace)]
+    lib.mvf_reader_vector_space_at.argtypes = [vp, u64, C.POINTER(CVectorSpace)]
+    lib.mvf_reader_file_size.argtypes = [vp, C.POINTER(u64)]
+    lib.mvf_reader_has_metadata.argtypes = [vp, C.POINTER(i32)]
+    lib.mvf_reader_num_metadata_columns.argtypes = [vp, C.POINTER(u64)]
+    lib.mvf_reader_metadata_column_name.argtypes = [vp, u64, pp, C.POINTER(u32)]
+    lib.mvf_reader_num_blocks.argtypes = [vp, C.POINTER(u64)]
+    lib.mvf_reader_block.argtypes = [vp, u64, C.POINTER(DataBlock)]
+    lib.mvf_reader_validate.argtypes = [vp]
+    lib.mvf_reader_validate_with_checksum.argtypes = [vp]
+    lib.mvf_space_get_vector.argtypes = [C.POINTER(CVectorSpace), u64, pp, C.POINTER(u64)]
+    lib.mvf_space_map_vector_range.argtypes = [C.POINTER(CVectorSpace), u64, u64, C.POINTER(CVectorSlice)]
+    lib.mvf_vector_as_f32.argtypes = [vp, u64, u8, vp, u64, C.POINTER(u64)]
+    lib.mvf_builder_new.argtypes = [pp]
+    lib.mvf_builder_free.restype = None
+    lib.mvf_builder_free.argtypes = [vp]
+    lib.mvf_builder_add_vector_space.argtypes = [vp, C.c_char_p, u32, u8, u8, u8, C.POINTER(u64)]
+    lib.mvf_builder_add_vectors_f32.argtypes = [vp, C.c_char_p, vp, u64, u32]
+    lib.mvf_builder_add_vectors_raw.argtypes = [vp, C.c_char_p, vp, u64, u32]
+    lib.mvf_builder_add_metadata_column.argtypes = [vp, C.c_char_p, u8, vp, u64]
+    lib.mvf_builder_to_bytes.argtypes = [vp, u32, pp, C.POINTER(u64)]
+    lib.mvf_builder_save.argtypes = [vp, C.c_char_p, u32]
+    lib.mvf_free.restype = None
+    lib.mvf_free.argtypes = [vp]
+    lib.mvf_crc32.restype = u32
+    lib.mvf_crc32.argtypes = [vp, u64]
+    lib.mvf_f32_to_f16.restype = C.c_uint16
+    lib.mvf_f32_to_f16.argtypes = [C.c_float]
+    lib.mvf_f16_to_f32.restype = C.c_float
+    lib.mvf_f16_to_f32.argtypes = [C.c_uint16]
+    _host = lib
+    return lib
+
+
+def host_check(status: int) -> None:
+    if status != 0:
+        from .errors import raise_for_status
+        msg = host().mvf_last_error_message().decode("utf-8", "replace")
+        raise_for_status(status, msg or host().mvf_strerror(status).decode())
 
 
 def gpu_check(status: int) -> None:

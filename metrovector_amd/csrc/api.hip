@@ -81,7 +81,7 @@ struct mvfgpu_corpus {
 
     mutable std::mutex mu;       // guards the scratch + timing state
     mutable std::mutex host_mu;  // serialises the host-buffer API's device mirrors
-    mutable DevBuf cand, stage[2];        // scratch of the search pipeline
+    mutable DevBuf cand;                  // scratch: per-block candidate lists
     mutable DevBuf h_q, h_s, h_i, h_r;    // device mirrors for the host-buffer API
     mutable hipStream_t own_stream = nullptr;
     mutable hipEvent_t ev_done = nullptr;
@@ -90,7 +90,13 @@ struct mvfgpu_corpus {
 
     bool profiling = false;
     int scan_path = 0;
-    mutable hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+    struct ProfSlot {
+        hipEvent_t e[3] = {nullptr, nullptr, nullptr};
+        bool scanned = false;
+    };
+    static constexpr int kProfSlots = 64;
+    mutable ProfSlot prof[kProfSlots];
+    mutable uint64_t prof_next = 0;  // searches profiled since profiling was switched on
     mutable mvfgpu_timing timing{};
 };
 
@@ -120,7 +126,6 @@ int init_common(mvfgpu_corpus* c) {
     c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     HIP_TRY(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
     HIP_TRY(hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming));
-    for (auto& e : c->ev) HIP_TRY(hipEventCreate(&e));
     return MVF_OK;
 }
 
@@ -162,42 +167,6 @@ const void* scan_kernel(uint8_t dtype, int metric, int G, int nqv) {
     }
 }
 
-// Reduce [nqv][lists][kcap] sorted lists to the final [nqv][k] results.
-int run_merges(const mvfgpu_corpus* c, const uint64_t* lists, uint32_t nlists, uint32_t nqv, uint32_t k,
-               uint32_t kcap, uint8_t metric, float* d_scores, uint64_t* d_indices, int32_t* d_raw,
-               hipStream_t s) {
-    const uint32_t F = std::max(2u, kMergeMaxEntries / kcap);
-    const uint64_t* in = lists;
-    uint32_t lists_in = nlists;
-    int pp = 0;
-    for (;;) {
-        const uint32_t groups = lists_in == 0 ? 1 : (lists_in + F - 1) / F;
-        MergeParams mp{};
-        mp.in = in;
-        mp.lists_in = lists_in;
-        mp.kcap = kcap;
-        mp.F = F;
-        mp.P = next_pow2(std::max(2u, std::min(F, std::max(1u, lists_in)) * kcap));
-        if (groups == 1) {
-            mp.k = k;
-            mp.metric = metric;
-            mp.dtype = c->dtype;
-            mp.index_base = c->index_base;
-            mp.out_scores = d_scores;
-            mp.out_indices = d_indices;
-            mp.out_raw = d_raw;
-            HIP_TRY(launch_merge_lists(mp, 1, nqv, true, s));
-            return MVF_OK;
-        }
-        HIP_TRY(c->stage[pp].reserve((size_t)nqv * groups * kcap * 8));
-        mp.out = static_cast<uint64_t*>(c->stage[pp].p);
-        HIP_TRY(launch_merge_lists(mp, groups, nqv, false, s));
-        in = mp.out;
-        lists_in = groups;
-        pp ^= 1;
-    }
-}
-
 int search_stream_path(const mvfgpu_corpus* c, uint8_t metric, const void* d_queries, uint32_t nq, uint32_t k,
                        float* d_scores, uint64_t* d_indices, int32_t* d_raw, hipStream_t s) {
     const uint32_t kcap = next_pow2(k);
@@ -208,8 +177,14 @@ int search_stream_path(const mvfgpu_corpus* c, uint8_t metric, const void* d_que
 
     mvfgpu_timing tm{};
     tm.scan_kernel = 1;
-    float scan_ms = 0, select_ms = 0;
     bool first = true;
+    mvfgpu_corpus::ProfSlot* ps = nullptr;
+    if (c->profiling) {
+        ps = &c->prof[c->prof_next % mvfgpu_corpus::kProfSlots];
+        for (auto& e : ps->e)
+            if (!e) HIP_TRY(hipEventCreate(&e));
+        ps->scanned = false;
+    }
 
     for (uint32_t q0 = 0; q0 < nq;) {
         int nqv = (nq - q0) >= 2 ? 4 : 1;
@@ -248,34 +223,39 @@ int search_stream_path(const mvfgpu_corpus* c, uint8_t metric, const void* d_que
             sp.pmax = pmax;
             sp.chunk_rows = chunk_rows;
             sp.nchunks = nchunks;
-            if (c->profiling && first) HIP_TRY(hipEventRecord(c->ev[0], s));
+            if (ps && first) HIP_TRY(hipEventRecord(ps->e[0], s));
             HIP_TRY(scan_launch(c->dtype, sp, metric, G, nqv, dim3(nblocks), lds, s));
-            if (c->profiling && first) HIP_TRY(hipEventRecord(c->ev[1], s));
-            tm.scan_launches++;
-            tm.scan_bytes += (uint64_t)c->n * c->dim * elem_size(c->dtype);
-            tm.scan_flops += 2ull * nq_here * c->n * c->dim;
-        }
-        int rc = run_merges(c, static_cast<const uint64_t*>(c->cand.p), nblocks, nq_here, k, kcap, metric,
-                            d_scores + (size_t)q0 * k, d_indices + (size_t)q0 * k,
-                            d_raw ? d_raw + (size_t)q0 * k : nullptr, s);
-        if (rc != MVF_OK) return rc;
-        if (c->profiling && first) {
-            HIP_TRY(hipEventRecord(c->ev[2], s));
-            HIP_TRY(hipEventSynchronize(c->ev[2]));
-            if (nchunks > 0) {
-                HIP_TRY(hipEventElapsedTime(&scan_ms, c->ev[0], c->ev[1]));
-                HIP_TRY(hipEventElapsedTime(&select_ms, c->ev[1], c->ev[2]));
+            if (ps && first) {
+                HIP_TRY(hipEventRecord(ps->e[1], s));
+                ps->scanned = true;
+                tm.scan_bytes = (uint64_t)c->n * c->dim * elem_size(c->dtype);
+                tm.scan_flops = 2ull * nq_here * c->n * c->dim;
             }
+            tm.scan_launches++;
         }
+        {
+            SelectParams fp{};
+            fp.lists = static_cast<const uint64_t*>(c->cand.p);
+            fp.nlists = nblocks;
+            fp.kcap = kcap;
+            fp.heads = nblocks ? (k + nblocks - 1) / nblocks : 1;
+            fp.P = 4096;  // 32 KiB of LDS: >= k + kcap (fold path) and >= nlists*heads (nlists <= 2048)
+            fp.k = k;
+            fp.metric = metric;
+            fp.dtype = c->dtype;
+            fp.index_base = c->index_base;
+            fp.out_scores = d_scores + (size_t)q0 * k;
+            fp.out_indices = d_indices + (size_t)q0 * k;
+            fp.out_raw = d_raw ? d_raw + (size_t)q0 * k : nullptr;
+            HIP_TRY(launch_select_final(fp, nq_here, s));
+        }
+        if (ps && first) HIP_TRY(hipEventRecord(ps->e[2], s));
         first = false;
         q0 += nq_here;
     }
-    if (c->profiling) {
-        // scan_ms / select_ms are those of the FIRST launch group (one group when nq <= 4)
-        tm.scan_ms = scan_ms;
-        tm.select_ms = select_ms;
-        tm.total_ms = scan_ms + select_ms;
-        c->timing = tm;
+    if (ps) {
+        c->timing = tm;  // event times are read back lazily by mvfgpu_last_timing
+        c->prof_next++;
     }
     return MVF_OK;
 }
@@ -428,16 +408,15 @@ void mvfgpu_corpus_destroy(mvfgpu_corpus* c) {
         (void)hipDeviceSynchronize();
         if (c->d_rows) (void)hipFree(c->d_rows);
         c->cand.release();
-        c->stage[0].release();
-        c->stage[1].release();
         c->h_q.release();
         c->h_s.release();
         c->h_i.release();
         c->h_r.release();
         if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
         if (c->ev_done) (void)hipEventDestroy(c->ev_done);
-        for (auto& e : c->ev)
-            if (e) (void)hipEventDestroy(e);
+        for (auto& ps : c->prof)
+            for (auto& e : ps.e)
+                if (e) (void)hipEventDestroy(e);
     }
     delete c;
 }
@@ -452,7 +431,7 @@ int mvfgpu_corpus_get_info(const mvfgpu_corpus* c, mvfgpu_corpus_info* out) {
     out->data_type = c->dtype;
     out->device = c->device;
     std::lock_guard<std::mutex> lk(c->mu);
-    out->device_bytes = c->rows_bytes + c->cand.bytes + c->stage[0].bytes + c->stage[1].bytes + c->h_q.bytes +
+    out->device_bytes = c->rows_bytes + c->cand.bytes + c->h_q.bytes +
                         c->h_s.bytes + c->h_i.bytes + c->h_r.bytes;
     return MVF_OK;
 }
@@ -611,13 +590,43 @@ int mvfgpu_set_profiling(mvfgpu_corpus* c, int enabled) {
     if (!c) return fail(MVF_ERR_INVALID_ARGUMENT, "corpus is NULL");
     std::lock_guard<std::mutex> lk(c->mu);
     c->profiling = enabled != 0;
+    c->prof_next = 0;
+    c->timing = mvfgpu_timing{};
     return MVF_OK;
 }
 
 int mvfgpu_last_timing(const mvfgpu_corpus* c, mvfgpu_timing* out) {
     if (!c || !out) return fail(MVF_ERR_INVALID_ARGUMENT, "NULL argument");
     std::lock_guard<std::mutex> lk(c->mu);
-    *out = c->timing;
+    mvfgpu_timing tm = c->timing;
+    if (c->prof_next > 0) {
+        DeviceGuard guard(c->device);
+        const uint64_t newest = c->prof_next - 1;
+        const uint64_t oldest = c->prof_next > mvfgpu_corpus::kProfSlots ? c->prof_next - mvfgpu_corpus::kProfSlots : 0;
+        double ssum = 0, lsum = 0;
+        uint32_t cnt = 0;
+        for (uint64_t i = newest + 1; i-- > oldest;) {
+            const auto& ps = c->prof[i % mvfgpu_corpus::kProfSlots];
+            HIP_TRY(hipEventSynchronize(ps.e[2]));
+            float a = 0, b = 0;
+            if (ps.scanned) {
+                HIP_TRY(hipEventElapsedTime(&a, ps.e[0], ps.e[1]));
+                HIP_TRY(hipEventElapsedTime(&b, ps.e[1], ps.e[2]));
+            }
+            if (i == newest) {
+                tm.scan_ms = a;
+                tm.select_ms = b;
+                tm.total_ms = a + b;
+            }
+            ssum += a;
+            lsum += b;
+            cnt++;
+        }
+        tm.samples = cnt;
+        tm.scan_ms_avg = cnt ? (float)(ssum / cnt) : 0.f;
+        tm.select_ms_avg = cnt ? (float)(lsum / cnt) : 0.f;
+    }
+    *out = tm;
     return MVF_OK;
 }
 

@@ -6,20 +6,18 @@
 
 namespace mvf {
 
-struct MergeParams {
-    const uint64_t* in;   // [nq][lists_in][kcap] sorted composites (pad = ~0)
-    uint64_t* out;        // non-final: [nq][groups_out][kcap]
-    uint32_t lists_in;
+struct SelectParams {
+    const uint64_t* lists;  // [nq][nlists][kcap] composites, each list sorted ascending, ~0-padded
+    uint32_t nlists;
     uint32_t kcap;
-    uint32_t F;           // lists merged per block
-    uint32_t P;           // next_pow2(F * kcap), LDS entries
-    // final stage only
+    uint32_t heads;         // entries taken from each list for the threshold: ceil(k / nlists), >= 1
+    uint32_t P;             // LDS capacity in entries (power of two, >= max(2*k, nlists*heads))
     uint32_t k;
     uint8_t metric, dtype;
     uint64_t index_base;
-    float* out_scores;    // [nq][k]
+    float* out_scores;      // [nq][k]
     uint64_t* out_indices;
-    int32_t* out_raw;     // nullable
+    int32_t* out_raw;       // nullable
 };
 
 struct ShardMergeParams {
@@ -33,9 +31,9 @@ struct ShardMergeParams {
     int32_t* out_raw;         // nullable
 };
 
-constexpr uint32_t kMergeMaxEntries = 8192;  // LDS entries per merge block (64 KiB of u64)
+constexpr uint32_t kMergeMaxEntries = 8192;  // LDS entries per select / merge block (64 KiB of u64)
 
-hipError_t launch_merge_lists(const MergeParams& p, uint32_t groups_out, uint32_t nq, bool final_stage, hipStream_t s);
+hipError_t launch_select_final(const SelectParams& p, uint32_t nq, hipStream_t s);
 hipError_t launch_merge_shards(const ShardMergeParams& p, hipStream_t s);
 hipError_t launch_synth_rows(unsigned char* rows, uint64_t n, uint32_t dim, uint32_t pitch, uint8_t dtype,
                              uint64_t seed, uint64_t row0, hipStream_t s);

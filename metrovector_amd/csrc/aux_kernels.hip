@@ -6,6 +6,7 @@
 // composites (order key << 32 | local row) in LDS.
 
 #include "aux_kernels.h"
+#include "bitonic.h"
 #include "mvf_common.h"
 
 #include <hip/hip_fp16.h>
@@ -13,25 +14,7 @@
 namespace mvf {
 namespace {
 
-__device__ __forceinline__ void bitonic_sort_u64(uint64_t* buf, uint32_t P, int tid, int nthreads) {
-    for (uint32_t size = 2; size <= P; size <<= 1) {
-        for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
-            for (uint32_t t = tid; t < (P >> 1); t += nthreads) {
-                uint32_t i = 2 * t - (t & (stride - 1));
-                uint32_t j = i + stride;
-                bool up = (i & size) == 0;
-                uint64_t a = buf[i], b = buf[j];
-                if ((a > b) == up) {
-                    buf[i] = b;
-                    buf[j] = a;
-                }
-            }
-            __syncthreads();
-        }
-    }
-}
-
-__device__ __forceinline__ void write_result(uint64_t comp, uint32_t o, const MergeParams& p) {
+__device__ __forceinline__ void write_result(uint64_t comp, uint32_t o, const SelectParams& p) {
     const uint32_t key = (uint32_t)(comp >> 32);
     if (comp == kPadComposite) {
         p.out_scores[o] = pad_score(p.metric);
@@ -52,27 +35,72 @@ __device__ __forceinline__ void write_result(uint64_t comp, uint32_t o, const Me
     if (p.out_raw) p.out_raw[o] = raw;
 }
 
-// grid (groups_out, nq); block 256; dynamic LDS P*8.
-// in: [q][lists_in][kcap] sorted composites; block g merges lists [g*F, (g+1)*F).
-template <bool FINAL>
-__global__ void __launch_bounds__(256) merge_lists_kernel(MergeParams p) {
+// K3 final select.  grid (nq); block 1024; dynamic LDS P*8 + 16.
+// Input: nlists sorted lists per query (one per scan block).
+//   1. threshold: the k-th smallest of the lists' first `heads` entries is the
+//      k-th smallest of a subset of the corpus, hence >= the true k-th best.
+//      With the top-k spread over many lists it is almost exact.
+//   2. every list's prefix <= threshold is appended to LDS (one thread per
+//      list, usually 0-2 entries each);
+//   3. the survivors are bitonic-sorted and the first k formatted.
+// If the survivors overflow LDS (adversarial clustering) the lists are folded
+// group by group into a running top-k instead.
+__global__ void __launch_bounds__(1024) select_final_kernel(SelectParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint64_t* buf = reinterpret_cast<uint64_t*>(smem);
+    uint32_t* cnt = reinterpret_cast<uint32_t*>(buf + p.P);
     const int tid = threadIdx.x;
-    const uint32_t g = blockIdx.x, q = blockIdx.y;
-    const uint32_t l0 = g * p.F;
-    const uint32_t nl = min(p.F, p.lists_in - l0);
-    const uint32_t total = nl * p.kcap;
-    const uint64_t* src = p.in + ((size_t)q * p.lists_in + l0) * p.kcap;
-    for (uint32_t i = tid; i < p.P; i += 256) buf[i] = i < total ? src[i] : kPadComposite;
+    const uint32_t q = blockIdx.x;
+    const uint64_t* lists = p.lists + (size_t)q * p.nlists * p.kcap;
+
+    // 1. threshold from the list heads
+    const uint32_t H = p.nlists * p.heads;
+    const uint32_t HP = next_pow2(H < 2 ? 2 : H);
+    for (uint32_t i = tid; i < HP; i += 1024)
+        buf[i] = i < H ? lists[(size_t)(i / p.heads) * p.kcap + (i % p.heads)] : kPadComposite;
+    if (tid == 0) *cnt = 0;
     __syncthreads();
-    if (nl > 1 || !FINAL) bitonic_sort_u64(buf, p.P, tid, 256);
-    if constexpr (FINAL) {
-        for (uint32_t i = tid; i < p.k; i += 256) write_result(buf[i], q * p.k + i, p);
-    } else {
-        uint64_t* dst = p.out + ((size_t)q * gridDim.x + g) * p.kcap;
-        for (uint32_t i = tid; i < p.kcap; i += 256) dst[i] = buf[i];
+    bitonic_sort_u64<1024>(buf, HP, tid);
+    const uint64_t tau = (H >= p.k) ? buf[p.k - 1] : kPadComposite;
+    __syncthreads();
+
+    // 2. gather every list's prefix <= tau
+    for (uint32_t l = tid; l < p.nlists; l += 1024) {
+        const uint64_t* li = lists + (size_t)l * p.kcap;
+        for (uint32_t i = 0; i < p.kcap; i++) {
+            const uint64_t c = li[i];
+            if (c > tau || c == kPadComposite) break;
+            const uint32_t slot = atomicAdd(cnt, 1u);
+            if (slot < p.P) buf[slot] = c;
+        }
     }
+    __syncthreads();
+    uint32_t m = *cnt;
+    __syncthreads();
+
+    if (m <= p.P) {
+        const uint32_t P2 = next_pow2(m < 2 ? 2 : m);
+        for (uint32_t i = m + tid; i < P2; i += 1024) buf[i] = kPadComposite;
+        __syncthreads();
+        bitonic_sort_u64<1024>(buf, P2, tid);
+    } else {
+        // overflow: fold groups of lists into a running top-k (always fits: k + F*kcap <= P)
+        const uint32_t F = (p.P - p.k) / p.kcap;
+        uint32_t kcur = 0;
+        for (uint32_t l0 = 0; l0 < p.nlists; l0 += F) {
+            const uint32_t nl = min(F, p.nlists - l0);
+            __syncthreads();
+            for (uint32_t i = tid; i < nl * p.kcap; i += 1024) buf[kcur + i] = lists[(size_t)l0 * p.kcap + i];
+            const uint32_t tot = kcur + nl * p.kcap;
+            const uint32_t P2 = next_pow2(tot < 2 ? 2 : tot);
+            for (uint32_t i = tot + tid; i < P2; i += 1024) buf[i] = kPadComposite;
+            __syncthreads();
+            bitonic_sort_u64<1024>(buf, P2, tid);
+            kcur = tot < p.k ? tot : p.k;
+        }
+        m = kcur;
+    }
+    for (uint32_t i = tid; i < p.k; i += 1024) write_result(i < m ? buf[i] : kPadComposite, q * p.k + i, p);
 }
 
 // Cross-shard merge of formatted results: entries are (key u32, global idx u64)
@@ -170,11 +198,8 @@ __global__ void synth_packed_kernel(void* out, uint64_t nelem, uint8_t dtype, ui
 
 }  // namespace
 
-hipError_t launch_merge_lists(const MergeParams& p, uint32_t groups_out, uint32_t nq, bool final_stage, hipStream_t s) {
-    dim3 grid(groups_out, nq);
-    const size_t lds = (size_t)p.P * 8;
-    if (final_stage) hipLaunchKernelGGL(merge_lists_kernel<true>, grid, dim3(256), lds, s, p);
-    else hipLaunchKernelGGL(merge_lists_kernel<false>, grid, dim3(256), lds, s, p);
+hipError_t launch_select_final(const SelectParams& p, uint32_t nq, hipStream_t s) {
+    hipLaunchKernelGGL(select_final_kernel, dim3(nq), dim3(1024), (size_t)p.P * 8 + 16, s, p);
     return hipGetLastError();
 }
 

@@ -9,7 +9,7 @@ namespace mvf {
 struct ScanParams {
     const unsigned char* rows;  // device rows, `pitch` bytes apart, 16-B aligned
     const void* queries;        // device [nq_total][dim]: f32, or the space's int type
-    uint64_t* cand;             // out: [launch queries][gridDim.x][kcap] sorted composites
+    uint64_t* cand;             // out: [launch queries][gridDim.x][kcap] sorted composites, ~0-padded
     uint32_t n;                 // rows in the shard
     uint32_t pitch;             // bytes per device row (multiple of 16)
     uint32_t dim;

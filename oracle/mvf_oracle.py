@@ -149,8 +149,14 @@ def find_top_k_similar_faithful(block: bytes | np.ndarray, total_vectors: int, d
     return idx[: cnt.value].copy(), sc[: cnt.value].copy()
 
 
-def synth_rows(seed: int, row0: int, nrows: int, dim: int, dtype: int) -> np.ndarray:
-    out = np.empty((nrows, dim), NP_DTYPE[dtype])
+def synth_rows(seed: int, row0: int, nrows: int, dim: int, dtype: int, out: np.ndarray | None = None) -> np.ndarray:
+    """Rows [row0, row0+nrows) of the synthetic corpus.  `out` (C-contiguous,
+    right dtype, >= nrows rows) lets callers reuse one buffer across chunks."""
+    if out is None:
+        out = np.empty((nrows, dim), NP_DTYPE[dtype])
+    else:
+        assert out.dtype == NP_DTYPE[dtype] and out.flags.c_contiguous and out.shape[1] == dim and out.shape[0] >= nrows
+        out = out[:nrows]
     lib().mvfo_synth_rows(seed, row0, nrows, dim, dtype, _ptr(out))
     return out
 

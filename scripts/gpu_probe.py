@@ -18,7 +18,9 @@ def check(dt, metric, n, dim, nq, k, seed=7):
         ok = (r.indices == oidx).all() and (r.raw == oraw).all() and (r.scores.view(np.uint32) == osc.view(np.uint32)).all()
         return ok, 0.0
     # float: compare rank-wise scores, and index sets modulo near ties
-    err = np.max(np.abs(r.scores - osc) / np.maximum(np.abs(osc), 1e-6))
+    fin = np.isfinite(osc)
+    err = np.max(np.abs(r.scores[fin] - osc[fin]) / np.maximum(np.abs(osc[fin]), 1e-6)) if fin.any() else 0.0
+    if not (r.indices[~fin] == oidx[~fin]).all(): err = 1.0
     same = (r.indices == oidx).mean()
     return (err < 1e-5 and same > 0.98), err
 

@@ -1,0 +1,79 @@
+"""Shared comparison helpers for the parity tests."""
+import numpy as np
+
+PAD = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+# north_star tolerance: f32 L2 / cosine within 1e-5 relative.  Dot products and
+# cosines are compared relative to |q||x| (cancellation makes "relative to the
+# value" meaningless near 0) — SURVEY.md §8c.
+TOL = 1e-5
+
+
+def norms(rows_f32, q_f32):
+    return np.linalg.norm(rows_f32.astype(np.float64), axis=1), float(np.linalg.norm(q_f32.astype(np.float64)))
+
+
+def score_tolerance(metric, oracle_scores, rows_f32, q_f32, idx):
+    """Absolute tolerance per returned entry."""
+    if metric == 0:
+        return TOL * np.maximum(np.abs(oracle_scores), 1e-30)
+    if metric == 2:
+        return np.full(len(idx), TOL)
+    xn, qn = norms(rows_f32[idx], q_f32)
+    return TOL * np.maximum(xn * qn, 1e-30)
+
+
+def assert_float_topk(metric, got_scores, got_idx, all_scores, rows_f32, q_f32, k, index_base=0):
+    """GPU top-k of ONE query vs the oracle's score of every row.
+
+    all_scores: oracle f32 score per local row.  Checks: padding, uniqueness,
+    per-entry score within tolerance, best-first order, and set equality up to
+    rows whose oracle score is within tolerance of the k-th best."""
+    n = len(all_scores)
+    kk = min(k, n)
+    got_idx = np.asarray(got_idx)
+    assert (got_idx[kk:] == PAD).all(), "padding indices"
+    pad = np.inf if metric == 0 else -np.inf
+    assert (got_scores[kk:] == pad).all(), "padding scores"
+    li = (got_idx[:kk] - np.uint64(index_base)).astype(np.int64)
+    assert ((li >= 0) & (li < n)).all()
+    assert len(set(li.tolist())) == kk, "duplicate indices"
+    sc = got_scores[:kk].astype(np.float64)
+    ref = all_scores[li].astype(np.float64)
+    tol = score_tolerance(metric, ref, rows_f32, q_f32, li)
+    fin = np.isfinite(ref)
+    assert (np.abs(sc[fin] - ref[fin]) <= tol[fin]).all(), f"score mismatch max={np.max(np.abs(sc[fin]-ref[fin]))}"
+    sign = 1.0 if metric == 0 else -1.0
+    order = sign * sc
+    finite_order = order[np.isfinite(order)]
+    assert (np.diff(finite_order) >= 0).all(), "not sorted best-first"
+    # set equality modulo near-ties at the boundary
+    key = sign * all_scores.astype(np.float64)
+    key = np.where(np.isnan(key), np.inf, key)
+    kth = np.sort(key)[kk - 1] if kk else np.inf
+    if metric == 0:
+        btol = TOL * max(abs(kth), 1e-30)
+    elif metric == 2:
+        btol = TOL
+    else:
+        xn, qn = norms(rows_f32, q_f32)
+        btol = TOL * float(xn.max() * qn)
+    btol *= 2
+    must = set(np.nonzero(key < kth - btol)[0].tolist())
+    may = set(np.nonzero(key <= kth + btol)[0].tolist())
+    got = set(li.tolist())
+    assert must <= got, f"missing clear winners: {sorted(must - got)[:5]}"
+    assert got <= may, f"returned clear losers: {sorted(got - may)[:5]}"
+
+
+def assert_exact(res, osc, oidx, oraw):
+    """Integer spaces: bit-exact indices, raw integers and f32 score bits."""
+    assert (res.indices == oidx).all()
+    assert (res.raw == oraw).all()
+    assert (res.scores.view(np.uint32) == osc.view(np.uint32)).all()
+
+
+def recall_at_k(got_idx, ref_idx):
+    got_idx, ref_idx = np.asarray(got_idx), np.asarray(ref_idx)
+    hits = sum(len(set(g.tolist()) & set(r.tolist())) for g, r in zip(got_idx, ref_idx))
+    return hits / ref_idx.size

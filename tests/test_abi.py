@@ -1,0 +1,103 @@
+"""The C-ABI libraries load and export every symbol their headers declare;
+without a GPU the compute entry points refuse loudly (no CPU fallback).
+CPU only."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from metrovector_amd import _lib
+from metrovector_amd import errors as E
+from metrovector_amd import gpu as G
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared(header, prefix):
+    text = open(os.path.join(ROOT, "include", header)).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(%s\w+)\s*\(" % prefix, text)))
+
+
+def test_gpu_library_exports_header_symbols():
+    lib = _lib.gpu()
+    names = _declared("mvf_gpu.h", "mvfgpu_")
+    assert len(names) >= 15
+    for n in names:
+        assert hasattr(lib, n), f"libmvf_gpu.so does not export {n}"
+
+
+def test_host_library_exports_header_symbols():
+    lib = _lib.host()
+    names = _declared("mvf_file.h", "mvf_")
+    assert len(names) >= 30
+    for n in names:
+        assert hasattr(lib, n), f"libmvf_host.so does not export {n}"
+
+
+def test_struct_layouts_match_header():
+    assert C.sizeof(_lib.CorpusInfo) == 40
+    assert C.sizeof(_lib.Timing) == 48
+    assert C.sizeof(_lib.DataBlock) == 40
+
+
+def test_strerror_covers_reference_variants():
+    lib = _lib.gpu()
+    msgs = [lib.mvfgpu_strerror(i).decode() for i in range(13)]
+    assert msgs[5] == "Index out of bounds" and msgs[6] == "Dimension mismatch" and msgs[10] == "Build error"
+    assert len(set(msgs)) == 13
+
+
+def _no_gpu():
+    return G.device_count() == 0
+
+
+def test_no_cpu_fallback_without_device():
+    if not _no_gpu():
+        pytest.skip("a GPU is present")
+    rows = np.zeros((4, 4), np.float32)
+    with pytest.raises(E.DeviceError, match="no CPU fallback"):
+        G.GpuCorpus.from_array(rows)
+    with pytest.raises(E.DeviceError):
+        G.GpuCorpus.synthetic(10, 4, 0, 1)
+
+
+def test_argument_validation_precedes_device_use():
+    rows = np.zeros((4, 4), np.float32)
+    with pytest.raises(E.BuildError, match="Unsupported vector data type"):   # vector_space.rs:126
+        G.GpuCorpus.from_pointer(rows.ctypes.data, 4, 4, 6, 16)
+    with pytest.raises(E.InvalidArgument):
+        G.GpuCorpus.from_pointer(rows.ctypes.data, 4, 0, 0, 16)
+    with pytest.raises(E.BuildError, match="33025"):
+        G.GpuCorpus.from_pointer(rows.ctypes.data, 1, 40000, 2, 40000)
+    with pytest.raises(E.CorruptedData):
+        G.GpuCorpus.from_pointer(rows.ctypes.data, 4, 4, 0, 8)                # stride < row bytes
+
+
+@pytest.mark.parametrize("dtype,metric", [(0, 0), (0, 1), (0, 2), (2, 1), (3, 0), (2, 2)])
+def test_merge_topk_host_matches_oracle(oracle, dtype, metric):
+    rows = oracle.synth_rows(31, 0, 500, 24, dtype)
+    q = oracle.synth_queries(32, 4, 24, dtype)
+    k = 33
+    cuts = [0, 10, 170, 171, 500]
+    parts = [oracle.search(rows[a:b], dtype, metric, q, k, index_base=a) for a, b in zip(cuts[:-1], cuts[1:])]
+    S, I, R = (np.stack([p[j] for p in parts]) for j in range(3))
+    got = G.merge_topk_host(S, I, R, metric, dtype)
+    ws, wi, wr = oracle.search(rows, dtype, metric, q, k)
+    assert (got.indices == wi).all()
+    assert (got.scores.view(np.uint32) == ws.view(np.uint32)).all()
+    assert (got.raw == wr).all()
+
+
+def test_merge_topk_host_padding(oracle):
+    rows = oracle.synth_rows(1, 0, 5, 8, 0)
+    q = oracle.synth_queries(2, 1, 8, 0)
+    a = oracle.search(rows[:2], 0, 0, q, 4, index_base=0)
+    b = oracle.search(rows[2:], 0, 0, q, 4, index_base=2)
+    got = G.merge_topk_host(np.stack([a[0], b[0]]), np.stack([a[1], b[1]]), None, 0, 0)
+    ws, wi, _ = oracle.search(rows, 0, 0, q, 4)
+    assert (got.indices == wi).all()
+    got = G.merge_topk_host(a[0][None], a[1][None], None, 0, 0)
+    assert got.indices[0, 2] == np.uint64(0xFFFFFFFFFFFFFFFF) and got.scores[0, 2] == np.inf

@@ -1,0 +1,311 @@
+"""Parity of the HIP path (libmvf_gpu.so through its C ABI) against the CPU
+oracle — the -m gpu tier.  Bit-exact for Int8/UInt8; within 1e-5 for f32/f16
+(tolerances in tests/_util.py)."""
+import os
+
+import numpy as np
+import pytest
+
+from metrovector_amd import errors as E
+from metrovector_amd import gpu as G
+from tests._util import PAD, assert_exact, assert_float_topk, recall_at_k
+
+pytestmark = pytest.mark.gpu
+
+SEED = 0x4D564631  # "MVF1" 
+
+
+def _check(oracle, dtype, metric, rows, q, k, index_base=0):
+    with G.GpuCorpus.from_array(rows, index_base=index_base) as c:
+        res = c.search(q, k, metric)
+    q2 = q if q.ndim == 2 else q[None]
+    if dtype in (2, 3):
+        osc, oidx, oraw = oracle.search(rows, dtype, metric, q2, k, index_base=index_base)
+        assert_exact(res, osc, oidx, oraw)
+    else:
+        rows32 = rows.astype(np.float32)
+        for i in range(q2.shape[0]):
+            sc, _, _ = oracle.scores(rows, dtype, metric, q2[i])
+            assert_float_topk(metric, res.scores[i], res.indices[i], sc, rows32, q2[i], k, index_base)
+        assert (res.raw == 0).all()
+    return res
+
+
+@pytest.mark.parametrize("dtype", [0, 1, 2, 3])
+@pytest.mark.parametrize("metric", [0, 1, 2])
+@pytest.mark.parametrize("shape", [(1000, 128, 1, 10), (5000, 768, 3, 100), (777, 4, 1, 5), (3000, 13, 5, 7),
+                                   (100, 100, 2, 128), (2049, 48, 9, 33), (1, 16, 1, 1), (513, 1024, 2, 64)])
+def test_all_dtypes_metrics_shapes(oracle, dtype, metric, shape):
+    n, dim, nq, k = shape
+    rows = oracle.synth_rows(SEED, 0, n, dim, dtype)
+    q = oracle.synth_queries(SEED + 1, nq, dim, dtype)
+    _check(oracle, dtype, metric, rows, q, k)
+
+
+def test_reference_example_known_answers(golden):
+    """examples/similarity_search.rs dataset + queries: intended (nearest) answers."""
+    g = golden["similarity_search_60x4"]
+    X = np.array(g["rows_bits"], np.uint32).view(np.float32)
+    with G.GpuCorpus.from_array(X) as c:
+        for case in g["cases"]:
+            res = c.search(np.array(case["query"], np.float32), case["k"], G.L2)
+            assert res.indices[0].tolist() == case["intended_nearest"]["indices"]
+            want = np.array(case["intended_nearest"]["score_bits"], np.uint32).view(np.float32)
+            np.testing.assert_allclose(res.scores[0], want, rtol=1e-5, atol=1e-7)
+
+
+def test_find_top_k_similar_on_mvf_file(golden, golden_dir):
+    """The drop-in, end to end: open the .mvf, map_vector_range -> HBM -> search."""
+    from metrovector_amd.reader import MvfReader
+    from metrovector_amd.search import find_top_k_similar
+    r = MvfReader.open(os.path.join(golden_dir, "clusters_60x4_f32.mvf"))
+    space = r.vector_space(r.vector_space_names()[0])
+    for case in golden["similarity_search_60x4"]["cases"]:
+        top = find_top_k_similar(space, case["query"], case["k"])
+        assert [t.index for t in top] == case["intended_nearest"]["indices"]
+        want = np.array(case["intended_nearest"]["score_bits"], np.uint32).view(np.float32)
+        np.testing.assert_allclose([t.score for t in top], want, rtol=1e-5, atol=1e-7)
+        assert (top[0].vector == space.get_vector(top[0].index).as_f32()).all()
+    with pytest.raises(E.DimensionMismatch, match="expected 4, got 3"):
+        find_top_k_similar(space, [1, 2, 3], 5)
+
+
+def test_multi_space_file_all_dtypes(oracle, golden_dir):
+    from metrovector_amd.reader import MvfReader
+    from metrovector_amd.search import find_top_k_similar, upload_space
+    r = MvfReader.open(os.path.join(golden_dir, "multi_space.mvf"))
+    src = np.load(os.path.join(golden_dir, "multi_space_src.npz"))
+    rng = np.random.default_rng(5)
+    # f32 cosine (metric taken from the file), unaligned block offsets downstream
+    q = rng.standard_normal(24).astype(np.float32)
+    top = find_top_k_similar(r.vector_space("f32_cos"), q, 6)
+    sc, idx, _ = oracle.search(src["A"], 0, 2, q, 6)
+    assert [t.index for t in top] == idx[0].tolist()
+    top = find_top_k_similar(r.vector_space("f16_l2"), q, 6)
+    sc, idx, _ = oracle.search(src["A"].astype(np.float16), 1, 0, q, 6)
+    assert [t.index for t in top] == idx[0].tolist()
+    qi = rng.integers(-128, 128, 20, dtype=np.int8)
+    top = find_top_k_similar(r.vector_space("i8_dot"), qi, 50)
+    sc, idx, raw = oracle.search(src["I8"], 2, 1, qi, 50)
+    assert [t.index for t in top] == idx[0].tolist() and [t.score for t in top] == sc[0].tolist()
+    qu = rng.integers(0, 256, 7, dtype=np.uint8)
+    sp = r.vector_space("u8_l2")
+    with upload_space(sp) as c:
+        assert (c.read_rows(0, 33) == src["U8"]).all()
+        res = c.search(qu, 40, G.L2)
+    sc, idx, raw = oracle.search(src["U8"], 3, 0, qu, 40)
+    assert_exact(res, sc, idx, raw)
+
+
+def test_integer_ties_break_by_index(oracle):
+    # few distinct values -> massive score ties; order must be (score, index)
+    rng = np.random.default_rng(1)
+    rows = rng.integers(0, 2, (4000, 16), dtype=np.uint8)
+    q = np.ones(16, np.uint8)
+    _check(oracle, 3, 1, rows, q, 300)
+    rows8 = rng.integers(-1, 2, (3000, 32)).astype(np.int8)
+    _check(oracle, 2, 0, rows8, np.zeros(32, np.int8), 1024)
+
+
+def test_float_ties_duplicates_and_all_equal(oracle):
+    rows = np.tile(np.array([[0.25, -0.5, 1.0, 2.0]], np.float32), (1500, 1))
+    q = np.array([1, 1, 1, 1], np.float32)
+    with G.GpuCorpus.from_array(rows) as c:
+        for metric in (0, 1, 2):
+            res = c.search(q, 20, metric)
+            assert res.indices[0].tolist() == list(range(20))  # all scores equal -> ascending index
+            assert len(set(res.scores[0].tolist())) == 1
+
+
+def test_nan_rows_sort_last(oracle):
+    rows = oracle.synth_rows(3, 0, 600, 8, 0)
+    rows[5, 2] = np.nan
+    rows[77, 0] = np.nan
+    q = oracle.synth_queries(4, 1, 8, 0)[0]
+    with G.GpuCorpus.from_array(rows) as c:
+        res = c.search(q, 600, G.L2)
+    assert sorted(res.indices[0, -2:].tolist()) == [5, 77]
+    assert np.isnan(res.scores[0, -2:]).all() and not np.isnan(res.scores[0, :-2]).any()
+
+
+def test_zero_norm_cosine_is_zero():
+    rows = np.zeros((10, 8), np.float32)
+    rows[3] = 1.0
+    with G.GpuCorpus.from_array(rows) as c:
+        res = c.search(np.ones(8, np.float32), 10, G.COSINE)
+    assert res.indices[0, 0] == 3 and abs(res.scores[0, 0] - 1.0) < 1e-6
+    assert (res.scores[0, 1:] == 0.0).all() and res.indices[0, 1:].tolist() == [0, 1, 2, 4, 5, 6, 7, 8, 9]
+
+
+def test_empty_and_tiny_corpora():
+    with G.GpuCorpus.from_array(np.zeros((0, 8), np.float32)) as c:
+        res = c.search(np.ones(8, np.float32), 3, G.L2)
+        assert (res.indices == PAD).all() and (res.scores == np.inf).all()
+        res = c.search(np.ones(8, np.float32), 3, G.INNER_PRODUCT)
+        assert (res.scores == -np.inf).all()
+    with G.GpuCorpus.from_array(np.array([[1, 2, 3]], np.int8)) as c:
+        res = c.search(np.array([1, 1, 1], np.int8), 2, G.INNER_PRODUCT)
+        assert res.indices[0].tolist() == [0, int(PAD)] and res.raw[0, 0] == 6
+
+
+def test_strided_and_misaligned_host_rows(oracle):
+    # rows embedded in a wider host array at an odd byte offset (like an mmap'd block after an odd-sized one)
+    base = oracle.synth_rows(8, 0, 300, 40, 0)
+    buf = np.zeros(300 * 200 + 7, np.uint8)
+    view = np.lib.stride_tricks.as_strided(buf[3:].view(np.uint8), (300, 160), (200, 1))
+    view[:] = base.view(np.uint8).reshape(300, 160)
+    ptr = buf.ctypes.data + 3
+    q = oracle.synth_queries(9, 2, 40, 0)
+    c = G.GpuCorpus.from_pointer(ptr, 300, 40, 0, 200, index_base=1000)
+    try:
+        assert (c.read_rows(0, 300).view(np.uint32) == base.view(np.uint32)).all()
+        res = c.search(q, 10, G.L2)
+    finally:
+        c.close()
+    ws, wi, _ = oracle.search(base, 0, 0, q, 10, index_base=1000)
+    assert recall_at_k(res.indices, wi) == 1.0 and res.indices.min() >= 1000
+
+
+def test_error_codes_mirror_reference():
+    rows = np.zeros((8, 16), np.float32)
+    with G.GpuCorpus.from_array(rows) as c:
+        with pytest.raises(E.DimensionMismatch, match="expected 16, got 8"):
+            c.search(np.zeros(8, np.float32), 2)
+        with pytest.raises(E.BuildError):
+            c.search(np.zeros(16, np.int8), 2)
+        with pytest.raises(E.InvalidArgument):
+            c.search(np.zeros(16, np.float32), 0)
+        with pytest.raises(E.InvalidArgument):
+            c.search(np.zeros(16, np.float32), 2000)
+        with pytest.raises(E.InvalidArgument):
+            c.search(np.zeros(16, np.float32), 2, metric=255)
+        with pytest.raises(E.IndexOutOfBounds):
+            c.read_rows(4, 5)
+    with G.GpuCorpus.from_array(np.zeros((8, 16), np.int8)) as c:
+        with pytest.raises(E.BuildError):
+            c.search(np.zeros(16, np.float32), 2)
+
+
+def test_synthetic_generator_matches_oracle(oracle):
+    for dtype in (0, 1, 2, 3):
+        with G.GpuCorpus.synthetic(1000, 52, dtype, SEED, row0=12345) as c:
+            got = c.read_rows(0, 1000)
+            want = oracle.synth_rows(SEED, 12345, 1000, 52, dtype)
+            assert (got.view(np.uint8) == want.view(np.uint8)).all()
+            assert c.info().index_base == 12345
+
+
+def test_device_pointer_api_and_shard_merge_device(oracle):
+    """mvfgpu_search_device on torch-owned buffers + mvfgpu_merge_topk_device:
+    merge(top-k per shard) == top-k(global)  (SURVEY.md §8e)."""
+    import ctypes as C
+    import torch
+    from metrovector_amd import _lib
+    n, dim, nq, k = 6000, 96, 5, 50
+    for dtype, metric in ((0, 2), (1, 0), (2, 1)):
+        rows = oracle.synth_rows(SEED, 0, n, dim, dtype)
+        q = oracle.synth_queries(SEED + 1, nq, dim, dtype)
+        qd = G.query_dtype_code(dtype)
+        tq = torch.from_numpy(q.copy()).cuda()
+        cuts = [0, 1500, 1501, 6000]
+        S = torch.empty((3, nq, k), dtype=torch.float32, device="cuda")
+        I = torch.empty((3, nq, k), dtype=torch.int64, device="cuda")
+        R = torch.empty((3, nq, k), dtype=torch.int32, device="cuda")
+        stream = torch.cuda.current_stream().cuda_stream
+        shards = []
+        for j, (a, b) in enumerate(zip(cuts[:-1], cuts[1:])):
+            c = G.GpuCorpus.from_array(rows[a:b], index_base=a)
+            shards.append(c)
+            c.search_device(tq.data_ptr(), qd, dim, nq, k, metric, S[j].data_ptr(), I[j].data_ptr(), R[j].data_ptr(), stream)
+        OS = torch.empty((nq, k), dtype=torch.float32, device="cuda")
+        OI = torch.empty((nq, k), dtype=torch.int64, device="cuda")
+        OR = torch.empty((nq, k), dtype=torch.int32, device="cuda")
+        _lib.gpu_check(_lib.gpu().mvfgpu_merge_topk_device(S.data_ptr(), I.data_ptr(), R.data_ptr(), 3, nq, k, metric, dtype,
+                                                           OS.data_ptr(), OI.data_ptr(), OR.data_ptr(), 0, C.c_void_p(stream)))
+        torch.cuda.synchronize()
+        for c in shards:
+            c.close()
+        gi = OI.cpu().numpy().view(np.uint64)
+        ws, wi, wr = oracle.search(rows, dtype, metric, q, k)
+        if dtype == 2:
+            assert (gi == wi).all() and (OR.cpu().numpy() == wr).all()
+        else:
+            assert recall_at_k(gi, wi) >= 0.99
+            np.testing.assert_allclose(OS.cpu().numpy(), ws, rtol=1e-4, atol=1e-5)
+        # host merge of the same per-shard lists agrees with the device merge
+        hm = G.merge_topk_host(S.cpu().numpy(), I.cpu().numpy().view(np.uint64), R.cpu().numpy(), metric, dtype)
+        assert (hm.indices == gi).all()
+
+
+def test_concurrent_searches_on_one_handle(oracle):
+    import threading
+    rows = oracle.synth_rows(SEED, 0, 20000, 64, 0)
+    qs = oracle.synth_queries(SEED + 1, 8, 64, 0)
+    want = oracle.search(rows, 0, 0, qs, 10)[1]
+    out = [None] * 8
+    with G.GpuCorpus.from_array(rows) as c:
+        def work(i):
+            out[i] = c.search(qs[i], 10, G.L2).indices[0]
+        ts = [threading.Thread(target=work, args=(i,)) for i in range(8)]
+        [t.start() for t in ts]
+        [t.join() for t in ts]
+    assert recall_at_k(np.stack(out), want) == 1.0
+
+
+# ---------------------------------------------------------------------------
+# BASELINE.json full sizes: size-independent properties (the oracle cannot
+# score 7.7e9 elements in seconds; rows are regenerated on demand instead).
+# ---------------------------------------------------------------------------
+
+@pytest.fixture(scope="module")
+def corpus_10m():
+    c = G.GpuCorpus.synthetic(10_000_000, 768, 0, SEED)
+    yield c
+    c.close()
+
+
+@pytest.mark.parametrize("metric", [0, 2])
+def test_full_size_cfg2_properties(oracle, corpus_10m, metric):
+    n, dim, k = 10_000_000, 768, 100
+    c = corpus_10m
+    q = oracle.synth_queries(SEED + 1, 1, dim, 0)[0]
+    res = c.search(q, k, metric)
+    idx = res.indices[0].astype(np.int64)
+    assert len(set(idx.tolist())) == k and idx.min() >= 0 and idx.max() < n
+    # (1) every returned row re-scored by the oracle from regenerated bytes
+    rows = np.stack([oracle.synth_rows(SEED, int(i), 1, dim, 0)[0] for i in idx])
+    sc, _, _ = oracle.scores(rows, 0, metric, q)
+    tol = 1e-5 * np.abs(sc) if metric == 0 else 1e-5
+    assert (np.abs(sc - res.scores[0]) <= tol).all()
+    sign = 1 if metric == 0 else -1
+    assert (np.diff(sign * res.scores[0]) >= 0).all()
+    # (2) no row of a 200k-row oracle-scored sample beats the k-th result unless it was returned
+    kth = sign * float(res.scores[0, -1])
+    r0 = 3_333_333
+    sample = oracle.synth_rows(SEED, r0, 200_000, dim, 0)
+    ssc, _, _ = oracle.scores(sample, 0, metric, q)
+    better = np.nonzero(sign * ssc.astype(np.float64) < kth - 1e-5 * abs(kth))[0] + r0
+    assert set(better.tolist()) <= set(idx.tolist())
+    # (3) planted neighbour: a query equal to a corpus row must find it first with distance 0 / cosine 1
+    planted = 8_765_432
+    pq = oracle.synth_rows(SEED, planted, 1, dim, 0)[0]
+    pres = c.search(pq, 5, metric)
+    assert pres.indices[0, 0] == planted
+    assert abs(pres.scores[0, 0] - (0.0 if metric == 0 else 1.0)) < 1e-5
+
+
+def test_full_size_shard_merge_invariance(oracle, corpus_10m):
+    """top-k(whole) == merge(top-k(shards)) at full size, using device shards of the same synthetic corpus."""
+    dim, k = 768, 100
+    q = oracle.synth_queries(SEED + 1, 2, dim, 0)
+    whole = corpus_10m.search(q, k, G.COSINE)
+    cuts = [0, 2_500_000, 6_000_001, 10_000_000]
+    S, I = [], []
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        with G.GpuCorpus.synthetic(b - a, dim, 0, SEED, row0=a) as c:
+            r = c.search(q, k, G.COSINE)
+            S.append(r.scores)
+            I.append(r.indices)
+    merged = G.merge_topk_host(np.stack(S), np.stack(I), None, G.COSINE, 0)
+    assert (merged.indices == whole.indices).all()
+    assert (merged.scores.view(np.uint32) == whole.scores.view(np.uint32)).all()
