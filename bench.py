@@ -188,6 +188,19 @@ def main():
                                   "kernel": "scan_stream_kernel", "kernel_ms_avg": tm.scan_ms_avg,
                                   "select_ms_avg": tm.select_ms_avg, "launches_timed": tm.samples,
                                   "algorithmic_bytes_per_launch": alg_bytes}
+            # HBM bytes per launch from the PMC counters: they need their own rocprofv3 --pmc passes
+            # (FETCH_SIZE x2 on gfx950 + WRITE_SIZE, MI355X_MICROARCH.md §HBM), so the figure is the committed
+            # summary of those passes for this exact workload, not a live measurement.
+            tp = os.path.join(ROOT, "profiles", "r01_bench_n1_hbm_traffic.json")
+            if os.path.exists(tp):
+                prof = json.load(open(tp))
+                w = prof.get("workload", {})
+                if (w.get("rows"), w.get("dim"), w.get("dtype"), w.get("metric"), w.get("queries"), w.get("k")) == (
+                        args.rows, args.dim, args.dtype, args.metric, args.queries, args.k):
+                    for name, kern in prof["kernels"].items():
+                        if name.startswith("scan_stream_kernel"):
+                            result["roofline"]["traffic"] = kern["hbm_bytes_per_launch_corrected"]
+                            result["roofline"]["traffic_source"] = "profiles/r01_bench_n1_hbm_traffic.json"
         result["corpus_generation_s"] = gen_s
 
         if world == 1:
