@@ -9,6 +9,7 @@
 
 #include "aux_kernels.h"
 #include "mvf_common.h"
+#include "scan_mfma.h"
 #include "scan_stream.h"
 
 #include <algorithm>
@@ -81,7 +82,10 @@ struct mvfgpu_corpus {
 
     mutable std::mutex mu;       // guards the scratch + timing state
     mutable std::mutex host_mu;  // serialises the host-buffer API's device mirrors
-    mutable DevBuf cand;                  // scratch: per-block candidate lists
+    mutable DevBuf cand;                  // scratch: per-block candidate lists (K1)
+    mutable DevBuf bq, bstate, bcand, xnorm;  // K2: padded queries + norms; tau/cnt/overflow; candidates; row norms
+    mutable bool xnorm_ready = false;
+    mutable uint32_t bstate_slots = 0;    // queries the K2 state arrays are armed for
     mutable DevBuf h_q, h_s, h_i, h_r;    // device mirrors for the host-buffer API
     mutable hipStream_t own_stream = nullptr;
     mutable hipEvent_t ev_done = nullptr;
@@ -168,7 +172,7 @@ const void* scan_kernel(uint8_t dtype, int metric, int G, int nqv) {
 }
 
 int search_stream_path(const mvfgpu_corpus* c, uint8_t metric, const void* d_queries, uint32_t nq, uint32_t k,
-                       float* d_scores, uint64_t* d_indices, int32_t* d_raw, hipStream_t s) {
+                       float* d_scores, uint64_t* d_indices, int32_t* d_raw, hipStream_t s, bool profile = true) {
     const uint32_t kcap = next_pow2(k);
     const int G = c->G;
     const uint32_t chunk_rows = scan_chunk_rows(G);
@@ -179,7 +183,7 @@ int search_stream_path(const mvfgpu_corpus* c, uint8_t metric, const void* d_que
     tm.scan_kernel = 1;
     bool first = true;
     mvfgpu_corpus::ProfSlot* ps = nullptr;
-    if (c->profiling) {
+    if (c->profiling && profile) {
         ps = &c->prof[c->prof_next % mvfgpu_corpus::kProfSlots];
         for (auto& e : ps->e)
             if (!e) HIP_TRY(hipEventCreate(&e));
@@ -258,6 +262,135 @@ int search_stream_path(const mvfgpu_corpus* c, uint8_t metric, const void* d_que
         c->prof_next++;
     }
     return MVF_OK;
+}
+
+
+// K2 path: MFMA batched scan in geometric phases with per-query candidate
+// compaction between them (see scan_mfma.hip).  Blocking at the end: the
+// overflow flags are read back and any flagged query is redone exactly with K1.
+int search_batched_path(const mvfgpu_corpus* c, uint8_t metric, const void* d_queries, uint32_t nq, uint32_t k,
+                        float* d_scores, uint64_t* d_indices, int32_t* d_raw, hipStream_t s) {
+    const uint32_t nq_pad = (nq + 127u) & ~127u;
+    const uint32_t KT = (c->dim + 31u) / 32u, KP = KT * 32u;
+    const uint32_t cap = kBatchCap;
+    const uint32_t n = (uint32_t)c->n;
+
+    HIP_TRY(c->bq.reserve(((size_t)nq_pad * KP + nq_pad) * 4));
+    float* qmat = static_cast<float*>(c->bq.p);
+    float* qnorm = qmat + (size_t)nq_pad * KP;
+    if (c->bstate_slots < nq_pad) {
+        HIP_TRY(c->bstate.reserve((size_t)nq_pad * 12));
+        HIP_TRY(hipMemsetAsync(c->bstate.p, 0xFF, (size_t)nq_pad * 4, s));                                  // tau
+        HIP_TRY(hipMemsetAsync(static_cast<unsigned char*>(c->bstate.p) + (size_t)nq_pad * 4, 0, (size_t)nq_pad * 8, s));  // cnt, overflow
+        c->bstate_slots = nq_pad;
+    }
+    uint32_t* tau = static_cast<uint32_t*>(c->bstate.p);
+    uint32_t* cnt = tau + c->bstate_slots;
+    uint32_t* overflow = cnt + c->bstate_slots;
+    HIP_TRY(c->bcand.reserve((size_t)nq_pad * cap * 8));
+    if (metric == MVF_METRIC_COSINE && !c->xnorm_ready) {  // K4, once per resident corpus
+        HIP_TRY(c->xnorm.reserve((size_t)std::max<uint32_t>(n, 1) * 4));
+        HIP_TRY(launch_row_norms_f32(c->d_rows, n, c->pitch, static_cast<float*>(c->xnorm.p), s));
+        c->xnorm_ready = true;
+    }
+    HIP_TRY(launch_prep_queries(static_cast<const float*>(d_queries), nq, nq_pad, c->dim, KP, qmat, qnorm, s));
+
+    BatchParams bp{};
+    bp.qmat = qmat;
+    bp.qnorm = qnorm;
+    bp.rows = c->d_rows;
+    bp.xnorm = static_cast<const float*>(c->xnorm.p);
+    bp.tau = tau;
+    bp.cand = static_cast<uint64_t*>(c->bcand.p);
+    bp.cnt = cnt;
+    bp.pitch = c->pitch;
+    bp.V = c->V;
+    bp.KP = KP;
+    bp.KT = KT;
+    bp.nq = nq;
+    bp.mtiles = nq_pad / 128;
+    bp.cap = cap;
+
+    CompactParams cp{};
+    cp.cand = bp.cand;
+    cp.cnt = cnt;
+    cp.tau = tau;
+    cp.overflow = overflow;
+    cp.cap = cap;
+    cp.k = k;
+    cp.metric = metric;
+    cp.index_base = c->index_base;
+    cp.out_scores = d_scores;
+    cp.out_indices = d_indices;
+    cp.out_raw = d_raw;
+
+    mvfgpu_timing tm{};
+    tm.scan_kernel = 2;
+    mvfgpu_corpus::ProfSlot* ps = nullptr;
+    if (c->profiling) {
+        ps = &c->prof[c->prof_next % mvfgpu_corpus::kProfSlots];
+        for (auto& e : ps->e)
+            if (!e) HIP_TRY(hipEventCreate(&e));
+        ps->scanned = false;
+    }
+
+    // phase p scans rows [R_p, R_{p+1}); phase 0 passes everything (R_1 = cap rows), later phases grow by g:
+    // expected survivors per query k*(g-1) + k carried <= cap/2
+    const uint32_t g = std::min(8u, std::max(2u, cap / (2u * k)));
+    uint64_t begin = 0, end = std::min<uint64_t>(n, cap);
+    for (;;) {
+        const bool last = end >= n;
+        if (end > begin) {
+            bp.row_begin = (uint32_t)begin;
+            bp.row_end = (uint32_t)end;
+            bp.ntiles = (uint32_t)((end - begin + 127) / 128);
+            if (ps && last) HIP_TRY(hipEventRecord(ps->e[0], s));
+            HIP_TRY(launch_scan_mfma_f32(bp, metric, s));
+            if (ps && last) {
+                HIP_TRY(hipEventRecord(ps->e[1], s));
+                ps->scanned = true;
+                tm.scan_bytes = (end - begin) * c->dim * elem_size(c->dtype);
+                tm.scan_flops = 2ull * nq * (end - begin) * c->dim;
+            }
+            tm.scan_launches++;
+        }
+        HIP_TRY(launch_compact(cp, nq, last, s));
+        if (last) break;
+        begin = end;
+        end = std::min<uint64_t>(n, ((end * g + 127) / 128) * 128);
+    }
+    if (ps) {
+        HIP_TRY(hipEventRecord(ps->e[2], s));
+        c->timing = tm;
+        c->prof_next++;
+    }
+
+    // overflow check (rare: needs > cap survivors for one query within one phase)
+    std::vector<uint32_t> flags(nq);
+    HIP_TRY(hipMemcpyAsync(flags.data(), overflow, (size_t)nq * 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    bool any = false;
+    for (uint32_t q = 0; q < nq; q++) any |= flags[q] != 0;
+    if (any) {
+        HIP_TRY(hipMemsetAsync(overflow, 0, (size_t)nq_pad * 4, s));
+        const uint32_t qes = 4;
+        for (uint32_t q = 0; q < nq; q++) {
+            if (!flags[q]) continue;
+            int rc = search_stream_path(c, metric, static_cast<const unsigned char*>(d_queries) + (size_t)q * c->dim * qes,
+                                        1, k, d_scores + (size_t)q * k, d_indices + (size_t)q * k,
+                                        d_raw ? d_raw + (size_t)q * k : nullptr, s, /*profile=*/false);
+            if (rc != MVF_OK) return rc;
+        }
+        HIP_TRY(hipStreamSynchronize(s));
+    }
+    return MVF_OK;
+}
+
+bool use_batched_path(const mvfgpu_corpus* c, uint8_t metric, uint32_t nq) {
+    if (c->scan_path == 1) return false;
+    const bool supported = c->dtype == MVF_DTYPE_FLOAT32 && (metric == MVF_METRIC_COSINE || metric == MVF_METRIC_INNER_PRODUCT);
+    if (!supported) return false;
+    return c->scan_path == 2 || nq >= 32;
 }
 
 int check_query_args(const mvfgpu_corpus* c, uint8_t metric, const void* queries, uint8_t query_dtype,
@@ -408,6 +541,10 @@ void mvfgpu_corpus_destroy(mvfgpu_corpus* c) {
         (void)hipDeviceSynchronize();
         if (c->d_rows) (void)hipFree(c->d_rows);
         c->cand.release();
+        c->bq.release();
+        c->bstate.release();
+        c->bcand.release();
+        c->xnorm.release();
         c->h_q.release();
         c->h_s.release();
         c->h_i.release();
@@ -431,7 +568,7 @@ int mvfgpu_corpus_get_info(const mvfgpu_corpus* c, mvfgpu_corpus_info* out) {
     out->data_type = c->dtype;
     out->device = c->device;
     std::lock_guard<std::mutex> lk(c->mu);
-    out->device_bytes = c->rows_bytes + c->cand.bytes + c->h_q.bytes +
+    out->device_bytes = c->rows_bytes + c->cand.bytes + c->bq.bytes + c->bstate.bytes + c->bcand.bytes + c->xnorm.bytes + c->h_q.bytes +
                         c->h_s.bytes + c->h_i.bytes + c->h_r.bytes;
     return MVF_OK;
 }
@@ -461,7 +598,8 @@ int mvfgpu_search_device(const mvfgpu_corpus* c, uint8_t metric, const void* d_q
     std::lock_guard<std::mutex> lk(c->mu);
     // the scratch buffers are stream-ordered: a call on another stream waits for the previous one
     if (c->has_done && c->last_stream != s) HIP_TRY(hipStreamWaitEvent(s, c->ev_done, 0));
-    rc = search_stream_path(c, metric, d_queries, nq, k, d_scores, d_indices, d_raw, s);
+    rc = use_batched_path(c, metric, nq) ? search_batched_path(c, metric, d_queries, nq, k, d_scores, d_indices, d_raw, s)
+                                         : search_stream_path(c, metric, d_queries, nq, k, d_scores, d_indices, d_raw, s);
     if (rc != MVF_OK) return rc;
     HIP_TRY(hipEventRecord(c->ev_done, s));
     c->has_done = true;

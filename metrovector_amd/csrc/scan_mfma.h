@@ -1,0 +1,50 @@
+// scan_mfma.h — launch interface of K2 (MFMA batched scan) and its helpers.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <algorithm>
+
+namespace mvf {
+
+struct BatchParams {
+    const float* qmat;          // [nq_pad][KP] f32 queries, zero padded (nq_pad multiple of 128)
+    const float* qnorm;         // [nq_pad] sqrt(sum q^2)
+    const unsigned char* rows;  // device rows
+    const float* xnorm;         // [n] sqrt(sum x^2) (cosine only)
+    const uint32_t* tau;        // [nq_pad] order-key thresholds (0xFFFFFFFF = none yet)
+    uint64_t* cand;             // [nq_pad][cap] composites
+    uint32_t* cnt;              // [nq_pad] entries appended (may exceed cap: overflow)
+    uint32_t pitch, V;          // row pitch in bytes, pitch/16
+    uint32_t KP, KT;            // padded k (floats), k-tiles of 32
+    uint32_t nq;
+    uint32_t row_begin, row_end;  // rows of this launch (phase)
+    uint32_t ntiles, mtiles;      // ceil((row_end-row_begin)/128), nq_pad/128
+    uint32_t cap;
+};
+
+struct CompactParams {
+    uint64_t* cand;
+    uint32_t* cnt;
+    uint32_t* tau;
+    uint32_t* overflow;
+    uint32_t cap, k;
+    // final stage only
+    uint8_t metric;
+    uint64_t index_base;
+    float* out_scores;
+    uint64_t* out_indices;
+    int32_t* out_raw;
+};
+
+constexpr uint32_t kBatchCap = 4096;  // candidate slots per query between compactions (32 KiB of LDS to sort)
+
+size_t scan_mfma_lds_bytes();
+hipError_t launch_scan_mfma_f32(const BatchParams& p, int metric, hipStream_t s);
+hipError_t launch_prep_queries(const float* q, uint32_t nq, uint32_t nq_pad, uint32_t dim, uint32_t KP, float* qmat,
+                               float* qnorm, hipStream_t s);
+hipError_t launch_row_norms_f32(const unsigned char* rows, uint32_t n, uint32_t pitch, float* xnorm, hipStream_t s);
+hipError_t launch_compact(const CompactParams& p, uint32_t nq, bool final_stage, hipStream_t s);
+
+}  // namespace mvf

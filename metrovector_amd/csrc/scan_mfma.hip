@@ -1,0 +1,294 @@
+// scan_mfma.hip — K2: the batched-query scan on the matrix cores, plus its
+// helpers (K4 row norms, query preparation, candidate compaction).
+//
+// Replaces, for nq >> 1, the same reference loop as K1
+// (examples/similarity_search.rs:147-169) evaluated for a whole batch of
+// queries at once:  S[q][r] = sum_d Q[q][d] * X[r][d]  is a GEMM
+// (M = queries, N = corpus rows, K = dimension); scores are never
+// materialised (1024 x 10M x 4 B = 41 GB) — the epilogue keeps only entries
+// that beat each query's current threshold.
+//
+// f32 path: v_mfma_f32_32x32x2_f32 — exact f32 (a k-ordered fmaf chain), 64
+// FLOP/clk/SIMD = 157.3 TFLOP/s peak (MI355X_MICROARCH.md §Matrix cores).
+//
+// Block = 256 threads = 4 waves (2 x 2), block tile 128 queries x 128 rows x
+// 32 k; each wave owns a 64 x 64 output = 2 x 2 MFMA tiles (64 acc VGPRs).
+// A (queries) and B (corpus rows) tiles are staged global -> registers -> LDS
+// (two LDS stages, one barrier per k-tile; the next tile's global loads are
+// issued before the current tile's MFMAs).  LDS rows are padded to 36 floats
+// so the ds_read_b128 operand fetches (lane l: row l&31, k = 4*(l>>5)..+3 of
+// each group of 8 k) are bank-conflict-free.  Using 4 consecutive k per lane
+// half (instead of the instruction's natural k = l>>5) is legal because A and
+// B use the same k permutation and a dot product is order-independent.
+//
+// Grid order is XCD-aware: blocks b and b+8 share an XCD (round-robin
+// dispatch), so XCD x walks corpus tiles x, x+8, ... and runs all query tiles
+// of one corpus tile back to back — the corpus tile is fetched from HBM once
+// and served from that XCD's L2 to the other query tiles.
+//
+// Algorithmic work per launch: 2 * nq * rows * dim flop; rows*dim*es bytes.
+
+#include "scan_mfma.h"
+
+#include "bitonic.h"
+#include "mvf_common.h"
+
+namespace mvf {
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int BM = 128, BN = 128, BK = 32;
+constexpr int LDP = BK + 4;                    // padded LDS row pitch in floats
+constexpr int TILE_F = BM * LDP;               // floats per operand tile per stage
+constexpr size_t kLdsBytes = (size_t)4 * TILE_F * 4 + 2 * BM * 4;  // 2 stages x (A + B) + qnorm + tau
+
+template <int METRIC>
+__global__ void __launch_bounds__(256, 2) scan_mfma_f32_kernel(BatchParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* lds = reinterpret_cast<float*>(smem);
+    float* qn_s = lds + 4 * TILE_F;                              // [BM]
+    uint32_t* tau_s = reinterpret_cast<uint32_t*>(qn_s + BM);    // [BM]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    // XCD-aware tile order
+    const uint32_t b = blockIdx.x;
+    const uint32_t xcd = b & 7u, slot = b >> 3;
+    const uint32_t nt = (slot / p.mtiles) * 8u + xcd;
+    const uint32_t mt = slot % p.mtiles;
+    if (nt >= p.ntiles) return;
+    const uint32_t q0 = mt * BM;
+    const uint32_t r0 = p.row_begin + nt * BN;
+
+    if (tid < BM) {
+        qn_s[tid] = p.qnorm[q0 + tid];
+        tau_s[tid] = p.tau[q0 + tid];
+    }
+
+    // ---- staging maps: thread -> (row sr + 32*i, float4 column sc) -------------
+    const int sr = tid >> 3, sc = tid & 7;
+    const float* qsrc = p.qmat + (size_t)(q0 + sr) * p.KP + sc * 4;
+    const unsigned char* xsrc[4];
+    bool xok[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const uint32_t r = r0 + sr + 32 * i;
+        xok[i] = r < p.row_end;
+        xsrc[i] = p.rows + (size_t)(xok[i] ? r : 0u) * p.pitch + sc * 16;
+    }
+    f32x4 ra[4], rb[4];
+    auto load_tile = [&](uint32_t kt) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            ra[i] = *reinterpret_cast<const f32x4*>(qsrc + (size_t)i * 32 * p.KP + kt * BK);
+            const uint32_t v = kt * 8 + sc;  // 16-B vector index within the row
+            rb[i] = (xok[i] && v < p.V) ? *reinterpret_cast<const f32x4*>(xsrc[i] + (size_t)kt * (BK * 4))
+                                        : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    auto store_tile = [&](int stage) {
+        float* a = lds + stage * 2 * TILE_F;
+        float* bb = a + TILE_F;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            *reinterpret_cast<f32x4*>(a + (sr + 32 * i) * LDP + sc * 4) = ra[i];
+            *reinterpret_cast<f32x4*>(bb + (sr + 32 * i) * LDP + sc * 4) = rb[i];
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) acc[i][j][e] = 0.f;
+
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+
+    const int fr = lane & 31, fh = lane >> 5;
+    for (uint32_t kt = 0; kt < p.KT; kt++) {
+        const int cur = kt & 1;
+        if (kt + 1 < p.KT) load_tile(kt + 1);
+        const float* a = lds + cur * 2 * TILE_F + (wm * 64 + fr) * LDP + fh * 4;
+        const float* bb = lds + cur * 2 * TILE_F + TILE_F + (wn * 64 + fr) * LDP + fh * 4;
+#pragma unroll
+        for (int ks = 0; ks < BK / 8; ks++) {
+            f32x4 fa[2], fb[2];
+#pragma unroll
+            for (int i = 0; i < 2; i++) {
+                fa[i] = *reinterpret_cast<const f32x4*>(a + i * 32 * LDP + ks * 8);
+                fb[i] = *reinterpret_cast<const f32x4*>(bb + i * 32 * LDP + ks * 8);
+            }
+#pragma unroll
+            for (int s = 0; s < 4; s++)
+#pragma unroll
+                for (int i = 0; i < 2; i++)
+#pragma unroll
+                    for (int j = 0; j < 2; j++)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][s], fb[j][s], acc[i][j], 0, 0, 0);
+        }
+        if (kt + 1 < p.KT) store_tile(cur ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: score -> key, threshold filter, append ------------------------
+    // C/D map of the 32x32 MFMA: col = lane&31 (corpus row), row = (e&3) + 8*(e>>2) + 4*(lane>>5) (query)
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        const uint32_t r = r0 + wn * 64 + j * 32 + fr;
+        const bool rok = r < p.row_end;
+        float xn = 0.f;
+        if (METRIC == MVF_METRIC_COSINE && rok) xn = p.xnorm[r];
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+#pragma unroll
+            for (int e = 0; e < 16; e++) {
+                const int ql = wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
+                float s = acc[i][j][e];
+                if (METRIC == MVF_METRIC_COSINE) {
+                    const float den = qn_s[ql] * xn;
+                    s = den > 0.0f ? s / den : 0.0f;
+                }
+                const uint32_t key = key_from_score(s, METRIC);
+                const uint32_t q = q0 + ql;
+                if (rok && q < p.nq && key <= tau_s[ql]) {
+                    const uint32_t slot_i = atomicAdd(&p.cnt[q], 1u);
+                    if (slot_i < p.cap) p.cand[(size_t)q * p.cap + slot_i] = ((uint64_t)key << 32) | r;
+                }
+            }
+        }
+    }
+}
+
+// ---- query preparation: zero-padded [nq_pad][KP] f32 copy + norms --------------
+__global__ void prep_queries_kernel(const float* q, uint32_t nq, uint32_t nq_pad, uint32_t dim, uint32_t KP,
+                                    float* qmat, float* qnorm) {
+    const uint32_t row = blockIdx.x;
+    float part = 0.f;
+    for (uint32_t c = threadIdx.x; c < KP; c += blockDim.x) {
+        const float v = (row < nq && c < dim) ? q[(size_t)row * dim + c] : 0.f;
+        qmat[(size_t)row * KP + c] = v;
+        part = fmaf(v, v, part);
+    }
+    __shared__ float red[4];
+    for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = part;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float s = 0.f;
+        for (uint32_t w = 0; w < (blockDim.x + 63) / 64; w++) s += red[w];
+        qnorm[row] = sqrtf(s);
+    }
+}
+
+// ---- K4: row norms sqrt(sum x^2), one wave per row (f32 rows) ---------------------
+__global__ void __launch_bounds__(256) row_norms_f32_kernel(const unsigned char* rows, uint32_t n, uint32_t pitch,
+                                                             uint32_t V, float* xnorm) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t wave = (blockIdx.x * 256u + threadIdx.x) >> 6, nwaves = (gridDim.x * 256u) >> 6;
+    for (uint32_t r = wave; r < n; r += nwaves) {
+        const unsigned char* rp = rows + (size_t)r * pitch;
+        float s = 0.f;
+        for (uint32_t v = lane; v < V; v += 64) {
+            const f32x4 x = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(rp + (size_t)v * 16));
+            s = fmaf(x[0], x[0], s);
+            s = fmaf(x[1], x[1], s);
+            s = fmaf(x[2], x[2], s);
+            s = fmaf(x[3], x[3], s);
+        }
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+        if (lane == 0) xnorm[r] = sqrtf(s);
+    }
+}
+
+// ---- candidate compaction: keep each query's k best, publish the new threshold ----
+// grid (nq); block 1024; LDS cap*8.  FINAL additionally formats the results.
+__device__ __forceinline__ void write_result_b(uint64_t comp, uint32_t o, const CompactParams& p) {
+    if (comp == kPadComposite) {
+        p.out_scores[o] = pad_score(p.metric);
+        p.out_indices[o] = ~0ull;
+        if (p.out_raw) p.out_raw[o] = 0;
+        return;
+    }
+    p.out_scores[o] = score_from_key((uint32_t)(comp >> 32), p.metric);
+    p.out_indices[o] = p.index_base + (uint32_t)comp;
+    if (p.out_raw) p.out_raw[o] = 0;
+}
+
+template <bool FINAL>
+__global__ void __launch_bounds__(1024) compact_kernel(CompactParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint64_t* buf = reinterpret_cast<uint64_t*>(smem);
+    const int tid = threadIdx.x;
+    const uint32_t q = blockIdx.x;
+    const uint32_t raw_cnt = p.cnt[q];
+    const uint32_t m = raw_cnt < p.cap ? raw_cnt : p.cap;
+    uint64_t* c = p.cand + (size_t)q * p.cap;
+    const uint32_t P2 = next_pow2(m < 2 ? 2 : m);
+    for (uint32_t i = tid; i < P2; i += 1024) buf[i] = i < m ? c[i] : kPadComposite;
+    __syncthreads();
+    bitonic_sort_u64<1024>(buf, P2, tid);
+    const uint32_t keep = m < p.k ? m : p.k;
+    if (FINAL) {
+        for (uint32_t i = tid; i < p.k; i += 1024) write_result_b(i < keep ? buf[i] : kPadComposite, q * p.k + i, p);
+    } else {
+        for (uint32_t i = tid; i < keep; i += 1024) c[i] = buf[i];
+    }
+    if (tid == 0) {
+        if (raw_cnt > p.cap) p.overflow[q] = 1u;  // survivors were dropped: the host repairs this query exactly
+        p.cnt[q] = FINAL ? 0u : keep;
+        p.tau[q] = (!FINAL && keep == p.k) ? (uint32_t)(buf[p.k - 1] >> 32) : kNanKey;
+    }
+}
+
+}  // namespace
+
+size_t scan_mfma_lds_bytes() { return kLdsBytes; }
+
+hipError_t launch_scan_mfma_f32(const BatchParams& p, int metric, hipStream_t s) {
+    const uint32_t groups = (p.ntiles + 7) / 8;
+    const dim3 grid(groups * p.mtiles * 8);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&scan_mfma_f32_kernel<MVF_METRIC_COSINE>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&scan_mfma_f32_kernel<MVF_METRIC_INNER_PRODUCT>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    if (metric == MVF_METRIC_COSINE)
+        hipLaunchKernelGGL(scan_mfma_f32_kernel<MVF_METRIC_COSINE>, grid, dim3(256), kLdsBytes, s, p);
+    else
+        hipLaunchKernelGGL(scan_mfma_f32_kernel<MVF_METRIC_INNER_PRODUCT>, grid, dim3(256), kLdsBytes, s, p);
+    return hipGetLastError();
+}
+
+hipError_t launch_prep_queries(const float* q, uint32_t nq, uint32_t nq_pad, uint32_t dim, uint32_t KP, float* qmat,
+                               float* qnorm, hipStream_t s) {
+    hipLaunchKernelGGL(prep_queries_kernel, dim3(nq_pad), dim3(256), 0, s, q, nq, nq_pad, dim, KP, qmat, qnorm);
+    return hipGetLastError();
+}
+
+hipError_t launch_row_norms_f32(const unsigned char* rows, uint32_t n, uint32_t pitch, float* xnorm, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    const uint32_t blocks = (uint32_t)std::min<uint64_t>(((uint64_t)n + 3) / 4, 256u * 8u);
+    hipLaunchKernelGGL(row_norms_f32_kernel, dim3(blocks), dim3(256), 0, s, rows, n, pitch, pitch / 16, xnorm);
+    return hipGetLastError();
+}
+
+hipError_t launch_compact(const CompactParams& p, uint32_t nq, bool final_stage, hipStream_t s) {
+    const size_t lds = (size_t)p.cap * 8;
+    if (final_stage) hipLaunchKernelGGL(compact_kernel<true>, dim3(nq), dim3(1024), lds, s, p);
+    else hipLaunchKernelGGL(compact_kernel<false>, dim3(nq), dim3(1024), lds, s, p);
+    return hipGetLastError();
+}
+
+}  // namespace mvf

@@ -74,6 +74,11 @@ def assert_exact(res, osc, oidx, oraw):
 
 
 def recall_at_k(got_idx, ref_idx):
+    """|got ∩ ref| / |ref| over the non-padding entries."""
     got_idx, ref_idx = np.asarray(got_idx), np.asarray(ref_idx)
-    hits = sum(len(set(g.tolist()) & set(r.tolist())) for g, r in zip(got_idx, ref_idx))
-    return hits / ref_idx.size
+    hits = total = 0
+    for g, r in zip(got_idx, ref_idx):
+        rs = set(r[r != PAD].tolist())
+        hits += len(set(g[g != PAD].tolist()) & rs)
+        total += len(rs)
+    return hits / max(total, 1)

@@ -309,3 +309,55 @@ def test_full_size_shard_merge_invariance(oracle, corpus_10m):
     merged = G.merge_topk_host(np.stack(S), np.stack(I), None, G.COSINE, 0)
     assert (merged.indices == whole.indices).all()
     assert (merged.scores.view(np.uint32) == whole.scores.view(np.uint32)).all()
+
+
+# ---------------------------------------------------------------------------
+# K2: MFMA batched path (f32, cosine / dot)
+# ---------------------------------------------------------------------------
+
+@pytest.mark.parametrize("metric", [1, 2])
+@pytest.mark.parametrize("shape", [(20000, 768, 200, 100), (5000, 100, 33, 10), (300, 64, 128, 500), (9000, 36, 40, 1),
+                                   (4097, 128, 32, 64)])
+def test_batched_mfma_path(oracle, metric, shape):
+    n, dim, nq, k = shape
+    rows = oracle.synth_rows(SEED, 0, n, dim, 0)
+    q = oracle.synth_queries(SEED + 1, nq, dim, 0)
+    with G.GpuCorpus.from_array(rows, index_base=77) as c:
+        c.set_scan_path(2)
+        res = c.search(q, k, metric)
+        c.set_scan_path(1)
+        ref = c.search(q, k, metric)   # streaming path, same queries
+    rows32 = rows.astype(np.float32)
+    for i in range(nq):
+        sc, _, _ = oracle.scores(rows, 0, metric, q[i])
+        assert_float_topk(metric, res.scores[i], res.indices[i], sc, rows32, q[i], k, 77)
+    assert recall_at_k(res.indices, ref.indices) >= 0.999
+
+
+def test_batched_path_single_query_forced(oracle):
+    rows = oracle.synth_rows(SEED, 0, 3000, 96, 0)
+    q = oracle.synth_queries(SEED + 1, 1, 96, 0)
+    with G.GpuCorpus.from_array(rows) as c:
+        c.set_scan_path(2)
+        res = c.search(q, 20, G.COSINE)
+    sc, _, _ = oracle.scores(rows, 0, 2, q[0])
+    assert_float_topk(2, res.scores[0], res.indices[0], sc, rows, q[0], 20)
+
+
+def test_batched_overflow_is_repaired_exactly(oracle):
+    """Adversarial order: every row beats all previous ones, so a phase's
+    survivors overflow the per-query candidate buffer; the flagged queries must
+    be redone exactly by the streaming path."""
+    n, dim, nq, k = 60000, 32, 32, 10
+    rng = np.random.default_rng(9)
+    base = rng.standard_normal(dim).astype(np.float32)
+    scale = (np.arange(1, n + 1, dtype=np.float32) / n)[:, None]
+    rows = (base[None, :] * scale).astype(np.float32)             # dot with +base grows with the row index
+    q = np.tile(base, (nq, 1)) * rng.uniform(0.5, 2.0, (nq, 1)).astype(np.float32)
+    with G.GpuCorpus.from_array(rows) as c:
+        c.set_scan_path(2)
+        res = c.search(q, k, G.INNER_PRODUCT)
+    for i in range(nq):
+        sc, _, _ = oracle.scores(rows, 0, 1, q[i])
+        assert_float_topk(1, res.scores[i], res.indices[i], sc, rows, q[i], k)
+    assert (res.indices[:, 0] == n - 1).all()
