@@ -111,10 +111,16 @@ def main():
 
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU: metrovector_amd has no CPU fallback")
+    backend = os.environ.get("MVF_BENCH_BACKEND", "nccl")  # "gloo": rehearsal of N>1 on fewer GPUs than ranks
+    if backend != "nccl":
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     # ---- resident corpus shard (untimed) -----------------------------------------
     row0 = rank * args.rows
@@ -152,7 +158,7 @@ def main():
     corpus.set_profiling(False)
 
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 

@@ -35,6 +35,12 @@ def _all_gather(t, group):
     import torch.distributed as dist
     world = dist.get_world_size(group)
     flat = t.contiguous().view(-1)
+    if t.is_cuda and dist.get_backend(group) == "gloo":
+        # rehearsal only (several ranks sharing one GPU, where RCCL refuses duplicate devices):
+        # stage the lists through the host; the production backend is nccl (= RCCL)
+        host = torch.empty(world * flat.numel(), dtype=t.dtype)
+        dist.all_gather_into_tensor(host, flat.cpu(), group=group)
+        return host.to(t.device).view((world,) + tuple(t.shape)), None
     out = torch.empty(world * flat.numel(), dtype=t.dtype, device=t.device)
     work = dist.all_gather_into_tensor(out, flat, group=group, async_op=True)
     return out.view((world,) + tuple(t.shape)), work

@@ -361,3 +361,109 @@ def test_batched_overflow_is_repaired_exactly(oracle):
         sc, _, _ = oracle.scores(rows, 0, 1, q[i])
         assert_float_topk(1, res.scores[i], res.indices[i], sc, rows, q[i], k)
     assert (res.indices[:, 0] == n - 1).all()
+
+
+def test_sharded_searcher_two_ranks_one_gpu(oracle, tmp_path):
+    """Rehearsal of the N>1 GPU path: two ranks (gloo, sharing cuda:0) run
+    ShardedSearcher = search_device -> all-gather -> merge_topk_device and must
+    both hold the global answer.  (The production backend is nccl/RCCL.)"""
+    import subprocess
+    import sys
+    script = tmp_path / "rank.py"
+    script.write_text('''
+import os, sys, numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, %r)
+from metrovector_amd import gpu as G
+from metrovector_amd.sharded import ShardedSearcher, shard_range
+from oracle import mvf_oracle as O
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+torch.cuda.set_device(0)
+for dtype, metric in ((0, 2), (2, 1)):
+    n, dim, nq, k = 30001, 64, 6, 40
+    lo, hi = shard_range(n, world, rank)
+    c = G.GpuCorpus.synthetic(hi - lo, dim, dtype, 555, row0=lo, device=0)
+    q = O.synth_queries(556, nq, dim, dtype)
+    s, i, r = ShardedSearcher(c).search(torch.from_numpy(q.copy()).cuda(), k, metric)
+    torch.cuda.synchronize()
+    rows = O.synth_rows(555, 0, n, dim, dtype)
+    ws, wi, wr = O.search(rows, dtype, metric, q, k)
+    gi = i.cpu().numpy().view(np.uint64)
+    if dtype == 2:
+        assert (gi == wi).all() and (r.cpu().numpy() == wr).all()
+    else:
+        hits = sum(len(set(a.tolist()) & set(b.tolist())) for a, b in zip(gi, wi))
+        assert hits >= 0.99 * wi.size, hits
+        assert np.allclose(s.cpu().numpy(), ws, atol=1e-5)
+    c.close()
+dist.destroy_process_group()
+print("rank", rank, "ok")
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29731", str(script)],
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    assert out.stdout.count("ok") == 2
+
+
+# ---------------------------------------------------------------------------
+# The remaining BASELINE.json configs as parity cases
+# ---------------------------------------------------------------------------
+
+def test_cfg1_reference_cpu_case_10k_x_128_l2_top10(oracle):
+    """configs[0]: examples/similarity_search on CPU, 10k x 128 f32 Euclidean, single query, top-10.
+    GPU vs the FAITHFUL restatement of the reference loop (intended = nearest semantics)."""
+    rows = oracle.synth_rows(SEED, 0, 10_000, 128, 0)
+    q = oracle.synth_queries(SEED + 1, 1, 128, 0)[0]
+    idx, sc = oracle.find_top_k_similar_faithful(rows, 10_000, 128, 0, q, 10, farthest=False)
+    with G.GpuCorpus.from_array(rows) as c:
+        res = c.search(q, 10, G.L2)
+    assert res.indices[0].tolist() == idx.tolist()
+    np.testing.assert_allclose(res.scores[0], sc, rtol=1e-5)
+
+
+def test_cfg4_50m_x_768_int8_dot_256_queries_bit_exact(oracle):
+    """configs[3]: 50M x 768 Int8 dot, 256 batched queries — bit-exact vs the CPU on every returned row,
+    plus an exhaustively scored 400k-row window."""
+    n, dim, nq, k = 50_000_000, 768, 256, 100
+    q = oracle.synth_queries(SEED + 1, nq, dim, 2)
+    with G.GpuCorpus.synthetic(n, dim, 2, SEED) as c:
+        res = c.search(q, k, G.INNER_PRODUCT)
+    assert res.indices.max() < n
+    r64 = None
+    for qi in (0, 100, 255):
+        idx = res.indices[qi].astype(np.int64)
+        assert len(set(idx.tolist())) == k
+        rows = np.stack([oracle.synth_rows(SEED, int(i), 1, dim, 2)[0] for i in idx])
+        _, _, raw = oracle.scores(rows, 2, 1, q[qi])
+        assert (raw == res.raw[qi]).all()                       # exact i32 dot of every returned row
+        assert (res.scores[qi] == raw.astype(np.float32)).all()
+        order = np.lexsort((idx, -raw.astype(np.int64)))
+        assert (order == np.arange(k)).all()                    # sorted by (score desc, index asc)
+    r0 = 31_000_000
+    win = oracle.synth_rows(SEED, r0, 400_000, dim, 2)
+    for qi in (7, 200):
+        _, _, raw = oracle.scores(win, 2, 1, q[qi])
+        kth = int(res.raw[qi, -1])
+        better = np.nonzero(raw > kth)[0] + r0
+        assert set(better.tolist()) <= set(res.indices[qi].tolist())
+
+
+def test_cfg5_shard_12p5m_x_1024_f16_l2_batched(oracle):
+    """configs[4], one GPU's shard: 12.5M x 1024 Float16 L2, batched queries, rows [25M, 37.5M) of the 100M corpus."""
+    n, dim, nq, k, row0 = 12_500_000, 1024, 64, 100, 25_000_000
+    q = oracle.synth_queries(SEED + 1, nq, dim, 1)
+    with G.GpuCorpus.synthetic(n, dim, 1, SEED, row0=row0) as c:
+        res = c.search(q, k, G.L2)
+    assert res.indices.min() >= row0 and res.indices.max() < row0 + n
+    for qi in (0, 63):
+        idx = res.indices[qi].astype(np.int64)
+        rows = np.stack([oracle.synth_rows(SEED, int(i), 1, dim, 1)[0] for i in idx])
+        sc, _, _ = oracle.scores(rows, 1, 0, q[qi])
+        np.testing.assert_allclose(res.scores[qi], sc, rtol=1e-5)
+        assert (np.diff(res.scores[qi]) >= 0).all()
+        win = oracle.synth_rows(SEED, row0 + 5_000_000, 200_000, dim, 1)
+        wsc, _, _ = oracle.scores(win, 1, 0, q[qi])
+        kth = float(res.scores[qi, -1])
+        better = np.nonzero(wsc.astype(np.float64) < kth * (1 - 1e-5))[0] + row0 + 5_000_000
+        assert set(better.tolist()) <= set(idx.tolist())
