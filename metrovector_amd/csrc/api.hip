@@ -266,18 +266,25 @@ int search_stream_path(const mvfgpu_corpus* c, uint8_t metric, const void* d_que
 
 
 // K2 path: MFMA batched scan in geometric phases with per-query candidate
-// compaction between them (see scan_mfma.hip).  Blocking at the end: the
-// overflow flags are read back and any flagged query is redone exactly with K1.
+// compaction between them (scan_mfma.hip for Float32 rows, scan_mfma16.hip for
+// Float16 / Int8 rows).  Blocking at the end: the overflow flags are read back
+// and any flagged query is redone exactly with K1.
 int search_batched_path(const mvfgpu_corpus* c, uint8_t metric, const void* d_queries, uint32_t nq, uint32_t k,
                         float* d_scores, uint64_t* d_indices, int32_t* d_raw, hipStream_t s) {
-    const uint32_t nq_pad = (nq + 127u) & ~127u;
-    const uint32_t KT = (c->dim + 31u) / 32u, KP = KT * 32u;
+    const bool wide = c->dtype == MVF_DTYPE_FLOAT32;       // f32 rows: 128x128x32-float tiles
+    const uint32_t nq_pad = (nq + 255u) & ~255u;
+    const uint32_t tile_rows = wide ? 128u : 256u;
+    const uint32_t qpb = wide ? 128u : scan_mfma16_queries_per_block(c->dtype);
+    const uint32_t KT = wide ? (c->dim + 31u) / 32u : (c->dim * elem_size(c->dtype) + 127u) / 128u;
+    const uint32_t KPB = KT * 128u;                        // prepared query row, bytes (both layouts use 128-B k-tiles)
+    const uint32_t planes = c->dtype == MVF_DTYPE_FLOAT16 ? 2u : 1u;
     const uint32_t cap = kBatchCap;
     const uint32_t n = (uint32_t)c->n;
 
-    HIP_TRY(c->bq.reserve(((size_t)nq_pad * KP + nq_pad) * 4));
-    float* qmat = static_cast<float*>(c->bq.p);
-    float* qnorm = qmat + (size_t)nq_pad * KP;
+    HIP_TRY(c->bq.reserve((size_t)planes * nq_pad * KPB + (size_t)nq_pad * 8));
+    unsigned char* qprep = static_cast<unsigned char*>(c->bq.p);
+    float* qaux0 = reinterpret_cast<float*>(qprep + (size_t)planes * nq_pad * KPB);
+    float* qaux1 = qaux0 + nq_pad;
     if (c->bstate_slots < nq_pad) {
         HIP_TRY(c->bstate.reserve((size_t)nq_pad * 12));
         HIP_TRY(hipMemsetAsync(c->bstate.p, 0xFF, (size_t)nq_pad * 4, s));                                  // tau
@@ -288,16 +295,23 @@ int search_batched_path(const mvfgpu_corpus* c, uint8_t metric, const void* d_qu
     uint32_t* cnt = tau + c->bstate_slots;
     uint32_t* overflow = cnt + c->bstate_slots;
     HIP_TRY(c->bcand.reserve((size_t)nq_pad * cap * 8));
-    if (metric == MVF_METRIC_COSINE && !c->xnorm_ready) {  // K4, once per resident corpus
+    const bool need_norms = wide ? metric == MVF_METRIC_COSINE
+                                 : (c->dtype == MVF_DTYPE_FLOAT16 ? metric == MVF_METRIC_COSINE : metric != MVF_METRIC_INNER_PRODUCT);
+    if (need_norms && !c->xnorm_ready) {  // K4, once per resident corpus
         HIP_TRY(c->xnorm.reserve((size_t)std::max<uint32_t>(n, 1) * 4));
-        HIP_TRY(launch_row_norms_f32(c->d_rows, n, c->pitch, static_cast<float*>(c->xnorm.p), s));
+        if (wide) HIP_TRY(launch_row_norms_f32(c->d_rows, n, c->pitch, static_cast<float*>(c->xnorm.p), s));
+        else HIP_TRY(launch_row_norms16(c->d_rows, c->dtype, n, c->pitch, c->xnorm.p, s));
         c->xnorm_ready = true;
     }
-    HIP_TRY(launch_prep_queries(static_cast<const float*>(d_queries), nq, nq_pad, c->dim, KP, qmat, qnorm, s));
+    if (wide)
+        HIP_TRY(launch_prep_queries(static_cast<const float*>(d_queries), nq, nq_pad, c->dim, KPB / 4,
+                                    reinterpret_cast<float*>(qprep), qaux0, s));
+    else
+        HIP_TRY(launch_prep_queries16(d_queries, c->dtype, nq, nq_pad, c->dim, KPB, qprep, qaux0, qaux1, s));
 
     BatchParams bp{};
-    bp.qmat = qmat;
-    bp.qnorm = qnorm;
+    bp.qmat = reinterpret_cast<const float*>(qprep);
+    bp.qnorm = qaux0;
     bp.rows = c->d_rows;
     bp.xnorm = static_cast<const float*>(c->xnorm.p);
     bp.tau = tau;
@@ -305,11 +319,30 @@ int search_batched_path(const mvfgpu_corpus* c, uint8_t metric, const void* d_qu
     bp.cnt = cnt;
     bp.pitch = c->pitch;
     bp.V = c->V;
-    bp.KP = KP;
+    bp.KP = KPB / 4;
     bp.KT = KT;
     bp.nq = nq;
-    bp.mtiles = nq_pad / 128;
+    bp.mtiles = nq_pad / qpb;
     bp.cap = cap;
+
+    Batch16Params hp{};
+    hp.qprep = qprep;
+    hp.qaux0 = qaux0;
+    hp.qaux1 = qaux1;
+    hp.rows = c->d_rows;
+    hp.xnorm_f = static_cast<const float*>(c->xnorm.p);
+    hp.xnorm_i = static_cast<const int32_t*>(c->xnorm.p);
+    hp.tau = tau;
+    hp.cand = bp.cand;
+    hp.cnt = cnt;
+    hp.pitch = c->pitch;
+    hp.V = c->V;
+    hp.KPB = KPB;
+    hp.KT = KT;
+    hp.nq = nq;
+    hp.nq_pad = nq_pad;
+    hp.mtiles = nq_pad / qpb;
+    hp.cap = cap;
 
     CompactParams cp{};
     cp.cand = bp.cand;
@@ -319,6 +352,7 @@ int search_batched_path(const mvfgpu_corpus* c, uint8_t metric, const void* d_qu
     cp.cap = cap;
     cp.k = k;
     cp.metric = metric;
+    cp.dtype = c->dtype;
     cp.index_base = c->index_base;
     cp.out_scores = d_scores;
     cp.out_indices = d_indices;
@@ -341,11 +375,12 @@ int search_batched_path(const mvfgpu_corpus* c, uint8_t metric, const void* d_qu
     for (;;) {
         const bool last = end >= n;
         if (end > begin) {
-            bp.row_begin = (uint32_t)begin;
-            bp.row_end = (uint32_t)end;
-            bp.ntiles = (uint32_t)((end - begin + 127) / 128);
+            bp.row_begin = hp.row_begin = (uint32_t)begin;
+            bp.row_end = hp.row_end = (uint32_t)end;
+            bp.ntiles = hp.ntiles = (uint32_t)((end - begin + tile_rows - 1) / tile_rows);
             if (ps && last) HIP_TRY(hipEventRecord(ps->e[0], s));
-            HIP_TRY(launch_scan_mfma_f32(bp, metric, s));
+            if (wide) HIP_TRY(launch_scan_mfma_f32(bp, metric, s));
+            else HIP_TRY(launch_scan_mfma16(hp, c->dtype, metric, s));
             if (ps && last) {
                 HIP_TRY(hipEventRecord(ps->e[1], s));
                 ps->scanned = true;
@@ -357,7 +392,7 @@ int search_batched_path(const mvfgpu_corpus* c, uint8_t metric, const void* d_qu
         HIP_TRY(launch_compact(cp, nq, last, s));
         if (last) break;
         begin = end;
-        end = std::min<uint64_t>(n, ((end * g + 127) / 128) * 128);
+        end = std::min<uint64_t>(n, ((end * g + 255) / 256) * 256);
     }
     if (ps) {
         HIP_TRY(hipEventRecord(ps->e[2], s));
@@ -373,7 +408,7 @@ int search_batched_path(const mvfgpu_corpus* c, uint8_t metric, const void* d_qu
     for (uint32_t q = 0; q < nq; q++) any |= flags[q] != 0;
     if (any) {
         HIP_TRY(hipMemsetAsync(overflow, 0, (size_t)nq_pad * 4, s));
-        const uint32_t qes = 4;
+        const uint32_t qes = is_int_dtype(c->dtype) ? 1u : 4u;
         for (uint32_t q = 0; q < nq; q++) {
             if (!flags[q]) continue;
             int rc = search_stream_path(c, metric, static_cast<const unsigned char*>(d_queries) + (size_t)q * c->dim * qes,
@@ -388,7 +423,11 @@ int search_batched_path(const mvfgpu_corpus* c, uint8_t metric, const void* d_qu
 
 bool use_batched_path(const mvfgpu_corpus* c, uint8_t metric, uint32_t nq) {
     if (c->scan_path == 1) return false;
-    const bool supported = c->dtype == MVF_DTYPE_FLOAT32 && (metric == MVF_METRIC_COSINE || metric == MVF_METRIC_INNER_PRODUCT);
+    // Float32 / Float16: cosine and dot (batched L2 needs GEMM-form selection + exact re-scoring: not built yet);
+    // Int8: every metric (exact integers).  UInt8 has no unsigned MFMA: stays on K1.
+    const bool supported = ((c->dtype == MVF_DTYPE_FLOAT32 || c->dtype == MVF_DTYPE_FLOAT16) &&
+                            (metric == MVF_METRIC_COSINE || metric == MVF_METRIC_INNER_PRODUCT)) ||
+                           c->dtype == MVF_DTYPE_INT8;
     if (!supported) return false;
     return c->scan_path == 2 || nq >= 32;
 }

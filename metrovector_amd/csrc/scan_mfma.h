@@ -24,6 +24,25 @@ struct BatchParams {
     uint32_t cap;
 };
 
+// K2 for 16-byte-operand MFMAs (Float16 / Int8 rows), scan_mfma16.hip
+struct Batch16Params {
+    const unsigned char* qprep;  // f16: [2 planes][nq_pad][KPB] hi/lo halves; i8: [nq_pad][KPB] int8; zero padded
+    const float* qaux0;          // [nq_pad] f16: 2^-e (undo of the query scale); i8: bit pattern of i32 sum q^2
+    const float* qaux1;          // [nq_pad] f16: |q| (f32)
+    const unsigned char* rows;
+    const float* xnorm_f;        // [n] f16 rows: sqrt(sum x^2)
+    const int32_t* xnorm_i;      // [n] i8 rows: sum x^2
+    const uint32_t* tau;
+    uint64_t* cand;
+    uint32_t* cnt;
+    uint32_t pitch, V;
+    uint32_t KPB, KT;            // padded row bytes of qprep, k-tiles of 128 bytes
+    uint32_t nq, nq_pad;
+    uint32_t row_begin, row_end;
+    uint32_t ntiles, mtiles;     // ceil(rows/256), nq_pad / queries-per-block
+    uint32_t cap;
+};
+
 struct CompactParams {
     uint64_t* cand;
     uint32_t* cnt;
@@ -31,7 +50,7 @@ struct CompactParams {
     uint32_t* overflow;
     uint32_t cap, k;
     // final stage only
-    uint8_t metric;
+    uint8_t metric, dtype;
     uint64_t index_base;
     float* out_scores;
     uint64_t* out_indices;
@@ -46,5 +65,11 @@ hipError_t launch_prep_queries(const float* q, uint32_t nq, uint32_t nq_pad, uin
                                float* qnorm, hipStream_t s);
 hipError_t launch_row_norms_f32(const unsigned char* rows, uint32_t n, uint32_t pitch, float* xnorm, hipStream_t s);
 hipError_t launch_compact(const CompactParams& p, uint32_t nq, bool final_stage, hipStream_t s);
+
+uint32_t scan_mfma16_queries_per_block(int dtype);
+hipError_t launch_scan_mfma16(const Batch16Params& p, int dtype, int metric, hipStream_t s);
+hipError_t launch_prep_queries16(const void* q, int dtype, uint32_t nq, uint32_t nq_pad, uint32_t dim, uint32_t KPB,
+                                 unsigned char* qprep, float* qaux0, float* qaux1, hipStream_t s);
+hipError_t launch_row_norms16(const unsigned char* rows, int dtype, uint32_t n, uint32_t pitch, void* out, hipStream_t s);
 
 }  // namespace mvf

@@ -216,9 +216,18 @@ __device__ __forceinline__ void write_result_b(uint64_t comp, uint32_t o, const 
         if (p.out_raw) p.out_raw[o] = 0;
         return;
     }
-    p.out_scores[o] = score_from_key((uint32_t)(comp >> 32), p.metric);
+    const uint32_t key = (uint32_t)(comp >> 32);
+    float s;
+    int32_t raw = 0;
+    if (key_is_raw(p.dtype, p.metric)) {
+        raw = raw_from_key(key, p.metric);
+        s = p.metric == MVF_METRIC_L2 ? sqrtf((float)raw) : (float)raw;
+    } else {
+        s = score_from_key(key, p.metric);
+    }
+    p.out_scores[o] = s;
     p.out_indices[o] = p.index_base + (uint32_t)comp;
-    if (p.out_raw) p.out_raw[o] = 0;
+    if (p.out_raw) p.out_raw[o] = raw;
 }
 
 template <bool FINAL>

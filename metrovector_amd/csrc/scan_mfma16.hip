@@ -1,0 +1,373 @@
+// scan_mfma16.hip — K2 for the narrow types: Float16 rows on
+// v_mfma_f32_32x32x16_f16 and Int8 rows on v_mfma_i32_32x32x32_i8.  Both
+// instructions take 16 bytes per lane per operand, so staging, LDS image and
+// fragment fetches are byte-identical; only the MFMA, the accumulator type and
+// the epilogue differ.
+//
+// Same role as scan_mfma.hip (the batched form of the reference loop,
+// examples/similarity_search.rs:147-169), different balance: these MFMAs are
+// 16-32x faster than the f32 one, so the tile is 256 corpus rows x 256 A rows
+// (8 waves as 2 x 4, each 128 x 64 outputs) — smaller tiles would be bound by
+// L2->LDS traffic, not by the matrix cores or HBM.
+//
+//   Int8    : A rows = 256 queries (int8), exact i32 accumulation -> bit-exact
+//             dot / L2 (qq + xx - 2 dot) / cosine, identical to K1 and the CPU.
+//   Float16 : the reference semantics are "f32 query x exactly-widened f16 row"
+//             (Vector::as_f32, src/vectors/vector.rs:81-89).  An f16 MFMA needs
+//             an f16 query, so each query is scaled by a power of two (max |q|
+//             into [2^14, 2^15)) and split q*2^e = hi + lo into two f16 planes;
+//             A rows = 128 queries x 2 planes; products of f16 pairs are exact in
+//             f32, so dot = (hi.x + lo.x) * 2^-e differs from the f32 dot by
+//             ~2^-22 relative — inside the 1e-5 tolerance.
+//
+// k-tile = 128 bytes per row (128 int8 / 64 f16), 4 MFMA k-steps of 32 bytes;
+// LDS rows padded to 144 B (conflict-free ds_read_b128); two LDS stages; the
+// exact k order inside a step does not matter (A and B share the lane->k map).
+
+#include "scan_mfma.h"
+
+#include "mvf_common.h"
+
+#include <hip/hip_fp16.h>
+
+namespace mvf {
+namespace {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int AROWS = 256, BROWS = 256;     // LDS rows per operand tile
+constexpr int BKB = 128;                    // k-tile bytes per row
+constexpr int LDPB = BKB + 16;              // padded LDS row pitch in bytes
+constexpr int TILE_B = AROWS * LDPB;        // bytes per operand tile per stage
+constexpr size_t kLds16 = (size_t)4 * TILE_B + 2 * 256 * 4 + 256 * 4;  // stages + qaux0 + tau + qaux1
+
+template <int DT> struct T16;
+template <> struct T16<MVF_DTYPE_FLOAT16> {
+    static constexpr int PLANES = 2, IT = 2;  // i-tiles (32 queries) per wave
+    using Acc = f32x16;
+};
+template <> struct T16<MVF_DTYPE_INT8> {
+    static constexpr int PLANES = 1, IT = 4;
+    using Acc = i32x16;
+};
+
+template <int DT, int METRIC>
+__global__ void __launch_bounds__(512, 2) scan_mfma16_kernel(Batch16Params p) {
+    using Tr = T16<DT>;
+    constexpr int PLANES = Tr::PLANES, IT = Tr::IT;
+    constexpr int BMQ = AROWS / PLANES;  // queries per block
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* qa_s = reinterpret_cast<float*>(smem + 4 * TILE_B);    // [256] f16: 2^-e / i8: qq (as int)
+    uint32_t* tau_s = reinterpret_cast<uint32_t*>(qa_s + 256);    // [256]
+    float* qb_s = reinterpret_cast<float*>(tau_s + 256);          // [256] f16: |q|
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 2, wn = wave & 3;
+
+    const uint32_t b = blockIdx.x;
+    const uint32_t xcd = b & 7u, slot = b >> 3;
+    const uint32_t nt = (slot / p.mtiles) * 8u + xcd;
+    const uint32_t mt = slot % p.mtiles;
+    if (nt >= p.ntiles) return;
+    const uint32_t q0 = mt * BMQ;
+    const uint32_t r0 = p.row_begin + nt * BROWS;
+
+    if (tid < BMQ) {
+        qa_s[tid] = p.qaux0[q0 + tid];
+        qb_s[tid] = p.qaux1[q0 + tid];
+        tau_s[tid] = p.tau[q0 + tid];
+    }
+
+    // ---- staging: thread -> 16-B chunk (row sr + 64*i, column sc) of each tile ----------
+    const int sr = tid >> 3, sc = tid & 7;
+    const unsigned char* asrc[4];
+    const unsigned char* xsrc[4];
+    bool xok[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int ar = sr + 64 * i;                      // LDS A row: plane = ar / BMQ, query = ar % BMQ
+        asrc[i] = p.qprep + ((size_t)(ar / BMQ) * p.nq_pad + q0 + (ar % BMQ)) * p.KPB + sc * 16;
+        const uint32_t r = r0 + sr + 64 * i;
+        xok[i] = r < p.row_end;
+        xsrc[i] = p.rows + (size_t)(xok[i] ? r : 0u) * p.pitch + sc * 16;
+    }
+    u32x4 ra[4], rb[4];
+    auto load_tile = [&](uint32_t kt) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            ra[i] = *reinterpret_cast<const u32x4*>(asrc[i] + (size_t)kt * BKB);
+            const uint32_t v = kt * 8 + sc;
+            rb[i] = (xok[i] && v < p.V) ? __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(xsrc[i] + (size_t)kt * BKB))
+                                        : u32x4{0, 0, 0, 0};
+        }
+    };
+    auto store_tile = [&](int stage) {
+        unsigned char* a = smem + stage * 2 * TILE_B;
+        unsigned char* bb = a + TILE_B;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            *reinterpret_cast<u32x4*>(a + (sr + 64 * i) * LDPB + sc * 16) = ra[i];
+            *reinterpret_cast<u32x4*>(bb + (sr + 64 * i) * LDPB + sc * 16) = rb[i];
+        }
+    };
+
+    typename Tr::Acc acc[IT][2];
+#pragma unroll
+    for (int i = 0; i < IT; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) acc[i][j][e] = 0;
+
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+
+    const int fr = lane & 31, fh = lane >> 5;
+    for (uint32_t kt = 0; kt < p.KT; kt++) {
+        const int cur = kt & 1;
+        if (kt + 1 < p.KT) load_tile(kt + 1);
+        const unsigned char* a = smem + cur * 2 * TILE_B + (wm * (BMQ / 2) + fr) * LDPB + fh * 16;
+        const unsigned char* bb = smem + cur * 2 * TILE_B + TILE_B + (wn * 64 + fr) * LDPB + fh * 16;
+#pragma unroll
+        for (int ks = 0; ks < 4; ks++) {
+            u32x4 fb[2];
+#pragma unroll
+            for (int j = 0; j < 2; j++) fb[j] = *reinterpret_cast<const u32x4*>(bb + j * 32 * LDPB + ks * 32);
+#pragma unroll
+            for (int pl = 0; pl < PLANES; pl++) {
+#pragma unroll
+                for (int i = 0; i < IT; i++) {
+                    const u32x4 fa = *reinterpret_cast<const u32x4*>(a + (pl * BMQ + i * 32) * LDPB + ks * 32);
+#pragma unroll
+                    for (int j = 0; j < 2; j++) {
+                        if constexpr (DT == MVF_DTYPE_FLOAT16)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, fa),
+                                                                                __builtin_bit_cast(half8, fb[j]), acc[i][j], 0, 0, 0);
+                        else
+                            acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(__builtin_bit_cast(i32x4, fa),
+                                                                               __builtin_bit_cast(i32x4, fb[j]), acc[i][j], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        if (kt + 1 < p.KT) store_tile(cur ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue (C/D map: col = lane&31 -> corpus row, row = (e&3)+8*(e>>2)+4*(lane>>5) -> query)
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        const uint32_t r = r0 + wn * 64 + j * 32 + fr;
+        const bool rok = r < p.row_end;
+        float xnf = 0.f;
+        int32_t xxi = 0;
+        if (rok) {
+            if constexpr (DT == MVF_DTYPE_FLOAT16) {
+                if (METRIC == MVF_METRIC_COSINE) xnf = p.xnorm_f[r];
+            } else {
+                if (METRIC != MVF_METRIC_INNER_PRODUCT) xxi = p.xnorm_i[r];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < IT; i++) {
+#pragma unroll
+            for (int e = 0; e < 16; e++) {
+                const int ql = wm * (BMQ / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
+                uint32_t key;
+                if constexpr (DT == MVF_DTYPE_FLOAT16) {
+                    float s = acc[i][j][e] * qa_s[ql];  // undo the power-of-two query scale (exact)
+                    if (METRIC == MVF_METRIC_COSINE) {
+                        const float den = qb_s[ql] * xnf;
+                        s = den > 0.0f ? s / den : 0.0f;
+                    }
+                    key = key_from_score(s, METRIC);
+                } else {
+                    const int32_t dot = acc[i][j][e];
+                    const int32_t qq = __float_as_int(qa_s[ql]);
+                    if (METRIC == MVF_METRIC_L2) {
+                        key = key_from_raw(qq + xxi - 2 * dot, METRIC);
+                    } else if (METRIC == MVF_METRIC_INNER_PRODUCT) {
+                        key = key_from_raw(dot, METRIC);
+                    } else {
+                        const float den = sqrtf((float)qq) * sqrtf((float)xxi);
+                        key = key_from_score(den > 0.0f ? (float)dot / den : 0.0f, METRIC);
+                    }
+                }
+                const uint32_t q = q0 + ql;
+                if (rok && q < p.nq && key <= tau_s[ql]) {
+                    const uint32_t slot_i = atomicAdd(&p.cnt[q], 1u);
+                    if (slot_i < p.cap) p.cand[(size_t)q * p.cap + slot_i] = ((uint64_t)key << 32) | r;
+                }
+            }
+        }
+    }
+}
+
+// ---- query preparation ---------------------------------------------------------------
+// f16: per query, scale = 2^e with max|q|*2^e in [2^14, 2^15); planes hi = f16(q*2^e), lo = f16(q*2^e - hi).
+//      qaux0 = 2^-e, qaux1 = |q| (f32 norm of the ORIGINAL query).
+__global__ void prep_queries_f16_kernel(const float* q, uint32_t nq, uint32_t nq_pad, uint32_t dim, uint32_t KPB,
+                                        unsigned char* qprep, float* qaux0, float* qaux1) {
+    const uint32_t row = blockIdx.x;
+    const uint32_t KP = KPB / 2;
+    __shared__ float red[8];
+    float mx = 0.f, ss = 0.f;
+    if (row < nq)
+        for (uint32_t c = threadIdx.x; c < dim; c += blockDim.x) {
+            const float v = q[(size_t)row * dim + c];
+            mx = fmaxf(mx, fabsf(v));
+            ss = fmaf(v, v, ss);
+        }
+    for (int off = 32; off > 0; off >>= 1) {
+        mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+        ss += __shfl_xor(ss, off, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        red[threadIdx.x >> 6] = mx;
+        red[4 + (threadIdx.x >> 6)] = ss;
+    }
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    ss = red[4] + red[5] + red[6] + red[7];
+    int e = 0;
+    if (mx > 0.f && mx < 3.0e38f) {
+        int ex;
+        (void)frexpf(mx, &ex);  // mx = m * 2^ex, m in [0.5, 1)
+        e = 15 - ex;            // mx * 2^e in [2^14, 2^15)
+    }
+    const float up = ldexpf(1.0f, e), down = ldexpf(1.0f, -e);
+    __half* hi = reinterpret_cast<__half*>(qprep + (size_t)row * KPB);
+    __half* lo = reinterpret_cast<__half*>(qprep + ((size_t)nq_pad + row) * KPB);
+    for (uint32_t c = threadIdx.x; c < KP; c += blockDim.x) {
+        float v = (row < nq && c < dim) ? q[(size_t)row * dim + c] * up : 0.f;
+        const __half h = __float2half_rn(v);
+        hi[c] = h;
+        lo[c] = __float2half_rn(v - __half2float(h));
+    }
+    if (threadIdx.x == 0) {
+        qaux0[row] = down;
+        qaux1[row] = sqrtf(ss);
+    }
+}
+
+// i8: zero-padded copy; qaux0 = bit pattern of the i32 sum q^2.
+__global__ void prep_queries_i8_kernel(const int8_t* q, uint32_t nq, uint32_t nq_pad, uint32_t dim, uint32_t KPB,
+                                       unsigned char* qprep, float* qaux0, float* qaux1) {
+    const uint32_t row = blockIdx.x;
+    __shared__ int red[4];
+    int ss = 0;
+    for (uint32_t c = threadIdx.x; c < KPB; c += blockDim.x) {
+        const int8_t v = (row < nq && c < dim) ? q[(size_t)row * dim + c] : (int8_t)0;
+        reinterpret_cast<int8_t*>(qprep)[(size_t)row * KPB + c] = v;
+        ss += (int)v * (int)v;
+    }
+    for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ss;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        qaux0[row] = __int_as_float(red[0] + red[1] + red[2] + red[3]);
+        qaux1[row] = 0.f;
+    }
+}
+
+// ---- K4 for the narrow types: one wave per row ----------------------------------------------
+__global__ void __launch_bounds__(256) row_norms_f16_kernel(const unsigned char* rows, uint32_t n, uint32_t pitch,
+                                                             uint32_t V, float* xnorm) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t wave = (blockIdx.x * 256u + threadIdx.x) >> 6, nwaves = (gridDim.x * 256u) >> 6;
+    for (uint32_t r = wave; r < n; r += nwaves) {
+        const unsigned char* rp = rows + (size_t)r * pitch;
+        float s = 0.f;
+        for (uint32_t v = lane; v < V; v += 64) {
+            const u32x4 x = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(rp + (size_t)v * 16));
+#pragma unroll
+            for (int w = 0; w < 4; w++) {
+                const float a = __half2float(__ushort_as_half((unsigned short)(x[w] & 0xFFFFu)));
+                const float b2 = __half2float(__ushort_as_half((unsigned short)(x[w] >> 16)));
+                s = fmaf(a, a, s);
+                s = fmaf(b2, b2, s);
+            }
+        }
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+        if (lane == 0) xnorm[r] = sqrtf(s);
+    }
+}
+
+__global__ void __launch_bounds__(256) row_norms_i8_kernel(const unsigned char* rows, uint32_t n, uint32_t pitch,
+                                                            uint32_t V, int32_t* xx) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t wave = (blockIdx.x * 256u + threadIdx.x) >> 6, nwaves = (gridDim.x * 256u) >> 6;
+    for (uint32_t r = wave; r < n; r += nwaves) {
+        const unsigned char* rp = rows + (size_t)r * pitch;
+        int s = 0;
+        for (uint32_t v = lane; v < V; v += 64) {
+            const u32x4 x = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(rp + (size_t)v * 16));
+#pragma unroll
+            for (int w = 0; w < 4; w++) s = __builtin_amdgcn_sdot4((int)x[w], (int)x[w], s, false);
+        }
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+        if (lane == 0) xx[r] = s;
+    }
+}
+
+template <int DT>
+hipError_t launch_dt(const Batch16Params& p, int metric, dim3 grid, hipStream_t s) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        const void* fns[3] = {reinterpret_cast<const void*>(&scan_mfma16_kernel<DT, MVF_METRIC_L2>),
+                              reinterpret_cast<const void*>(&scan_mfma16_kernel<DT, MVF_METRIC_INNER_PRODUCT>),
+                              reinterpret_cast<const void*>(&scan_mfma16_kernel<DT, MVF_METRIC_COSINE>)};
+        for (const void* f : fns) {
+            hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds16);
+            if (e != hipSuccess) return e;
+        }
+        attr_set = true;
+    }
+    switch (metric) {
+    case MVF_METRIC_L2: hipLaunchKernelGGL((scan_mfma16_kernel<DT, MVF_METRIC_L2>), grid, dim3(512), kLds16, s, p); break;
+    case MVF_METRIC_INNER_PRODUCT:
+        hipLaunchKernelGGL((scan_mfma16_kernel<DT, MVF_METRIC_INNER_PRODUCT>), grid, dim3(512), kLds16, s, p);
+        break;
+    default: hipLaunchKernelGGL((scan_mfma16_kernel<DT, MVF_METRIC_COSINE>), grid, dim3(512), kLds16, s, p); break;
+    }
+    return hipGetLastError();
+}
+
+}  // namespace
+
+uint32_t scan_mfma16_queries_per_block(int dtype) { return dtype == MVF_DTYPE_FLOAT16 ? 128u : 256u; }
+
+hipError_t launch_scan_mfma16(const Batch16Params& p, int dtype, int metric, hipStream_t s) {
+    const uint32_t groups = (p.ntiles + 7) / 8;
+    const dim3 grid(groups * p.mtiles * 8);
+    if (dtype == MVF_DTYPE_FLOAT16) return launch_dt<MVF_DTYPE_FLOAT16>(p, metric, grid, s);
+    return launch_dt<MVF_DTYPE_INT8>(p, metric, grid, s);
+}
+
+hipError_t launch_prep_queries16(const void* q, int dtype, uint32_t nq, uint32_t nq_pad, uint32_t dim, uint32_t KPB,
+                                 unsigned char* qprep, float* qaux0, float* qaux1, hipStream_t s) {
+    if (dtype == MVF_DTYPE_FLOAT16)
+        hipLaunchKernelGGL(prep_queries_f16_kernel, dim3(nq_pad), dim3(256), 0, s, static_cast<const float*>(q), nq, nq_pad,
+                           dim, KPB, qprep, qaux0, qaux1);
+    else
+        hipLaunchKernelGGL(prep_queries_i8_kernel, dim3(nq_pad), dim3(256), 0, s, static_cast<const int8_t*>(q), nq, nq_pad,
+                           dim, KPB, qprep, qaux0, qaux1);
+    return hipGetLastError();
+}
+
+hipError_t launch_row_norms16(const unsigned char* rows, int dtype, uint32_t n, uint32_t pitch, void* out, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    const uint32_t blocks = (uint32_t)std::min<uint64_t>(((uint64_t)n + 3) / 4, 256u * 8u);
+    if (dtype == MVF_DTYPE_FLOAT16)
+        hipLaunchKernelGGL(row_norms_f16_kernel, dim3(blocks), dim3(256), 0, s, rows, n, pitch, pitch / 16, static_cast<float*>(out));
+    else
+        hipLaunchKernelGGL(row_norms_i8_kernel, dim3(blocks), dim3(256), 0, s, rows, n, pitch, pitch / 16, static_cast<int32_t*>(out));
+    return hipGetLastError();
+}
+
+}  // namespace mvf

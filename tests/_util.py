@@ -9,8 +9,24 @@ PAD = np.uint64(0xFFFFFFFFFFFFFFFF)
 TOL = 1e-5
 
 
-def norms(rows_f32, q_f32):
-    return np.linalg.norm(rows_f32.astype(np.float64), axis=1), float(np.linalg.norm(q_f32.astype(np.float64)))
+_NORM_CACHE = {}
+
+
+def row_norms(rows_f32):
+    """|x| per row in f64, cached per array (the parity loops call this once per query)."""
+    key = (id(rows_f32), rows_f32.shape)
+    hit = _NORM_CACHE.get(key)
+    if hit is None or hit[0] is not rows_f32:
+        if len(_NORM_CACHE) > 4:
+            _NORM_CACHE.clear()
+        hit = (rows_f32, np.sqrt(np.einsum("ij,ij->i", rows_f32, rows_f32, dtype=np.float64)))
+        _NORM_CACHE[key] = hit
+    return hit[1]
+
+
+def norms(rows_f32, q_f32, idx=None):
+    xn = row_norms(rows_f32)
+    return (xn if idx is None else xn[idx]), float(np.linalg.norm(q_f32.astype(np.float64)))
 
 
 def score_tolerance(metric, oracle_scores, rows_f32, q_f32, idx):
@@ -19,7 +35,7 @@ def score_tolerance(metric, oracle_scores, rows_f32, q_f32, idx):
         return TOL * np.maximum(np.abs(oracle_scores), 1e-30)
     if metric == 2:
         return np.full(len(idx), TOL)
-    xn, qn = norms(rows_f32[idx], q_f32)
+    xn, qn = norms(rows_f32, q_f32, idx)
     return TOL * np.maximum(xn * qn, 1e-30)
 
 

@@ -467,3 +467,49 @@ def test_cfg5_shard_12p5m_x_1024_f16_l2_batched(oracle):
         kth = float(res.scores[qi, -1])
         better = np.nonzero(wsc.astype(np.float64) < kth * (1 - 1e-5))[0] + row0 + 5_000_000
         assert set(better.tolist()) <= set(idx.tolist())
+
+
+# ---------------------------------------------------------------------------
+# K2 for the narrow types (scan_mfma16.hip): Int8 on i32 MFMA (bit-exact),
+# Float16 on f16 MFMA with hi/lo-split queries
+# ---------------------------------------------------------------------------
+
+@pytest.mark.parametrize("metric", [0, 1, 2])
+@pytest.mark.parametrize("shape", [(30000, 768, 256, 100), (5000, 100, 33, 10), (300, 64, 300, 500), (9001, 20, 40, 1)])
+def test_batched_mfma_int8_bit_exact(oracle, metric, shape):
+    n, dim, nq, k = shape
+    rows = oracle.synth_rows(SEED, 0, n, dim, 2)
+    q = oracle.synth_queries(SEED + 1, nq, dim, 2)
+    with G.GpuCorpus.from_array(rows, index_base=5) as c:
+        c.set_scan_path(2)
+        res = c.search(q, k, metric)
+    osc, oidx, oraw = oracle.search(rows, 2, metric, q, k, index_base=5)
+    assert_exact(res, osc, oidx, oraw)
+
+
+def test_batched_mfma_int8_ties(oracle):
+    rng = np.random.default_rng(2)
+    rows = rng.integers(-1, 2, (20000, 48)).astype(np.int8)
+    q = rng.integers(-2, 3, (64, 48)).astype(np.int8)
+    with G.GpuCorpus.from_array(rows) as c:
+        c.set_scan_path(2)
+        res = c.search(q, 200, G.INNER_PRODUCT)
+    osc, oidx, oraw = oracle.search(rows, 2, 1, q, 200)
+    assert_exact(res, osc, oidx, oraw)
+
+
+@pytest.mark.parametrize("metric", [1, 2])
+@pytest.mark.parametrize("shape", [(20000, 1024, 128, 100), (5000, 100, 33, 10), (300, 72, 130, 400)])
+def test_batched_mfma_f16(oracle, metric, shape):
+    n, dim, nq, k = shape
+    rows = oracle.synth_rows(SEED, 0, n, dim, 1)
+    q = oracle.synth_queries(SEED + 1, nq, dim, 1)
+    q[0] *= 1000.0      # the per-query power-of-two scaling must make magnitude irrelevant
+    q[1] *= 1e-6
+    with G.GpuCorpus.from_array(rows) as c:
+        c.set_scan_path(2)
+        res = c.search(q, k, metric)
+    rows32 = rows.astype(np.float32)
+    for i in range(nq):
+        sc, _, _ = oracle.scores(rows, 1, metric, q[i])
+        assert_float_topk(metric, res.scores[i], res.indices[i], sc, rows32, q[i], k)
