@@ -22,6 +22,7 @@ struct BatchParams {
     uint32_t row_begin, row_end;  // rows of this launch (phase)
     uint32_t ntiles, mtiles;      // ceil((row_end-row_begin)/128), nq_pad/128
     uint32_t cap;
+    unsigned long long* stamps;   // diagnostic build aid: [65536][4] s_memtime stamps (start, prologue, k-loop, end) or NULL
 };
 
 // K2 for 16-byte-operand MFMAs (Float16 / Int8 rows), scan_mfma16.hip

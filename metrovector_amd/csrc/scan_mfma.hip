@@ -38,11 +38,12 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int BM = 128, BN = 128, BK = 32;
 constexpr int LDP = BK + 4;                    // padded LDS row pitch in floats
 constexpr int TILE_F = BM * LDP;               // floats per operand tile per stage
-constexpr size_t kLdsBytes = (size_t)4 * TILE_F * 4 + 2 * BM * 4;  // 2 stages x (A + B) + qnorm + tau
+constexpr size_t kLdsBytes = (size_t)4 * TILE_F * 4 + 3 * BM * 4;  // 2 stages x (A + B) + qnorm + tau + prefilter
 
 template <int METRIC>
 __global__ void __launch_bounds__(256, 2) scan_mfma_f32_kernel(BatchParams p) {
@@ -50,6 +51,7 @@ __global__ void __launch_bounds__(256, 2) scan_mfma_f32_kernel(BatchParams p) {
     float* lds = reinterpret_cast<float*>(smem);
     float* qn_s = lds + 4 * TILE_F;                              // [BM]
     uint32_t* tau_s = reinterpret_cast<uint32_t*>(qn_s + BM);    // [BM]
+    float* tql_s = reinterpret_cast<float*>(tau_s + BM);         // [BM] conservative float pre-filter threshold
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -63,40 +65,61 @@ __global__ void __launch_bounds__(256, 2) scan_mfma_f32_kernel(BatchParams p) {
     const uint32_t q0 = mt * BM;
     const uint32_t r0 = p.row_begin + nt * BN;
 
+    unsigned long long t_start = 0, t_pro = 0, t_loop = 0;
+    if (p.stamps) t_start = __builtin_amdgcn_s_memtime();
+
     if (tid < BM) {
-        qn_s[tid] = p.qnorm[q0 + tid];
-        tau_s[tid] = p.tau[q0 + tid];
+        const float qn = p.qnorm[q0 + tid];
+        const uint32_t tau = p.tau[q0 + tid];
+        qn_s[tid] = qn;
+        tau_s[tid] = tau;
+        // Pre-filter: "key <= tau" <=> "score >= ts" (ts = the k-th best score; NaN when there is none yet, and
+        // every comparison with NaN passes).  The epilogue tests y = dot * (1/|x|) against ts*|q| lowered by a
+        // 2e-6 relative margin (>> the rounding difference to the exact dot/(|q||x|)), so it never rejects a row
+        // the exact test would accept; the exact key is only computed for rows that pass.
+        const float ts = score_from_key(tau, METRIC);
+        const float tq = METRIC == MVF_METRIC_COSINE ? ts * qn : ts;
+        tql_s[tid] = tq - fabsf(tq) * 2e-6f;
     }
 
     // ---- staging maps: thread -> (row sr + 32*i, float4 column sc) -------------
+    // Loads are branch-free: rows past row_end read row 0 instead (their output columns are discarded
+    // in the epilogue); k beyond the row's pitch (last k-tile when dim % 32 != 0) reads the row start
+    // and is zeroed with a select, because 0 * garbage could be 0 * inf.
     const int sr = tid >> 3, sc = tid & 7;
     const float* qsrc = p.qmat + (size_t)(q0 + sr) * p.KP + sc * 4;
     const unsigned char* xsrc[4];
-    bool xok[4];
 #pragma unroll
     for (int i = 0; i < 4; i++) {
         const uint32_t r = r0 + sr + 32 * i;
-        xok[i] = r < p.row_end;
-        xsrc[i] = p.rows + (size_t)(xok[i] ? r : 0u) * p.pitch + sc * 16;
+        xsrc[i] = p.rows + (size_t)(r < p.row_end ? r : 0u) * p.pitch;
     }
-    f32x4 ra[4], rb[4];
-    auto load_tile = [&](uint32_t kt) {
+    // Staging registers: ra holds the A (query) k-tile one ahead of the LDS stage being computed; the B (corpus)
+    // k-tiles are loaded TWO ahead into alternating sets rb0/rb1: the 8 query-tile blocks of one corpus tile
+    // start together and all wait for the same HBM fetch, so every B load sees HBM latency (~2 us under load),
+    // longer than one k-tile of MFMAs.
+    f32x4 ra[4], rb0[4], rb1[4];
+    auto load_a = [&](uint32_t kt) {
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            ra[i] = *reinterpret_cast<const f32x4*>(qsrc + (size_t)i * 32 * p.KP + kt * BK);
-            const uint32_t v = kt * 8 + sc;  // 16-B vector index within the row
-            rb[i] = (xok[i] && v < p.V) ? *reinterpret_cast<const f32x4*>(xsrc[i] + (size_t)kt * (BK * 4))
-                                        : f32x4{0.f, 0.f, 0.f, 0.f};
-        }
+        for (int i = 0; i < 4; i++) ra[i] = *reinterpret_cast<const f32x4*>(qsrc + (size_t)i * 32 * p.KP + kt * BK);
     };
-    auto store_tile = [&](int stage) {
-        float* a = lds + stage * 2 * TILE_F;
-        float* bb = a + TILE_F;
+    auto load_b = [&](uint32_t kt, f32x4 (&rb)[4]) {
+        const uint32_t v = kt * 8 + sc;  // 16-B vector index within the row
+        const size_t xoff = v < p.V ? (size_t)v * 16 : 0;  // zeroed at store time if v >= V
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            *reinterpret_cast<f32x4*>(a + (sr + 32 * i) * LDP + sc * 4) = ra[i];
-            *reinterpret_cast<f32x4*>(bb + (sr + 32 * i) * LDP + sc * 4) = rb[i];
-        }
+        for (int i = 0; i < 4; i++) rb[i] = *reinterpret_cast<const f32x4*>(xsrc[i] + xoff);
+    };
+    auto store_a = [&](int stage) {
+        float* a = lds + stage * 2 * TILE_F;
+#pragma unroll
+        for (int i = 0; i < 4; i++) *reinterpret_cast<f32x4*>(a + (sr + 32 * i) * LDP + sc * 4) = ra[i];
+    };
+    auto store_b = [&](int stage, uint32_t kt, const f32x4 (&rb)[4]) {  // kt = the k-tile held in rb
+        float* bb = lds + stage * 2 * TILE_F + TILE_F;
+        const bool vok = kt * 8 + sc < p.V;
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+            *reinterpret_cast<f32x4*>(bb + (sr + 32 * i) * LDP + sc * 4) = vok ? rb[i] : f32x4{0.f, 0.f, 0.f, 0.f};
     };
 
     f32x16 acc[2][2];
@@ -107,62 +130,130 @@ __global__ void __launch_bounds__(256, 2) scan_mfma_f32_kernel(BatchParams p) {
 #pragma unroll
             for (int e = 0; e < 16; e++) acc[i][j][e] = 0.f;
 
-    load_tile(0);
-    store_tile(0);
+    // Pipeline.  LDS stage `cur` holds tile kt.  Tile kt's 64 MFMAs run as four k-groups of 16; the operand
+    // fragments of group g+1 are fetched while group g computes; the LDS stores of tile kt+1 ride in front of
+    // groups 1 (A) and 2 (B), the global loads of A tile kt+2 and B tile kt+3 in front of group 3.  (Spreading
+    // them one by one between MFMA pairs was measured 15 % SLOWER: per-op waits and branches.)  One barrier
+    // per k-tile.
+    load_a(0);
+    load_b(0, rb0);
+    store_a(0);
+    store_b(0, 0, rb0);
+    if (p.KT > 1) {
+        load_a(1);
+        load_b(1, rb1);
+    }
+    if (p.KT > 2) load_b(2, rb0);
     __syncthreads();
 
+    if (p.stamps) t_pro = __builtin_amdgcn_s_memtime();
     const int fr = lane & 31, fh = lane >> 5;
-    for (uint32_t kt = 0; kt < p.KT; kt++) {
+    struct Frag {
+        f32x4 a[2], b[2];
+    };
+    auto fetch = [&](Frag& f, const float* a, const float* bb, int ks) {
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            f.a[i] = *reinterpret_cast<const f32x4*>(a + i * 32 * LDP + ks * 8);
+            f.b[i] = *reinterpret_cast<const f32x4*>(bb + i * 32 * LDP + ks * 8);
+        }
+    };
+    auto mfma16 = [&](const Frag& f) {
+#pragma unroll
+        for (int s = 0; s < 4; s++)
+#pragma unroll
+            for (int i = 0; i < 2; i++)
+#pragma unroll
+                for (int j = 0; j < 2; j++)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[i][s], f.b[j][s], acc[i][j], 0, 0, 0);
+    };
+    Frag f0, f1;
+    // one k-tile; rb holds B tile kt+1 on entry and receives B tile kt+3
+    auto ktile = [&](uint32_t kt, f32x4 (&rb)[4]) {
         const int cur = kt & 1;
-        if (kt + 1 < p.KT) load_tile(kt + 1);
         const float* a = lds + cur * 2 * TILE_F + (wm * 64 + fr) * LDP + fh * 4;
         const float* bb = lds + cur * 2 * TILE_F + TILE_F + (wn * 64 + fr) * LDP + fh * 4;
-#pragma unroll
-        for (int ks = 0; ks < BK / 8; ks++) {
-            f32x4 fa[2], fb[2];
-#pragma unroll
-            for (int i = 0; i < 2; i++) {
-                fa[i] = *reinterpret_cast<const f32x4*>(a + i * 32 * LDP + ks * 8);
-                fb[i] = *reinterpret_cast<const f32x4*>(bb + i * 32 * LDP + ks * 8);
-            }
-#pragma unroll
-            for (int s = 0; s < 4; s++)
-#pragma unroll
-                for (int i = 0; i < 2; i++)
-#pragma unroll
-                    for (int j = 0; j < 2; j++)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][s], fb[j][s], acc[i][j], 0, 0, 0);
-        }
-        if (kt + 1 < p.KT) store_tile(cur ^ 1);
+        const bool more = kt + 1 < p.KT;
+        fetch(f0, a, bb, 0);
+        fetch(f1, a, bb, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma16(f0);                       // group 0
+        __builtin_amdgcn_sched_barrier(0);
+        fetch(f0, a, bb, 2);
+        if (more) store_a(cur ^ 1);
+        mfma16(f1);                       // group 1
+        __builtin_amdgcn_sched_barrier(0);
+        fetch(f1, a, bb, 3);
+        if (more) store_b(cur ^ 1, kt + 1, rb);
+        mfma16(f0);                       // group 2
+        __builtin_amdgcn_sched_barrier(0);
+        if (kt + 2 < p.KT) load_a(kt + 2);
+        if (kt + 3 < p.KT) load_b(kt + 3, rb);
+        mfma16(f1);                       // group 3
         __syncthreads();
+    };
+    for (uint32_t kt = 0; kt < p.KT; kt += 2) {
+        ktile(kt, rb1);
+        if (kt + 1 < p.KT) ktile(kt + 1, rb0);
     }
 
-    // ---- epilogue: score -> key, threshold filter, append ------------------------
-    // C/D map of the 32x32 MFMA: col = lane&31 (corpus row), row = (e&3) + 8*(e>>2) + 4*(lane>>5) (query)
+    if (p.stamps) t_loop = __builtin_amdgcn_s_memtime();
+    // ---- epilogue ---------------------------------------------------------------------------------
+    // C/D map of the 32x32 MFMA: col = lane&31 (corpus row), row = (e&3) + 8*(e>>2) + 4*(lane>>5) (query),
+    // so the 4 queries of one e>>2 group are contiguous in LDS (one b128 read).
+    // Fast path per score: one multiply, one compare.  Survivors are ~1 per block in the late phases, so the
+    // exact path (IEEE division as in K1, order key, atomic append) runs only for 32x32 tiles where the
+    // wave-wide ballot found a candidate.
 #pragma unroll
     for (int j = 0; j < 2; j++) {
         const uint32_t r = r0 + wn * 64 + j * 32 + fr;
         const bool rok = r < p.row_end;
-        float xn = 0.f;
-        if (METRIC == MVF_METRIC_COSINE && rok) xn = p.xnorm[r];
+        float xn = 0.f, rx = 1.f;
+        if (METRIC == MVF_METRIC_COSINE) {
+            if (rok) xn = p.xnorm[r];
+            rx = xn > 0.0f ? __builtin_amdgcn_rcpf(xn) : 0.0f;
+        }
 #pragma unroll
         for (int i = 0; i < 2; i++) {
+            uint32_t m = 0;
 #pragma unroll
-            for (int e = 0; e < 16; e++) {
-                const int ql = wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
-                float s = acc[i][j][e];
-                if (METRIC == MVF_METRIC_COSINE) {
-                    const float den = qn_s[ql] * xn;
-                    s = den > 0.0f ? s / den : 0.0f;
+            for (int g = 0; g < 4; g++) {
+                const f32x4 tql4 = *reinterpret_cast<const f32x4*>(tql_s + wm * 64 + i * 32 + 8 * g + 4 * fh);
+#pragma unroll
+                for (int t = 0; t < 4; t++) {
+                    const float y = METRIC == MVF_METRIC_COSINE ? acc[i][j][4 * g + t] * rx : acc[i][j][4 * g + t];
+                    m |= (y < tql4[t] ? 0u : 1u) << (4 * g + t);
                 }
-                const uint32_t key = key_from_score(s, METRIC);
-                const uint32_t q = q0 + ql;
-                if (rok && q < p.nq && key <= tau_s[ql]) {
-                    const uint32_t slot_i = atomicAdd(&p.cnt[q], 1u);
-                    if (slot_i < p.cap) p.cand[(size_t)q * p.cap + slot_i] = ((uint64_t)key << 32) | r;
+            }
+            if (!rok) m = 0;
+            if (__builtin_amdgcn_ballot_w64(m != 0) != 0) {  // wave-uniform: rare
+#pragma unroll
+                for (int e = 0; e < 16; e++) {
+                    if (m & (1u << e)) {
+                        const int ql = wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
+                        float sc = acc[i][j][e];
+                        if (METRIC == MVF_METRIC_COSINE) {
+                            const float den = qn_s[ql] * xn;
+                            sc = den > 0.0f ? sc / den : 0.0f;
+                        }
+                        const uint32_t key = key_from_score(sc, METRIC);
+                        const uint32_t q = q0 + ql;
+                        if (q < p.nq && key <= tau_s[ql]) {
+                            const uint32_t slot_i = atomicAdd(&p.cnt[q], 1u);
+                            if (slot_i < p.cap) p.cand[(size_t)q * p.cap + slot_i] = ((uint64_t)key << 32) | r;
+                        }
+                    }
                 }
             }
         }
+    }
+    if (p.stamps && tid == 0 && b < 65536u) {
+        const unsigned long long t_end = __builtin_amdgcn_s_memtime();
+        unsigned long long* o = p.stamps + (size_t)b * 4;
+        o[0] = t_start;
+        o[1] = t_pro;
+        o[2] = t_loop;
+        o[3] = t_end;
     }
 }
 

@@ -43,7 +43,7 @@ constexpr int AROWS = 256, BROWS = 256;     // LDS rows per operand tile
 constexpr int BKB = 128;                    // k-tile bytes per row
 constexpr int LDPB = BKB + 16;              // padded LDS row pitch in bytes
 constexpr int TILE_B = AROWS * LDPB;        // bytes per operand tile per stage
-constexpr size_t kLds16 = (size_t)4 * TILE_B + 2 * 256 * 4 + 256 * 4;  // stages + qaux0 + tau + qaux1
+constexpr size_t kLds16 = (size_t)4 * TILE_B + 4 * 256 * 4;  // stages + qaux0 + tau + qaux1 + prefilter
 
 template <int DT> struct T16;
 template <> struct T16<MVF_DTYPE_FLOAT16> {
@@ -64,6 +64,7 @@ __global__ void __launch_bounds__(512, 2) scan_mfma16_kernel(Batch16Params p) {
     float* qa_s = reinterpret_cast<float*>(smem + 4 * TILE_B);    // [256] f16: 2^-e / i8: qq (as int)
     uint32_t* tau_s = reinterpret_cast<uint32_t*>(qa_s + 256);    // [256]
     float* qb_s = reinterpret_cast<float*>(tau_s + 256);          // [256] f16: |q|
+    float* thr_s = qb_s + 256;                                    // [256] pre-filter threshold (float, or int bits)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 2, wn = wave & 3;
@@ -77,9 +78,29 @@ __global__ void __launch_bounds__(512, 2) scan_mfma16_kernel(Batch16Params p) {
     const uint32_t r0 = p.row_begin + nt * BROWS;
 
     if (tid < BMQ) {
-        qa_s[tid] = p.qaux0[q0 + tid];
-        qb_s[tid] = p.qaux1[q0 + tid];
-        tau_s[tid] = p.tau[q0 + tid];
+        const float qa = p.qaux0[q0 + tid], qb = p.qaux1[q0 + tid];
+        const uint32_t tau = p.tau[q0 + tid];
+        qa_s[tid] = qa;
+        qb_s[tid] = qb;
+        tau_s[tid] = tau;
+        // Pre-filter threshold in ACCUMULATOR units (see scan_mfma.hip): a superset test, one or two ops per score.
+        if constexpr (DT == MVF_DTYPE_FLOAT16) {
+            // score = acc * 2^-e [/ (|q||x|)] >= ts  <=>  acc [* 1/|x|] >= ts [* |q|] * 2^e
+            const float ts = score_from_key(tau, METRIC);
+            const float tq = (METRIC == MVF_METRIC_COSINE ? ts * qb : ts) / qa;
+            thr_s[tid] = tq - fabsf(tq) * 2e-6f;
+        } else {
+            const int32_t qq = __float_as_int(qa);
+            if (METRIC == MVF_METRIC_INNER_PRODUCT) {
+                thr_s[tid] = __int_as_float(raw_from_key(tau, METRIC));            // dot >= traw (exact)
+            } else if (METRIC == MVF_METRIC_L2) {
+                thr_s[tid] = __int_as_float(qq - raw_from_key(tau, METRIC));       // 2 dot - xx >= qq - traw (exact)
+            } else {
+                const float ts = score_from_key(tau, METRIC);
+                const float tq = ts * sqrtf((float)qq);                            // dot * 1/|x| >= ts * |q|
+                thr_s[tid] = tq - fabsf(tq) * 2e-6f;
+            }
+        }
     }
 
     // ---- staging: thread -> 16-B chunk (row sr + 64*i, column sc) of each tile ----------
@@ -159,12 +180,14 @@ __global__ void __launch_bounds__(512, 2) scan_mfma16_kernel(Batch16Params p) {
         __syncthreads();
     }
 
-    // ---- epilogue (C/D map: col = lane&31 -> corpus row, row = (e&3)+8*(e>>2)+4*(lane>>5) -> query)
+    // ---- epilogue (C/D map: col = lane&31 -> corpus row, row = (e&3)+8*(e>>2)+4*(lane>>5) -> query) ------
+    // Fast path: one or two ops + a compare per score against the per-query pre-filter; the exact key and the
+    // atomic append run only for 32x32 tiles where the wave-wide ballot found a candidate (rare).
 #pragma unroll
     for (int j = 0; j < 2; j++) {
         const uint32_t r = r0 + wn * 64 + j * 32 + fr;
         const bool rok = r < p.row_end;
-        float xnf = 0.f;
+        float xnf = 0.f, rx = 1.f;
         int32_t xxi = 0;
         if (rok) {
             if constexpr (DT == MVF_DTYPE_FLOAT16) {
@@ -173,35 +196,64 @@ __global__ void __launch_bounds__(512, 2) scan_mfma16_kernel(Batch16Params p) {
                 if (METRIC != MVF_METRIC_INNER_PRODUCT) xxi = p.xnorm_i[r];
             }
         }
+        if (METRIC == MVF_METRIC_COSINE) {
+            if constexpr (DT == MVF_DTYPE_FLOAT16) rx = xnf > 0.0f ? __builtin_amdgcn_rcpf(xnf) : 0.0f;
+            else rx = xxi > 0 ? __builtin_amdgcn_rcpf(sqrtf((float)xxi)) : 0.0f;
+        }
 #pragma unroll
         for (int i = 0; i < IT; i++) {
+            uint32_t m = 0;
 #pragma unroll
-            for (int e = 0; e < 16; e++) {
-                const int ql = wm * (BMQ / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
-                uint32_t key;
-                if constexpr (DT == MVF_DTYPE_FLOAT16) {
-                    float s = acc[i][j][e] * qa_s[ql];  // undo the power-of-two query scale (exact)
-                    if (METRIC == MVF_METRIC_COSINE) {
-                        const float den = qb_s[ql] * xnf;
-                        s = den > 0.0f ? s / den : 0.0f;
-                    }
-                    key = key_from_score(s, METRIC);
-                } else {
-                    const int32_t dot = acc[i][j][e];
-                    const int32_t qq = __float_as_int(qa_s[ql]);
-                    if (METRIC == MVF_METRIC_L2) {
-                        key = key_from_raw(qq + xxi - 2 * dot, METRIC);
+            for (int g = 0; g < 4; g++) {
+                const u32x4 th4 = *reinterpret_cast<const u32x4*>(thr_s + wm * (BMQ / 2) + i * 32 + 8 * g + 4 * fh);
+#pragma unroll
+                for (int t = 0; t < 4; t++) {
+                    bool pass;
+                    if constexpr (DT == MVF_DTYPE_FLOAT16) {
+                        const float y = METRIC == MVF_METRIC_COSINE ? acc[i][j][4 * g + t] * rx : acc[i][j][4 * g + t];
+                        pass = !(y < __uint_as_float(th4[t]));
                     } else if (METRIC == MVF_METRIC_INNER_PRODUCT) {
-                        key = key_from_raw(dot, METRIC);
+                        pass = acc[i][j][4 * g + t] >= (int32_t)th4[t];
+                    } else if (METRIC == MVF_METRIC_L2) {
+                        pass = 2 * acc[i][j][4 * g + t] - xxi >= (int32_t)th4[t];
                     } else {
-                        const float den = sqrtf((float)qq) * sqrtf((float)xxi);
-                        key = key_from_score(den > 0.0f ? (float)dot / den : 0.0f, METRIC);
+                        pass = !((float)acc[i][j][4 * g + t] * rx < __uint_as_float(th4[t]));
                     }
+                    m |= (pass ? 1u : 0u) << (4 * g + t);
                 }
-                const uint32_t q = q0 + ql;
-                if (rok && q < p.nq && key <= tau_s[ql]) {
-                    const uint32_t slot_i = atomicAdd(&p.cnt[q], 1u);
-                    if (slot_i < p.cap) p.cand[(size_t)q * p.cap + slot_i] = ((uint64_t)key << 32) | r;
+            }
+            if (!rok) m = 0;
+            if (__builtin_amdgcn_ballot_w64(m != 0) != 0) {  // wave-uniform: rare
+#pragma unroll
+                for (int e = 0; e < 16; e++) {
+                    if (m & (1u << e)) {
+                        const int ql = wm * (BMQ / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
+                        uint32_t key;
+                        if constexpr (DT == MVF_DTYPE_FLOAT16) {
+                            float sc = acc[i][j][e] * qa_s[ql];  // undo the power-of-two query scale (exact)
+                            if (METRIC == MVF_METRIC_COSINE) {
+                                const float den = qb_s[ql] * xnf;
+                                sc = den > 0.0f ? sc / den : 0.0f;
+                            }
+                            key = key_from_score(sc, METRIC);
+                        } else {
+                            const int32_t dot = acc[i][j][e];
+                            const int32_t qq = __float_as_int(qa_s[ql]);
+                            if (METRIC == MVF_METRIC_L2) {
+                                key = key_from_raw(qq + xxi - 2 * dot, METRIC);
+                            } else if (METRIC == MVF_METRIC_INNER_PRODUCT) {
+                                key = key_from_raw(dot, METRIC);
+                            } else {
+                                const float den = sqrtf((float)qq) * sqrtf((float)xxi);
+                                key = key_from_score(den > 0.0f ? (float)dot / den : 0.0f, METRIC);
+                            }
+                        }
+                        const uint32_t q = q0 + ql;
+                        if (q < p.nq && key <= tau_s[ql]) {
+                            const uint32_t slot_i = atomicAdd(&p.cnt[q], 1u);
+                            if (slot_i < p.cap) p.cand[(size_t)q * p.cap + slot_i] = ((uint64_t)key << 32) | r;
+                        }
+                    }
                 }
             }
         }
