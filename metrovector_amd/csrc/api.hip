@@ -379,25 +379,8 @@ int search_batched_path(const mvfgpu_corpus* c, uint8_t metric, const void* d_qu
             bp.row_end = hp.row_end = (uint32_t)end;
             bp.ntiles = hp.ntiles = (uint32_t)((end - begin + tile_rows - 1) / tile_rows);
             if (ps && last) HIP_TRY(hipEventRecord(ps->e[0], s));
-            static unsigned long long* dbg_stamps = nullptr;  // MVF_K2_STAMPS=<file>: dump s_memtime stamps of the last phase
-            const char* stamp_file = getenv("MVF_K2_STAMPS");
-            if (stamp_file && last && wide) {
-                if (!dbg_stamps) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&dbg_stamps), 65536 * 32));
-                HIP_TRY(hipMemsetAsync(dbg_stamps, 0, 65536 * 32, s));
-                bp.stamps = dbg_stamps;
-            }
-            if (wide) HIP_TRY(launch_scan_mfma_f32(bp, metric, s));
-            else HIP_TRY(launch_scan_mfma16(hp, c->dtype, metric, s));
-            if (bp.stamps) {
-                std::vector<unsigned long long> h(65536 * 4);
-                HIP_TRY(hipMemcpyAsync(h.data(), dbg_stamps, 65536 * 32, hipMemcpyDeviceToHost, s));
-                HIP_TRY(hipStreamSynchronize(s));
-                if (FILE* f = fopen(stamp_file, "wb")) {
-                    fwrite(h.data(), 8, h.size(), f);
-                    fclose(f);
-                }
-                bp.stamps = nullptr;
-            }
+            if (wide) HIP_TRY(launch_scan_mfma_f32(bp, metric, c->num_cus, s));
+            else HIP_TRY(launch_scan_mfma16(hp, c->dtype, metric, c->num_cus, s));
             if (ps && last) {
                 HIP_TRY(hipEventRecord(ps->e[1], s));
                 ps->scanned = true;

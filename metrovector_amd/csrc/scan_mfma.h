@@ -22,7 +22,6 @@ struct BatchParams {
     uint32_t row_begin, row_end;  // rows of this launch (phase)
     uint32_t ntiles, mtiles;      // ceil((row_end-row_begin)/128), nq_pad/128
     uint32_t cap;
-    unsigned long long* stamps;   // diagnostic build aid: [65536][4] s_memtime stamps (start, prologue, k-loop, end) or NULL
 };
 
 // K2 for 16-byte-operand MFMAs (Float16 / Int8 rows), scan_mfma16.hip
@@ -61,14 +60,14 @@ struct CompactParams {
 constexpr uint32_t kBatchCap = 4096;  // candidate slots per query between compactions (32 KiB of LDS to sort)
 
 size_t scan_mfma_lds_bytes();
-hipError_t launch_scan_mfma_f32(const BatchParams& p, int metric, hipStream_t s);
+hipError_t launch_scan_mfma_f32(const BatchParams& p, int metric, int num_cus, hipStream_t s);
 hipError_t launch_prep_queries(const float* q, uint32_t nq, uint32_t nq_pad, uint32_t dim, uint32_t KP, float* qmat,
                                float* qnorm, hipStream_t s);
 hipError_t launch_row_norms_f32(const unsigned char* rows, uint32_t n, uint32_t pitch, float* xnorm, hipStream_t s);
 hipError_t launch_compact(const CompactParams& p, uint32_t nq, bool final_stage, hipStream_t s);
 
 uint32_t scan_mfma16_queries_per_block(int dtype);
-hipError_t launch_scan_mfma16(const Batch16Params& p, int dtype, int metric, hipStream_t s);
+hipError_t launch_scan_mfma16(const Batch16Params& p, int dtype, int metric, int num_cus, hipStream_t s);
 hipError_t launch_prep_queries16(const void* q, int dtype, uint32_t nq, uint32_t nq_pad, uint32_t dim, uint32_t KPB,
                                  unsigned char* qprep, float* qaux0, float* qaux1, hipStream_t s);
 hipError_t launch_row_norms16(const unsigned char* rows, int dtype, uint32_t n, uint32_t pitch, void* out, hipStream_t s);

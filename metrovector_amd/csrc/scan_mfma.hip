@@ -56,65 +56,93 @@ __global__ void __launch_bounds__(256, 2) scan_mfma_f32_kernel(BatchParams p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
 
-    // XCD-aware tile order
-    const uint32_t b = blockIdx.x;
-    const uint32_t xcd = b & 7u, slot = b >> 3;
-    const uint32_t nt = (slot / p.mtiles) * 8u + xcd;
-    const uint32_t mt = slot % p.mtiles;
-    if (nt >= p.ntiles) return;
-    const uint32_t q0 = mt * BM;
-    const uint32_t r0 = p.row_begin + nt * BN;
-
-    unsigned long long t_start = 0, t_pro = 0, t_loop = 0;
-    if (p.stamps) t_start = __builtin_amdgcn_s_memtime();
-
-    if (tid < BM) {
-        const float qn = p.qnorm[q0 + tid];
-        const uint32_t tau = p.tau[q0 + tid];
-        qn_s[tid] = qn;
-        tau_s[tid] = tau;
-        // Pre-filter: "key <= tau" <=> "score >= ts" (ts = the k-th best score; NaN when there is none yet, and
-        // every comparison with NaN passes).  The epilogue tests y = dot * (1/|x|) against ts*|q| lowered by a
-        // 2e-6 relative margin (>> the rounding difference to the exact dot/(|q||x|)), so it never rejects a row
-        // the exact test would accept; the exact key is only computed for rows that pass.
-        const float ts = score_from_key(tau, METRIC);
-        const float tq = METRIC == MVF_METRIC_COSINE ? ts * qn : ts;
-        tql_s[tid] = tq - fabsf(tq) * 2e-6f;
-    }
-
-    // ---- staging maps: thread -> (row sr + 32*i, float4 column sc) -------------
-    // Loads are branch-free: rows past row_end read row 0 instead (their output columns are discarded
-    // in the epilogue); k beyond the row's pitch (last k-tile when dim % 32 != 0) reads the row start
-    // and is zeroed with a select, because 0 * garbage could be 0 * inf.
-    const int sr = tid >> 3, sc = tid & 7;
-    const float* qsrc = p.qmat + (size_t)(q0 + sr) * p.KP + sc * 4;
-    const unsigned char* xsrc[4];
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const uint32_t r = r0 + sr + 32 * i;
-        xsrc[i] = p.rows + (size_t)(r < p.row_end ? r : 0u) * p.pitch;
-    }
-    // Staging registers: ra holds the A (query) k-tile one ahead of the LDS stage being computed; the B (corpus)
-    // k-tiles are loaded TWO ahead into alternating sets rb0/rb1: the 8 query-tile blocks of one corpus tile
-    // start together and all wait for the same HBM fetch, so every B load sees HBM latency (~2 us under load),
-    // longer than one k-tile of MFMAs.
-    f32x4 ra[4], rb0[4], rb1[4];
-    auto load_a = [&](uint32_t kt) {
-#pragma unroll
-        for (int i = 0; i < 4; i++) ra[i] = *reinterpret_cast<const f32x4*>(qsrc + (size_t)i * 32 * p.KP + kt * BK);
+    // PERSISTENT blocks, XCD-aware tile order.  Blocks b and b+8 share an XCD (round-robin dispatch): block b is
+    // lane `ls` of XCD `xcd` and walks the slots ls, ls+nls, ls+2*nls, ...; slot -> (corpus tile, query tile) puts
+    // the query tiles of one corpus tile on consecutive lanes of one XCD, so the corpus tile is fetched from HBM
+    // once and re-served from that XCD's L2.  The load pipeline runs ACROSS tile boundaries, so only the first
+    // tile of a block pays the HBM round trips of a prologue (in-kernel stamps: prologue + dispatch gap + the
+    // old epilogue were 30 % of a one-tile-per-block launch).
+    const uint32_t xcd = blockIdx.x & 7u, ls = blockIdx.x >> 3, nls = gridDim.x >> 3;
+    auto slot_tile = [&](uint32_t n, uint32_t& nt, uint32_t& mt) {  // n-th work item of this block
+        const uint32_t slot = ls + n * nls;
+        nt = (slot / p.mtiles) * 8u + xcd;
+        mt = slot % p.mtiles;
+        return nt < p.ntiles;
     };
-    auto load_b = [&](uint32_t kt, f32x4 (&rb)[4]) {
-        const uint32_t v = kt * 8 + sc;  // 16-B vector index within the row
-        const size_t xoff = v < p.V ? (size_t)v * 16 : 0;  // zeroed at store time if v >= V
+    uint32_t my_tiles = 0;
+    {
+        // slots are visited in increasing order and nt is monotone in the slot: count the valid prefix
+        const uint32_t max_slot_excl = ((p.ntiles + 7u - xcd) / 8u) * p.mtiles;  // first slot whose nt >= ntiles
+        if (ls < max_slot_excl) my_tiles = (max_slot_excl - ls + nls - 1) / nls;
+    }
+    if (my_tiles == 0) return;
+    const uint32_t G = my_tiles * p.KT;  // flat k-tile count of this block
+
+    auto load_query_consts = [&](uint32_t q0) {
+        if (tid < BM) {
+            const float qn = p.qnorm[q0 + tid];
+            const uint32_t tau = p.tau[q0 + tid];
+            qn_s[tid] = qn;
+            tau_s[tid] = tau;
+            // Pre-filter: "key <= tau" <=> "score >= ts" (ts = the k-th best score; NaN when there is none yet, and
+            // every comparison with NaN passes).  The epilogue tests y = dot * (1/|x|) against ts*|q| lowered by a
+            // 2e-6 relative margin (>> the rounding difference to the exact dot/(|q||x|)), so it never rejects a
+            // row the exact test would accept; the exact key is only computed for rows that pass.
+            const float ts = score_from_key(tau, METRIC);
+            const float tq = METRIC == MVF_METRIC_COSINE ? ts * qn : ts;
+            tql_s[tid] = tq - fabsf(tq) * 2e-6f;
+        }
+    };
+
+    // ---- staging maps: thread -> (row sr + 32*i, float4 column sc) ------------------------------------------
+    // Loads are branch-free: rows past row_end read row 0 instead (their output columns are discarded in the
+    // epilogue); k beyond the row's pitch (last k-tile when dim % 32 != 0) reads the row start and is zeroed with
+    // a select at LDS-store time, because 0 * garbage could be 0 * inf.
+    const int sr = tid >> 3, sc = tid & 7;
+    // load cursors: flat position (tile ordinal, k-tile) of the next A / B global load
+    uint32_t a_n = 0, a_kt = 0, b_n = 0, b_kt = 0;
+    const float* qsrc = nullptr;
+    const unsigned char* xsrc[4];
+    auto set_a_tile = [&](uint32_t n) {
+        uint32_t nt, mt;
+        slot_tile(n, nt, mt);
+        qsrc = p.qmat + (size_t)(mt * BM + sr) * p.KP + sc * 4;
+    };
+    auto set_b_tile = [&](uint32_t n) {
+        uint32_t nt, mt;
+        slot_tile(n, nt, mt);
+        const uint32_t r0 = p.row_begin + nt * BN;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const uint32_t r = r0 + sr + 32 * i;
+            xsrc[i] = p.rows + (size_t)(r < p.row_end ? r : 0u) * p.pitch;
+        }
+    };
+    f32x4 ra[4], rb[4];
+    auto load_a = [&]() {  // next A k-tile of the flat sequence -> ra
+#pragma unroll
+        for (int i = 0; i < 4; i++) ra[i] = *reinterpret_cast<const f32x4*>(qsrc + (size_t)i * 32 * p.KP + a_kt * BK);
+        if (++a_kt == p.KT) {
+            a_kt = 0;
+            if (++a_n < my_tiles) set_a_tile(a_n);
+        }
+    };
+    auto load_b = [&]() {  // next B k-tile of the flat sequence -> rb
+        const uint32_t v = b_kt * 8 + sc;  // 16-B vector index within the row
+        const size_t xoff = v < p.V ? (size_t)v * 16 : 0;
 #pragma unroll
         for (int i = 0; i < 4; i++) rb[i] = *reinterpret_cast<const f32x4*>(xsrc[i] + xoff);
+        if (++b_kt == p.KT) {
+            b_kt = 0;
+            if (++b_n < my_tiles) set_b_tile(b_n);
+        }
     };
     auto store_a = [&](int stage) {
         float* a = lds + stage * 2 * TILE_F;
 #pragma unroll
         for (int i = 0; i < 4; i++) *reinterpret_cast<f32x4*>(a + (sr + 32 * i) * LDP + sc * 4) = ra[i];
     };
-    auto store_b = [&](int stage, uint32_t kt, const f32x4 (&rb)[4]) {  // kt = the k-tile held in rb
+    auto store_b = [&](int stage, uint32_t kt) {  // kt = the k-tile (within its tile) held in rb
         float* bb = lds + stage * 2 * TILE_F + TILE_F;
         const bool vok = kt * 8 + sc < p.V;
 #pragma unroll
@@ -123,30 +151,38 @@ __global__ void __launch_bounds__(256, 2) scan_mfma_f32_kernel(BatchParams p) {
     };
 
     f32x16 acc[2][2];
+    auto zero_acc = [&]() {
 #pragma unroll
-    for (int i = 0; i < 2; i++)
+        for (int i = 0; i < 2; i++)
 #pragma unroll
-        for (int j = 0; j < 2; j++)
+            for (int j = 0; j < 2; j++)
 #pragma unroll
-            for (int e = 0; e < 16; e++) acc[i][j][e] = 0.f;
+                for (int e = 0; e < 16; e++) acc[i][j][e] = 0.f;
+    };
+    zero_acc();
 
-    // Pipeline.  LDS stage `cur` holds tile kt.  Tile kt's 64 MFMAs run as four k-groups of 16; the operand
-    // fragments of group g+1 are fetched while group g computes; the LDS stores of tile kt+1 ride in front of
-    // groups 1 (A) and 2 (B), the global loads of A tile kt+2 and B tile kt+3 in front of group 3.  (Spreading
-    // them one by one between MFMA pairs was measured 15 % SLOWER: per-op waits and branches.)  One barrier
-    // per k-tile.
-    load_a(0);
-    load_b(0, rb0);
+    // compute cursor
+    uint32_t c_n = 0, c_kt = 0, c_nt, c_mt;
+    slot_tile(0, c_nt, c_mt);
+    load_query_consts(c_mt * BM);
+
+    // Pipeline.  LDS stage g&1 holds flat k-tile g; the staging registers hold k-tile g+1.  A k-tile's 64 MFMAs
+    // run as four k-groups of 16; the operand fragments of group x+1 are fetched while group x computes; the LDS
+    // stores of k-tile g+1 ride in front of groups 1 (A) and 2 (B), the global loads of k-tile g+2 in front of
+    // group 3.  (Spreading them one by one between MFMA pairs was measured 15 % SLOWER: per-op waits and
+    // branches; loading B two k-tiles ahead changed nothing.)  One barrier per k-tile.
+    set_a_tile(0);
+    set_b_tile(0);
+    load_a();
+    load_b();
     store_a(0);
-    store_b(0, 0, rb0);
-    if (p.KT > 1) {
-        load_a(1);
-        load_b(1, rb1);
+    store_b(0, 0);
+    if (G > 1) {
+        load_a();
+        load_b();
     }
-    if (p.KT > 2) load_b(2, rb0);
     __syncthreads();
 
-    if (p.stamps) t_pro = __builtin_amdgcn_s_memtime();
     const int fr = lane & 31, fh = lane >> 5;
     struct Frag {
         f32x4 a[2], b[2];
@@ -167,13 +203,70 @@ __global__ void __launch_bounds__(256, 2) scan_mfma_f32_kernel(BatchParams p) {
                 for (int j = 0; j < 2; j++)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[i][s], f.b[j][s], acc[i][j], 0, 0, 0);
     };
+
+    // ---- epilogue of one finished tile ---------------------------------------------------------------------
+    // C/D map of the 32x32 MFMA: col = lane&31 (corpus row), row = (e&3) + 8*(e>>2) + 4*(lane>>5) (query), so
+    // the 4 queries of one e>>2 group are contiguous in LDS (one b128 read).  Fast path per score: one multiply,
+    // one compare.  Survivors are ~1 per tile in the late phases, so the exact path (IEEE division as in K1,
+    // order key, atomic append) runs only for 32x32 tiles where the wave-wide ballot found a candidate.
+    auto epilogue = [&](uint32_t nt, uint32_t mt) {
+        const uint32_t q0 = mt * BM, r0 = p.row_begin + nt * BN;
+        // keep the epilogue's address arithmetic inside the epilogue: hoisted out of the k-tile loop it costs
+        // ~60 VGPRs there and spills
+        int lane_q = wm * 64 + 4 * fh, lane_r = wn * 64 + fr;
+        asm volatile("" : "+v"(lane_q), "+v"(lane_r));
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const uint32_t r = r0 + lane_r + j * 32;
+            const bool rok = r < p.row_end;
+            float xn = 0.f, rx = 1.f;
+            if (METRIC == MVF_METRIC_COSINE) {
+                if (rok) xn = p.xnorm[r];
+                rx = xn > 0.0f ? __builtin_amdgcn_rcpf(xn) : 0.0f;
+            }
+#pragma unroll
+            for (int i = 0; i < 2; i++) {
+                uint32_t m = 0;
+#pragma unroll
+                for (int g = 0; g < 4; g++) {
+                    const f32x4 tql4 = *reinterpret_cast<const f32x4*>(tql_s + lane_q + i * 32 + 8 * g);
+#pragma unroll
+                    for (int t = 0; t < 4; t++) {
+                        const float y = METRIC == MVF_METRIC_COSINE ? acc[i][j][4 * g + t] * rx : acc[i][j][4 * g + t];
+                        m |= (y < tql4[t] ? 0u : 1u) << (4 * g + t);
+                    }
+                }
+                if (!rok) m = 0;
+                if (__builtin_amdgcn_ballot_w64(m != 0) != 0) {  // wave-uniform: rare
+#pragma unroll
+                    for (int e = 0; e < 16; e++) {
+                        if (m & (1u << e)) {
+                            const int ql = lane_q + i * 32 + (e & 3) + 8 * (e >> 2);
+                            float sc_ = acc[i][j][e];
+                            if (METRIC == MVF_METRIC_COSINE) {
+                                const float den = qn_s[ql] * xn;
+                                sc_ = den > 0.0f ? sc_ / den : 0.0f;
+                            }
+                            const uint32_t key = key_from_score(sc_, METRIC);
+                            const uint32_t q = q0 + ql;
+                            if (q < p.nq && key <= tau_s[ql]) {
+                                const uint32_t slot_i = atomicAdd(&p.cnt[q], 1u);
+                                if (slot_i < p.cap) p.cand[(size_t)q * p.cap + slot_i] = ((uint64_t)key << 32) | r;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    };
+
     Frag f0, f1;
-    // one k-tile; rb holds B tile kt+1 on entry and receives B tile kt+3
-    auto ktile = [&](uint32_t kt, f32x4 (&rb)[4]) {
-        const int cur = kt & 1;
+    for (uint32_t g = 0; g < G; g++) {
+        const int cur = g & 1;
         const float* a = lds + cur * 2 * TILE_F + (wm * 64 + fr) * LDP + fh * 4;
         const float* bb = lds + cur * 2 * TILE_F + TILE_F + (wn * 64 + fr) * LDP + fh * 4;
-        const bool more = kt + 1 < p.KT;
+        const bool more = g + 1 < G, more2 = g + 2 < G;
+        const uint32_t next_kt = c_kt + 1 == p.KT ? 0u : c_kt + 1;  // k-tile (within its tile) held in the staging registers
         fetch(f0, a, bb, 0);
         fetch(f1, a, bb, 1);
         __builtin_amdgcn_sched_barrier(0);
@@ -184,76 +277,30 @@ __global__ void __launch_bounds__(256, 2) scan_mfma_f32_kernel(BatchParams p) {
         mfma16(f1);                       // group 1
         __builtin_amdgcn_sched_barrier(0);
         fetch(f1, a, bb, 3);
-        if (more) store_b(cur ^ 1, kt + 1, rb);
+        if (more) store_b(cur ^ 1, next_kt);
         mfma16(f0);                       // group 2
         __builtin_amdgcn_sched_barrier(0);
-        if (kt + 2 < p.KT) load_a(kt + 2);
-        if (kt + 3 < p.KT) load_b(kt + 3, rb);
+        if (more2) {
+            load_a();
+            load_b();
+        }
         mfma16(f1);                       // group 3
         __syncthreads();
-    };
-    for (uint32_t kt = 0; kt < p.KT; kt += 2) {
-        ktile(kt, rb1);
-        if (kt + 1 < p.KT) ktile(kt + 1, rb0);
-    }
-
-    if (p.stamps) t_loop = __builtin_amdgcn_s_memtime();
-    // ---- epilogue ---------------------------------------------------------------------------------
-    // C/D map of the 32x32 MFMA: col = lane&31 (corpus row), row = (e&3) + 8*(e>>2) + 4*(lane>>5) (query),
-    // so the 4 queries of one e>>2 group are contiguous in LDS (one b128 read).
-    // Fast path per score: one multiply, one compare.  Survivors are ~1 per block in the late phases, so the
-    // exact path (IEEE division as in K1, order key, atomic append) runs only for 32x32 tiles where the
-    // wave-wide ballot found a candidate.
-#pragma unroll
-    for (int j = 0; j < 2; j++) {
-        const uint32_t r = r0 + wn * 64 + j * 32 + fr;
-        const bool rok = r < p.row_end;
-        float xn = 0.f, rx = 1.f;
-        if (METRIC == MVF_METRIC_COSINE) {
-            if (rok) xn = p.xnorm[r];
-            rx = xn > 0.0f ? __builtin_amdgcn_rcpf(xn) : 0.0f;
-        }
-#pragma unroll
-        for (int i = 0; i < 2; i++) {
-            uint32_t m = 0;
-#pragma unroll
-            for (int g = 0; g < 4; g++) {
-                const f32x4 tql4 = *reinterpret_cast<const f32x4*>(tql_s + wm * 64 + i * 32 + 8 * g + 4 * fh);
-#pragma unroll
-                for (int t = 0; t < 4; t++) {
-                    const float y = METRIC == MVF_METRIC_COSINE ? acc[i][j][4 * g + t] * rx : acc[i][j][4 * g + t];
-                    m |= (y < tql4[t] ? 0u : 1u) << (4 * g + t);
-                }
-            }
-            if (!rok) m = 0;
-            if (__builtin_amdgcn_ballot_w64(m != 0) != 0) {  // wave-uniform: rare
-#pragma unroll
-                for (int e = 0; e < 16; e++) {
-                    if (m & (1u << e)) {
-                        const int ql = wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
-                        float sc = acc[i][j][e];
-                        if (METRIC == MVF_METRIC_COSINE) {
-                            const float den = qn_s[ql] * xn;
-                            sc = den > 0.0f ? sc / den : 0.0f;
-                        }
-                        const uint32_t key = key_from_score(sc, METRIC);
-                        const uint32_t q = q0 + ql;
-                        if (q < p.nq && key <= tau_s[ql]) {
-                            const uint32_t slot_i = atomicAdd(&p.cnt[q], 1u);
-                            if (slot_i < p.cap) p.cand[(size_t)q * p.cap + slot_i] = ((uint64_t)key << 32) | r;
-                        }
-                    }
+        if (++c_kt == p.KT) {  // tile finished: the next tile's first k-tile is already in LDS, its loads in flight
+            epilogue(c_nt, c_mt);
+            zero_acc();
+            c_kt = 0;
+            if (++c_n < my_tiles) {
+                uint32_t nmt;
+                slot_tile(c_n, c_nt, nmt);
+                if (nmt != c_mt) {  // block-uniform; rare (grid lanes per XCD not a multiple of the query tiles)
+                    __syncthreads();
+                    load_query_consts(nmt * BM);
+                    __syncthreads();
+                    c_mt = nmt;
                 }
             }
         }
-    }
-    if (p.stamps && tid == 0 && b < 65536u) {
-        const unsigned long long t_end = __builtin_amdgcn_s_memtime();
-        unsigned long long* o = p.stamps + (size_t)b * 4;
-        o[0] = t_start;
-        o[1] = t_pro;
-        o[2] = t_loop;
-        o[3] = t_end;
     }
 }
 
@@ -351,9 +398,13 @@ __global__ void __launch_bounds__(1024) compact_kernel(CompactParams p) {
 
 size_t scan_mfma_lds_bytes() { return kLdsBytes; }
 
-hipError_t launch_scan_mfma_f32(const BatchParams& p, int metric, hipStream_t s) {
-    const uint32_t groups = (p.ntiles + 7) / 8;
-    const dim3 grid(groups * p.mtiles * 8);
+hipError_t launch_scan_mfma_f32(const BatchParams& p, int metric, int num_cus, hipStream_t s) {
+    // persistent grid: 2 blocks per CU (LDS-limited), a multiple of 8 (one lane set per XCD); per-XCD lanes are
+    // rounded to a multiple of the query-tile count when possible so a block keeps its query tile
+    const uint32_t total = ((p.ntiles + 7) / 8) * p.mtiles * 8;
+    uint32_t nls = std::max(1u, (uint32_t)num_cus * 2u / 8u);
+    if (nls > p.mtiles) nls -= nls % p.mtiles;
+    const dim3 grid(std::min(total, nls * 8u));
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&scan_mfma_f32_kernel<MVF_METRIC_COSINE>),

@@ -30,6 +30,8 @@
 
 #include <hip/hip_fp16.h>
 
+#include <cstdlib>
+
 namespace mvf {
 namespace {
 
@@ -69,194 +71,288 @@ __global__ void __launch_bounds__(512, 2) scan_mfma16_kernel(Batch16Params p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 2, wn = wave & 3;
 
-    const uint32_t b = blockIdx.x;
-    const uint32_t xcd = b & 7u, slot = b >> 3;
-    const uint32_t nt = (slot / p.mtiles) * 8u + xcd;
-    const uint32_t mt = slot % p.mtiles;
-    if (nt >= p.ntiles) return;
-    const uint32_t q0 = mt * BMQ;
-    const uint32_t r0 = p.row_begin + nt * BROWS;
+    // PERSISTENT blocks, XCD-aware tile order, load pipeline running across tile boundaries — see
+    // scan_mfma.hip.  It matters more here: the LDS image allows ONE block per CU, so with one tile per block
+    // every prologue (two HBM round trips), epilogue and dispatch gap was fully exposed (~10 of 18 us per tile).
+    const uint32_t xcd = blockIdx.x & 7u, ls = blockIdx.x >> 3, nls = gridDim.x >> 3;
+    auto slot_tile = [&](uint32_t n, uint32_t& nt, uint32_t& mt) {
+        const uint32_t slot = ls + n * nls;
+        nt = (slot / p.mtiles) * 8u + xcd;
+        mt = slot % p.mtiles;
+        return nt < p.ntiles;
+    };
+    uint32_t my_tiles = 0;
+    {
+        const uint32_t max_slot_excl = ((p.ntiles + 7u - xcd) / 8u) * p.mtiles;
+        if (ls < max_slot_excl) my_tiles = (max_slot_excl - ls + nls - 1) / nls;
+    }
+    if (my_tiles == 0) return;
+    const uint32_t G = my_tiles * p.KT;
 
-    if (tid < BMQ) {
-        const float qa = p.qaux0[q0 + tid], qb = p.qaux1[q0 + tid];
-        const uint32_t tau = p.tau[q0 + tid];
-        qa_s[tid] = qa;
-        qb_s[tid] = qb;
-        tau_s[tid] = tau;
-        // Pre-filter threshold in ACCUMULATOR units (see scan_mfma.hip): a superset test, one or two ops per score.
-        if constexpr (DT == MVF_DTYPE_FLOAT16) {
-            // score = acc * 2^-e [/ (|q||x|)] >= ts  <=>  acc [* 1/|x|] >= ts [* |q|] * 2^e
-            const float ts = score_from_key(tau, METRIC);
-            const float tq = (METRIC == MVF_METRIC_COSINE ? ts * qb : ts) / qa;
-            thr_s[tid] = tq - fabsf(tq) * 2e-6f;
-        } else {
-            const int32_t qq = __float_as_int(qa);
-            if (METRIC == MVF_METRIC_INNER_PRODUCT) {
-                thr_s[tid] = __int_as_float(raw_from_key(tau, METRIC));            // dot >= traw (exact)
-            } else if (METRIC == MVF_METRIC_L2) {
-                thr_s[tid] = __int_as_float(qq - raw_from_key(tau, METRIC));       // 2 dot - xx >= qq - traw (exact)
-            } else {
+    auto load_query_consts = [&](uint32_t q0) {
+        if (tid < BMQ) {
+            const float qa = p.qaux0[q0 + tid], qb = p.qaux1[q0 + tid];
+            const uint32_t tau = p.tau[q0 + tid];
+            qa_s[tid] = qa;
+            qb_s[tid] = qb;
+            tau_s[tid] = tau;
+            // Pre-filter threshold in ACCUMULATOR units (see scan_mfma.hip): a superset test, one or two ops per score.
+            if constexpr (DT == MVF_DTYPE_FLOAT16) {
+                // score = acc * 2^-e [/ (|q||x|)] >= ts  <=>  acc [* 1/|x|] >= ts [* |q|] * 2^e
                 const float ts = score_from_key(tau, METRIC);
-                const float tq = ts * sqrtf((float)qq);                            // dot * 1/|x| >= ts * |q|
+                const float tq = (METRIC == MVF_METRIC_COSINE ? ts * qb : ts) / qa;
                 thr_s[tid] = tq - fabsf(tq) * 2e-6f;
+            } else {
+                const int32_t qq = __float_as_int(qa);
+                if (METRIC == MVF_METRIC_INNER_PRODUCT) {
+                    thr_s[tid] = __int_as_float(raw_from_key(tau, METRIC));            // dot >= traw (exact)
+                } else if (METRIC == MVF_METRIC_L2) {
+                    thr_s[tid] = __int_as_float(qq - raw_from_key(tau, METRIC));       // 2 dot - xx >= qq - traw (exact)
+                } else {
+                    const float ts = score_from_key(tau, METRIC);
+                    const float tq = ts * sqrtf((float)qq);                            // dot * 1/|x| >= ts * |q|
+                    thr_s[tid] = tq - fabsf(tq) * 2e-6f;
+                }
             }
         }
-    }
+    };
 
     // ---- staging: thread -> 16-B chunk (row sr + 64*i, column sc) of each tile ----------
+    // Branch-free loads: rows past row_end read row 0 (their output columns are discarded in the epilogue);
+    // k beyond the row's pitch reads the row start and is zeroed with a select at LDS-store time.
     const int sr = tid >> 3, sc = tid & 7;
+    uint32_t a_n = 0, a_kt = 0, b_n = 0, b_kt = 0;  // load cursors: (tile ordinal, k-tile) of the next A / B load
     const unsigned char* asrc[4];
     const unsigned char* xsrc[4];
-    bool xok[4];
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const int ar = sr + 64 * i;                      // LDS A row: plane = ar / BMQ, query = ar % BMQ
-        asrc[i] = p.qprep + ((size_t)(ar / BMQ) * p.nq_pad + q0 + (ar % BMQ)) * p.KPB + sc * 16;
-        const uint32_t r = r0 + sr + 64 * i;
-        xok[i] = r < p.row_end;
-        xsrc[i] = p.rows + (size_t)(xok[i] ? r : 0u) * p.pitch + sc * 16;
-    }
-    u32x4 ra[4], rb[4];
-    auto load_tile = [&](uint32_t kt) {
+    auto set_a_tile = [&](uint32_t n) {
+        uint32_t nt, mt;
+        slot_tile(n, nt, mt);
 #pragma unroll
         for (int i = 0; i < 4; i++) {
-            ra[i] = *reinterpret_cast<const u32x4*>(asrc[i] + (size_t)kt * BKB);
-            const uint32_t v = kt * 8 + sc;
-            rb[i] = (xok[i] && v < p.V) ? __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(xsrc[i] + (size_t)kt * BKB))
-                                        : u32x4{0, 0, 0, 0};
+            const int ar = sr + 64 * i;  // LDS A row: plane = ar / BMQ, query = ar % BMQ
+            asrc[i] = p.qprep + ((size_t)(ar / BMQ) * p.nq_pad + mt * BMQ + (ar % BMQ)) * p.KPB + sc * 16;
         }
     };
-    auto store_tile = [&](int stage) {
-        unsigned char* a = smem + stage * 2 * TILE_B;
-        unsigned char* bb = a + TILE_B;
+    auto set_b_tile = [&](uint32_t n) {
+        uint32_t nt, mt;
+        slot_tile(n, nt, mt);
+        const uint32_t r0 = p.row_begin + nt * BROWS;
 #pragma unroll
         for (int i = 0; i < 4; i++) {
-            *reinterpret_cast<u32x4*>(a + (sr + 64 * i) * LDPB + sc * 16) = ra[i];
-            *reinterpret_cast<u32x4*>(bb + (sr + 64 * i) * LDPB + sc * 16) = rb[i];
+            const uint32_t r = r0 + sr + 64 * i;
+            xsrc[i] = p.rows + (size_t)(r < p.row_end ? r : 0u) * p.pitch;
         }
+    };
+    // ra: A k-tile one ahead of the LDS stage being computed (queries are L2-hot).  B k-tiles are loaded TWO
+    // ahead into alternating sets rb0/rb1: these MFMAs retire a k-tile in ~1 us, less than an HBM round trip.
+    u32x4 ra[4], rb0[4], rb1[4];
+    auto load_a = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; i++) ra[i] = *reinterpret_cast<const u32x4*>(asrc[i] + (size_t)a_kt * BKB);
+        if (++a_kt == p.KT) {
+            a_kt = 0;
+            if (++a_n < my_tiles) set_a_tile(a_n);
+        }
+    };
+    auto load_b = [&](u32x4 (&rb)[4]) {
+        const uint32_t v = b_kt * 8 + sc;
+        const size_t xoff = v < p.V ? (size_t)v * 16 : 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) rb[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(xsrc[i] + xoff));
+        if (++b_kt == p.KT) {
+            b_kt = 0;
+            if (++b_n < my_tiles) set_b_tile(b_n);
+        }
+    };
+    auto store_a = [&](int stage) {
+        unsigned char* a = smem + stage * 2 * TILE_B;
+#pragma unroll
+        for (int i = 0; i < 4; i++) *reinterpret_cast<u32x4*>(a + (sr + 64 * i) * LDPB + sc * 16) = ra[i];
+    };
+    auto store_b = [&](int stage, uint32_t kt, const u32x4 (&rb)[4]) {  // kt = the k-tile (within its tile) held in rb
+        unsigned char* bb = smem + stage * 2 * TILE_B + TILE_B;
+        const bool vok = kt * 8 + sc < p.V;
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+            *reinterpret_cast<u32x4*>(bb + (sr + 64 * i) * LDPB + sc * 16) = vok ? rb[i] : u32x4{0, 0, 0, 0};
     };
 
     typename Tr::Acc acc[IT][2];
+    auto zero_acc = [&]() {
 #pragma unroll
-    for (int i = 0; i < IT; i++)
+        for (int i = 0; i < IT; i++)
 #pragma unroll
-        for (int j = 0; j < 2; j++)
+            for (int j = 0; j < 2; j++)
 #pragma unroll
-            for (int e = 0; e < 16; e++) acc[i][j][e] = 0;
+                for (int e = 0; e < 16; e++) acc[i][j][e] = 0;
+    };
+    zero_acc();
 
-    load_tile(0);
-    store_tile(0);
+    uint32_t c_n = 0, c_kt = 0, c_nt, c_mt;  // compute cursor
+    slot_tile(0, c_nt, c_mt);
+    load_query_consts(c_mt * BMQ);
+
+    set_a_tile(0);
+    set_b_tile(0);
+    load_a();
+    load_b(rb0);
+    store_a(0);
+    store_b(0, 0, rb0);
+    if (G > 1) {
+        load_a();
+        load_b(rb1);
+    }
+    if (G > 2) load_b(rb0);
     __syncthreads();
 
     const int fr = lane & 31, fh = lane >> 5;
-    for (uint32_t kt = 0; kt < p.KT; kt++) {
-        const int cur = kt & 1;
-        if (kt + 1 < p.KT) load_tile(kt + 1);
-        const unsigned char* a = smem + cur * 2 * TILE_B + (wm * (BMQ / 2) + fr) * LDPB + fh * 16;
-        const unsigned char* bb = smem + cur * 2 * TILE_B + TILE_B + (wn * 64 + fr) * LDPB + fh * 16;
+    // one k-step (32 bytes of k): IT*2*PLANES MFMAs
+    auto kstep = [&](const unsigned char* a, const unsigned char* bb, int ks) {
+        u32x4 fb[2];
 #pragma unroll
-        for (int ks = 0; ks < 4; ks++) {
-            u32x4 fb[2];
+        for (int j = 0; j < 2; j++) fb[j] = *reinterpret_cast<const u32x4*>(bb + j * 32 * LDPB + ks * 32);
 #pragma unroll
-            for (int j = 0; j < 2; j++) fb[j] = *reinterpret_cast<const u32x4*>(bb + j * 32 * LDPB + ks * 32);
+        for (int pl = 0; pl < PLANES; pl++) {
 #pragma unroll
-            for (int pl = 0; pl < PLANES; pl++) {
+            for (int i = 0; i < IT; i++) {
+                const u32x4 fa = *reinterpret_cast<const u32x4*>(a + (pl * BMQ + i * 32) * LDPB + ks * 32);
 #pragma unroll
-                for (int i = 0; i < IT; i++) {
-                    const u32x4 fa = *reinterpret_cast<const u32x4*>(a + (pl * BMQ + i * 32) * LDPB + ks * 32);
-#pragma unroll
-                    for (int j = 0; j < 2; j++) {
-                        if constexpr (DT == MVF_DTYPE_FLOAT16)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, fa),
-                                                                                __builtin_bit_cast(half8, fb[j]), acc[i][j], 0, 0, 0);
-                        else
-                            acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(__builtin_bit_cast(i32x4, fa),
-                                                                               __builtin_bit_cast(i32x4, fb[j]), acc[i][j], 0, 0, 0);
-                    }
+                for (int j = 0; j < 2; j++) {
+                    if constexpr (DT == MVF_DTYPE_FLOAT16)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, fa),
+                                                                            __builtin_bit_cast(half8, fb[j]), acc[i][j], 0, 0, 0);
+                    else
+                        acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(__builtin_bit_cast(i32x4, fa),
+                                                                           __builtin_bit_cast(i32x4, fb[j]), acc[i][j], 0, 0, 0);
                 }
             }
         }
-        if (kt + 1 < p.KT) store_tile(cur ^ 1);
-        __syncthreads();
-    }
+    };
 
-    // ---- epilogue (C/D map: col = lane&31 -> corpus row, row = (e&3)+8*(e>>2)+4*(lane>>5) -> query) ------
+    // ---- epilogue of one finished tile (C/D map: col = lane&31 -> corpus row, row = (e&3)+8*(e>>2)+4*(lane>>5) -> query)
     // Fast path: one or two ops + a compare per score against the per-query pre-filter; the exact key and the
     // atomic append run only for 32x32 tiles where the wave-wide ballot found a candidate (rare).
+    auto epilogue = [&](uint32_t nt, uint32_t mt) {
+        const uint32_t q0 = mt * BMQ, r0 = p.row_begin + nt * BROWS;
+        // keep this address arithmetic inside the epilogue (hoisted out of the k-tile loop it costs VGPRs there)
+        int lane_q = wm * (BMQ / 2) + 4 * fh, lane_r = wn * 64 + fr;
+        asm volatile("" : "+v"(lane_q), "+v"(lane_r));
 #pragma unroll
-    for (int j = 0; j < 2; j++) {
-        const uint32_t r = r0 + wn * 64 + j * 32 + fr;
-        const bool rok = r < p.row_end;
-        float xnf = 0.f, rx = 1.f;
-        int32_t xxi = 0;
-        if (rok) {
-            if constexpr (DT == MVF_DTYPE_FLOAT16) {
-                if (METRIC == MVF_METRIC_COSINE) xnf = p.xnorm_f[r];
-            } else {
-                if (METRIC != MVF_METRIC_INNER_PRODUCT) xxi = p.xnorm_i[r];
-            }
-        }
-        if (METRIC == MVF_METRIC_COSINE) {
-            if constexpr (DT == MVF_DTYPE_FLOAT16) rx = xnf > 0.0f ? __builtin_amdgcn_rcpf(xnf) : 0.0f;
-            else rx = xxi > 0 ? __builtin_amdgcn_rcpf(sqrtf((float)xxi)) : 0.0f;
-        }
-#pragma unroll
-        for (int i = 0; i < IT; i++) {
-            uint32_t m = 0;
-#pragma unroll
-            for (int g = 0; g < 4; g++) {
-                const u32x4 th4 = *reinterpret_cast<const u32x4*>(thr_s + wm * (BMQ / 2) + i * 32 + 8 * g + 4 * fh);
-#pragma unroll
-                for (int t = 0; t < 4; t++) {
-                    bool pass;
-                    if constexpr (DT == MVF_DTYPE_FLOAT16) {
-                        const float y = METRIC == MVF_METRIC_COSINE ? acc[i][j][4 * g + t] * rx : acc[i][j][4 * g + t];
-                        pass = !(y < __uint_as_float(th4[t]));
-                    } else if (METRIC == MVF_METRIC_INNER_PRODUCT) {
-                        pass = acc[i][j][4 * g + t] >= (int32_t)th4[t];
-                    } else if (METRIC == MVF_METRIC_L2) {
-                        pass = 2 * acc[i][j][4 * g + t] - xxi >= (int32_t)th4[t];
-                    } else {
-                        pass = !((float)acc[i][j][4 * g + t] * rx < __uint_as_float(th4[t]));
-                    }
-                    m |= (pass ? 1u : 0u) << (4 * g + t);
+        for (int j = 0; j < 2; j++) {
+            const uint32_t r = r0 + lane_r + j * 32;
+            const bool rok = r < p.row_end;
+            float xnf = 0.f, rx = 1.f;
+            int32_t xxi = 0;
+            if (rok) {
+                if constexpr (DT == MVF_DTYPE_FLOAT16) {
+                    if (METRIC == MVF_METRIC_COSINE) xnf = p.xnorm_f[r];
+                } else {
+                    if (METRIC != MVF_METRIC_INNER_PRODUCT) xxi = p.xnorm_i[r];
                 }
             }
-            if (!rok) m = 0;
-            if (__builtin_amdgcn_ballot_w64(m != 0) != 0) {  // wave-uniform: rare
+            if (METRIC == MVF_METRIC_COSINE) {
+                if constexpr (DT == MVF_DTYPE_FLOAT16) rx = xnf > 0.0f ? __builtin_amdgcn_rcpf(xnf) : 0.0f;
+                else rx = xxi > 0 ? __builtin_amdgcn_rcpf(sqrtf((float)xxi)) : 0.0f;
+            }
 #pragma unroll
-                for (int e = 0; e < 16; e++) {
-                    if (m & (1u << e)) {
-                        const int ql = wm * (BMQ / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
-                        uint32_t key;
+            for (int i = 0; i < IT; i++) {
+                uint32_t m = 0;
+#pragma unroll
+                for (int g = 0; g < 4; g++) {
+                    const u32x4 th4 = *reinterpret_cast<const u32x4*>(thr_s + lane_q + i * 32 + 8 * g);
+#pragma unroll
+                    for (int t = 0; t < 4; t++) {
+                        bool pass;
                         if constexpr (DT == MVF_DTYPE_FLOAT16) {
-                            float sc = acc[i][j][e] * qa_s[ql];  // undo the power-of-two query scale (exact)
-                            if (METRIC == MVF_METRIC_COSINE) {
-                                const float den = qb_s[ql] * xnf;
-                                sc = den > 0.0f ? sc / den : 0.0f;
-                            }
-                            key = key_from_score(sc, METRIC);
+                            const float y = METRIC == MVF_METRIC_COSINE ? acc[i][j][4 * g + t] * rx : acc[i][j][4 * g + t];
+                            pass = !(y < __uint_as_float(th4[t]));
+                        } else if (METRIC == MVF_METRIC_INNER_PRODUCT) {
+                            pass = acc[i][j][4 * g + t] >= (int32_t)th4[t];
+                        } else if (METRIC == MVF_METRIC_L2) {
+                            pass = 2 * acc[i][j][4 * g + t] - xxi >= (int32_t)th4[t];
                         } else {
-                            const int32_t dot = acc[i][j][e];
-                            const int32_t qq = __float_as_int(qa_s[ql]);
-                            if (METRIC == MVF_METRIC_L2) {
-                                key = key_from_raw(qq + xxi - 2 * dot, METRIC);
-                            } else if (METRIC == MVF_METRIC_INNER_PRODUCT) {
-                                key = key_from_raw(dot, METRIC);
-                            } else {
-                                const float den = sqrtf((float)qq) * sqrtf((float)xxi);
-                                key = key_from_score(den > 0.0f ? (float)dot / den : 0.0f, METRIC);
-                            }
+                            pass = !((float)acc[i][j][4 * g + t] * rx < __uint_as_float(th4[t]));
                         }
-                        const uint32_t q = q0 + ql;
-                        if (q < p.nq && key <= tau_s[ql]) {
-                            const uint32_t slot_i = atomicAdd(&p.cnt[q], 1u);
-                            if (slot_i < p.cap) p.cand[(size_t)q * p.cap + slot_i] = ((uint64_t)key << 32) | r;
+                        m |= (pass ? 1u : 0u) << (4 * g + t);
+                    }
+                }
+                if (!rok) m = 0;
+                if (__builtin_amdgcn_ballot_w64(m != 0) != 0) {  // wave-uniform: rare
+#pragma unroll
+                    for (int e = 0; e < 16; e++) {
+                        if (m & (1u << e)) {
+                            const int ql = lane_q + i * 32 + (e & 3) + 8 * (e >> 2);
+                            uint32_t key;
+                            if constexpr (DT == MVF_DTYPE_FLOAT16) {
+                                float sc_ = acc[i][j][e] * qa_s[ql];  // undo the power-of-two query scale (exact)
+                                if (METRIC == MVF_METRIC_COSINE) {
+                                    const float den = qb_s[ql] * xnf;
+                                    sc_ = den > 0.0f ? sc_ / den : 0.0f;
+                                }
+                                key = key_from_score(sc_, METRIC);
+                            } else {
+                                const int32_t dot = acc[i][j][e];
+                                const int32_t qq = __float_as_int(qa_s[ql]);
+                                if (METRIC == MVF_METRIC_L2) {
+                                    key = key_from_raw(qq + xxi - 2 * dot, METRIC);
+                                } else if (METRIC == MVF_METRIC_INNER_PRODUCT) {
+                                    key = key_from_raw(dot, METRIC);
+                                } else {
+                                    const float den = sqrtf((float)qq) * sqrtf((float)xxi);
+                                    key = key_from_score(den > 0.0f ? (float)dot / den : 0.0f, METRIC);
+                                }
+                            }
+                            const uint32_t q = q0 + ql;
+                            if (q < p.nq && key <= tau_s[ql]) {
+                                const uint32_t slot_i = atomicAdd(&p.cnt[q], 1u);
+                                if (slot_i < p.cap) p.cand[(size_t)q * p.cap + slot_i] = ((uint64_t)key << 32) | r;
+                            }
                         }
                     }
                 }
             }
         }
+    };
+
+    // one flat k-tile g; rb holds B k-tile g+1 on entry and receives B k-tile g+3.  The LDS stores of k-tile g+1 and
+    // the global loads ride between the four k-steps so the matrix pipe only drains at the one barrier per k-tile.
+    auto ktile = [&](uint32_t g, u32x4 (&rb)[4]) {
+        const int cur = g & 1;
+        const unsigned char* a = smem + cur * 2 * TILE_B + (wm * (BMQ / 2) + fr) * LDPB + fh * 16;
+        const unsigned char* bb = smem + cur * 2 * TILE_B + TILE_B + (wn * 64 + fr) * LDPB + fh * 16;
+        const bool more = g + 1 < G;
+        const uint32_t next_kt = c_kt + 1 == p.KT ? 0u : c_kt + 1;
+        kstep(a, bb, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) store_a(cur ^ 1);
+        kstep(a, bb, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) store_b(cur ^ 1, next_kt, rb);
+        kstep(a, bb, 2);
+        __builtin_amdgcn_sched_barrier(0);
+        if (g + 2 < G) load_a();
+        if (g + 3 < G) load_b(rb);
+        kstep(a, bb, 3);
+        __syncthreads();
+        if (++c_kt == p.KT) {  // tile finished: the next tile's first k-tile is already in LDS, its loads in flight
+            epilogue(c_nt, c_mt);
+            zero_acc();
+            c_kt = 0;
+            if (++c_n < my_tiles) {
+                uint32_t nmt;
+                slot_tile(c_n, c_nt, nmt);
+                if (nmt != c_mt) {  // block-uniform; rare
+                    __syncthreads();
+                    load_query_consts(nmt * BMQ);
+                    __syncthreads();
+                    c_mt = nmt;
+                }
+            }
+        }
+    };
+    for (uint32_t g = 0; g < G; g += 2) {
+        ktile(g, rb1);
+        if (g + 1 < G) ktile(g + 1, rb0);
     }
 }
 
@@ -394,9 +490,15 @@ hipError_t launch_dt(const Batch16Params& p, int metric, dim3 grid, hipStream_t 
 
 uint32_t scan_mfma16_queries_per_block(int dtype) { return dtype == MVF_DTYPE_FLOAT16 ? 128u : 256u; }
 
-hipError_t launch_scan_mfma16(const Batch16Params& p, int dtype, int metric, hipStream_t s) {
-    const uint32_t groups = (p.ntiles + 7) / 8;
-    const dim3 grid(groups * p.mtiles * 8);
+hipError_t launch_scan_mfma16(const Batch16Params& p, int dtype, int metric, int num_cus, hipStream_t s) {
+    // Grid: a multiple of 8 (one lane set per XCD).  Persistent (one block per CU, LDS-limited) or one tile per
+    // block — the same kernel: with the full grid every block owns exactly one tile.
+    const uint32_t total = ((p.ntiles + 7) / 8) * p.mtiles * 8;
+    uint32_t nls = std::max(1u, (uint32_t)num_cus / 8u);
+    if (nls > p.mtiles) nls -= nls % p.mtiles;
+    bool persistent = dtype != MVF_DTYPE_FLOAT16;  // measured: int8 equal either way, f16 13 % faster with one tile per block
+    if (const char* e = getenv("MVF_K2_PERSISTENT16")) persistent = atoi(e) != 0;
+    const dim3 grid(persistent ? std::min(total, nls * 8u) : total);
     if (dtype == MVF_DTYPE_FLOAT16) return launch_dt<MVF_DTYPE_FLOAT16>(p, metric, grid, s);
     return launch_dt<MVF_DTYPE_INT8>(p, metric, grid, s);
 }

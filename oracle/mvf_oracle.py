@@ -41,10 +41,26 @@ def build(force: bool = False) -> str:
 _lib = None
 
 
+def _cpu_budget() -> int:
+    """Threads the oracle's OpenMP loops may use: the CPU quota of this container / box
+    (cgroup cpu.max or the affinity mask), at most 16.  Oversubscribing a quota-limited box
+    with one OpenMP team per core turns every parallel region into milliseconds of spinning."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(16, n))
+
+
 def lib() -> C.CDLL:
     global _lib
     if _lib is None:
         build()
+        os.environ.setdefault("OMP_NUM_THREADS", str(_cpu_budget()))
+        os.environ.setdefault("OMP_WAIT_POLICY", "passive")
         _lib = C.CDLL(_LIB_PATH)
         vp, u64, u32, u8, i32 = C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint8, C.c_int
         _lib.mvfo_f32_to_f16.restype = C.c_uint16

@@ -1,0 +1,12 @@
+"""One batched int8 search for profiling (development aid)."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import mvf_oracle as O
+from metrovector_amd import gpu as G
+dt = int(sys.argv[1]) if len(sys.argv) > 1 else 2
+n, dim, nq, metric = (50_000_000, 768, 256, 1) if dt == 2 else (12_500_000, 1024, 1024, 2)
+c = G.GpuCorpus.synthetic(n, dim, dt, 0x4D564631)
+q = O.synth_queries(0x4D564632, nq, dim, dt)
+for _ in range(2):
+    c.search(q, 100, metric)
+c.close()
