@@ -33,6 +33,8 @@
 #include "bitonic.h"
 #include "mvf_common.h"
 
+#include <cstdlib>
+
 namespace mvf {
 namespace {
 
@@ -399,12 +401,17 @@ __global__ void __launch_bounds__(1024) compact_kernel(CompactParams p) {
 size_t scan_mfma_lds_bytes() { return kLdsBytes; }
 
 hipError_t launch_scan_mfma_f32(const BatchParams& p, int metric, int num_cus, hipStream_t s) {
-    // persistent grid: 2 blocks per CU (LDS-limited), a multiple of 8 (one lane set per XCD); per-XCD lanes are
-    // rounded to a multiple of the query-tile count when possible so a block keeps its query tile
+    // Grid: a multiple of 8 (one lane set per XCD).  The kernel is written persistent, but by default it is
+    // launched with the FULL grid (every block owns exactly one tile): the dispatcher then starts the query
+    // tiles of one corpus tile together, and the corpus tile is served from L2 to 7 of them (FETCH_SIZE 30 GB per
+    // 24 GB algorithmic).  Truly persistent blocks (2 per CU) drift apart in time: same speed (+0.5 %), but HBM
+    // traffic 102 GB — wasted re-reads.
     const uint32_t total = ((p.ntiles + 7) / 8) * p.mtiles * 8;
     uint32_t nls = std::max(1u, (uint32_t)num_cus * 2u / 8u);
     if (nls > p.mtiles) nls -= nls % p.mtiles;
-    const dim3 grid(std::min(total, nls * 8u));
+    bool persistent = false;
+    if (const char* e = getenv("MVF_K2_PERSISTENT")) persistent = atoi(e) != 0;
+    const dim3 grid(persistent ? std::min(total, nls * 8u) : total);
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&scan_mfma_f32_kernel<MVF_METRIC_COSINE>),
