@@ -51,6 +51,7 @@ def parse_args():
     ap.add_argument("--k", type=int, default=100)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-recall", action="store_true")
+    ap.add_argument("--no-batched", action="store_true", help="skip the extra q=1024 leg of the default N=1 run")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-baseline budget")
     return ap.parse_args()
 
@@ -204,36 +205,75 @@ def main():
                                   "kernel": "scan_stream_kernel", "kernel_ms_avg": tm.scan_ms_avg,
                                   "select_ms_avg": tm.select_ms_avg, "launches_timed": tm.samples,
                                   "algorithmic_bytes_per_launch": alg_bytes}
-            # HBM bytes per launch from the PMC counters: they need their own rocprofv3 --pmc passes
-            # (FETCH_SIZE x2 on gfx950 + WRITE_SIZE, MI355X_MICROARCH.md §HBM), so the figure is the committed
-            # summary of those passes for this exact workload, not a live measurement.
-            tp = os.path.join(ROOT, "profiles", "r01_bench_n1_hbm_traffic.json")
-            if os.path.exists(tp):
+        # HBM bytes per launch from the PMC counters: they need their own rocprofv3 --pmc passes (FETCH_SIZE x2 for
+        # wide streaming reads on gfx950 + WRITE_SIZE, MI355X_MICROARCH.md §HBM), so the figure is the committed
+        # summary of those passes for this exact workload, not a live measurement.
+        if "roofline" in result:
+            for name in ("r01_bench_n1_hbm_traffic.json", "r01_bench_n1_q1024_hbm_traffic.json"):
+                tp = os.path.join(ROOT, "profiles", name)
+                if not os.path.exists(tp):
+                    continue
                 prof = json.load(open(tp))
                 w = prof.get("workload", {})
                 if (w.get("rows"), w.get("dim"), w.get("dtype"), w.get("metric"), w.get("queries"), w.get("k")) == (
                         args.rows, args.dim, args.dtype, args.metric, args.queries, args.k):
-                    for name, kern in prof["kernels"].items():
-                        if name.startswith("scan_stream_kernel"):
-                            result["roofline"]["traffic"] = kern["hbm_bytes_per_launch_corrected"]
-                            result["roofline"]["traffic_source"] = "profiles/r01_bench_n1_hbm_traffic.json"
+                    result["roofline"]["traffic"] = prof["roofline_traffic_bytes_per_launch"]
+                    result["roofline"]["traffic_source"] = "profiles/" + name
         result["corpus_generation_s"] = gen_s
 
         if world == 1:
             from oracle import mvf_oracle as oracle
             oracle.build()
             q = dq.cpu().numpy()
-            if not args.no_recall and args.queries <= 4:
+            if not args.no_recall:
                 t1 = time.perf_counter()
-                osc, oidx = oracle_topk_full(args, oracle, q)
-                gi = out[1].cpu().numpy().view(np.uint64)
+                sel = sorted(set([0, args.queries // 3, 2 * args.queries // 3, args.queries - 1]))  # <= 4 sampled queries
+                osc, oidx = oracle_topk_full(args, oracle, q[sel])
+                gi = out[1].cpu().numpy().view(np.uint64)[sel]
                 hits = sum(len(set(a.tolist()) & set(b.tolist())) for a, b in zip(gi, oidx))
                 result["recall_at_k"] = hits / oidx.size
+                result["recall_queries_checked"] = len(sel)
                 result["recall_oracle_s"] = time.perf_counter() - t1
             if not args.no_cpu_baseline:
                 cb = cpu_baseline(args, oracle)
                 if cb:
                     result["cpu_baseline"] = cb
+            # ---- the metric's second leg: the same resident corpus, 1024 batched queries (MFMA path) ----------
+            if args.queries == 1 and args.dtype == 0 and not args.no_batched:
+                nqb, bsteps = 1024, 5
+                dqb = torch.empty((nqb, args.dim), dtype=qdt, device=f"cuda:{local_rank}")
+                _lib.gpu_check(_lib.gpu().mvfgpu_synth_queries_device(dqb.data_ptr(), nqb, args.dim, args.dtype, SEED + 1,
+                                                                      local_rank, None))
+                searcher.search(dqb, args.k, args.metric)  # warm-up (also computes the row norms once)
+                torch.cuda.synchronize()
+                corpus.set_profiling(True)
+                t0 = time.perf_counter()
+                for _ in range(bsteps):
+                    outb = searcher.search(dqb, args.k, args.metric)
+                torch.cuda.synchronize()
+                eb = time.perf_counter() - t0
+                tmb = corpus.last_timing()
+                corpus.set_profiling(False)
+                leg = {"workload": f"{args.rows // 1_000_000}M x {args.dim} {dtname} {mname}, {nqb} batched queries, top-{args.k}",
+                       "value": float(nqb) * args.rows * bsteps / eb, "unit": "distance-ops/s", "steps": bsteps,
+                       "ms_per_step": eb / bsteps * 1e3}
+                if tmb.samples and tmb.scan_ms_avg > 0 and tmb.scan_kernel == 2:
+                    achb = tmb.scan_flops / (tmb.scan_ms_avg * 1e-3) / 1e12
+                    leg["roofline"] = {"bound": "mfma", "achieved": achb, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
+                                       "frac": achb / MFMA_F32_PEAK_TF, "kernel": "scan_mfma_f32_kernel (last phase)",
+                                       "kernel_ms_avg": tmb.scan_ms_avg, "launches_timed": tmb.samples,
+                                       "algorithmic_flops_per_launch": float(tmb.scan_flops)}
+                    tp = os.path.join(ROOT, "profiles", "r01_bench_n1_q1024_hbm_traffic.json")
+                    if os.path.exists(tp):
+                        leg["roofline"]["traffic"] = json.load(open(tp))["roofline_traffic_bytes_per_launch"]
+                if not args.no_recall:
+                    qb = dqb.cpu().numpy()
+                    sel = [0, nqb // 3, 2 * nqb // 3, nqb - 1]
+                    osc, oidx = oracle_topk_full(args, oracle, qb[sel])
+                    gi = outb[1].cpu().numpy().view(np.uint64)[sel]
+                    leg["recall_at_k"] = sum(len(set(a.tolist()) & set(b.tolist())) for a, b in zip(gi, oidx)) / oidx.size
+                    leg["recall_queries_checked"] = len(sel)
+                result["batched_q1024"] = leg
         print(json.dumps(result), flush=True)
 
     corpus.close()
