@@ -295,14 +295,21 @@ int search_batched_path(const mvfgpu_corpus* c, uint8_t metric, const void* d_qu
     uint32_t* cnt = tau + c->bstate_slots;
     uint32_t* overflow = cnt + c->bstate_slots;
     HIP_TRY(c->bcand.reserve((size_t)nq_pad * cap * 8));
-    const bool need_norms = wide ? metric == MVF_METRIC_COSINE
-                                 : (c->dtype == MVF_DTYPE_FLOAT16 ? metric == MVF_METRIC_COSINE : metric != MVF_METRIC_INNER_PRODUCT);
-    if (need_norms && !c->xnorm_ready) {  // K4, once per resident corpus
-        HIP_TRY(c->xnorm.reserve((size_t)std::max<uint32_t>(n, 1) * 4));
-        if (wide) HIP_TRY(launch_row_norms_f32(c->d_rows, n, c->pitch, static_cast<float*>(c->xnorm.p), s));
-        else HIP_TRY(launch_row_norms16(c->d_rows, c->dtype, n, c->pitch, c->xnorm.p, s));
+    const bool is_float = !is_int_dtype(c->dtype);
+    const bool float_l2 = is_float && metric == MVF_METRIC_L2;
+    const bool need_norms = metric != MVF_METRIC_INNER_PRODUCT;
+    // K4 buffer: float rows: |x| [n], sum x^2 [n], max sum x^2 [1]; int8 rows: sum x^2 (i32) [n]
+    const size_t nn = std::max<uint32_t>(n, 1);
+    if (need_norms && !c->xnorm_ready) {  // once per resident corpus
+        HIP_TRY(c->xnorm.reserve(is_float ? (2 * nn + 1) * 4 : nn * 4));
+        float* xn = static_cast<float*>(c->xnorm.p);
+        if (is_float) HIP_TRY(hipMemsetAsync(xn + 2 * nn, 0, 4, s));
+        if (wide) HIP_TRY(launch_row_norms_f32(c->d_rows, n, c->pitch, xn, xn + nn, xn + 2 * nn, s));
+        else HIP_TRY(launch_row_norms16(c->d_rows, c->dtype, n, c->pitch, c->xnorm.p, xn + nn, xn + 2 * nn, s));
         c->xnorm_ready = true;
     }
+    const float* xx2 = is_float && c->xnorm.p ? static_cast<const float*>(c->xnorm.p) + nn : nullptr;
+    const float* xxmax = is_float && c->xnorm.p ? static_cast<const float*>(c->xnorm.p) + 2 * nn : nullptr;
     if (wide)
         HIP_TRY(launch_prep_queries(static_cast<const float*>(d_queries), nq, nq_pad, c->dim, KPB / 4,
                                     reinterpret_cast<float*>(qprep), qaux0, s));
@@ -314,6 +321,8 @@ int search_batched_path(const mvfgpu_corpus* c, uint8_t metric, const void* d_qu
     bp.qnorm = qaux0;
     bp.rows = c->d_rows;
     bp.xnorm = static_cast<const float*>(c->xnorm.p);
+    bp.xx2 = xx2;
+    bp.xxmax = xxmax;
     bp.tau = tau;
     bp.cand = static_cast<uint64_t*>(c->bcand.p);
     bp.cnt = cnt;
@@ -332,6 +341,8 @@ int search_batched_path(const mvfgpu_corpus* c, uint8_t metric, const void* d_qu
     hp.rows = c->d_rows;
     hp.xnorm_f = static_cast<const float*>(c->xnorm.p);
     hp.xnorm_i = static_cast<const int32_t*>(c->xnorm.p);
+    hp.xx2 = xx2;
+    hp.xxmax = xxmax;
     hp.tau = tau;
     hp.cand = bp.cand;
     hp.cnt = cnt;
@@ -357,6 +368,10 @@ int search_batched_path(const mvfgpu_corpus* c, uint8_t metric, const void* d_qu
     cp.out_scores = d_scores;
     cp.out_indices = d_indices;
     cp.out_raw = d_raw;
+    cp.qnorm = wide ? qaux0 : qaux1;  // |q| (f32 path: qnorm; f16 path: second aux array)
+    cp.xxmax = xxmax;
+    // bound of |GEMM-form - exact| squared distance relative to (qq + xx): f32 dot of `dim` terms plus the two norms
+    cp.eps = (float)(std::max<uint32_t>(c->dim, 64) + 16) * 1.1920929e-7f;
 
     mvfgpu_timing tm{};
     tm.scan_kernel = 2;
@@ -389,10 +404,29 @@ int search_batched_path(const mvfgpu_corpus* c, uint8_t metric, const void* d_qu
             }
             tm.scan_launches++;
         }
-        HIP_TRY(launch_compact(cp, nq, last, s));
+        if (float_l2) HIP_TRY(launch_compact_l2(cp, nq, s));
+        else HIP_TRY(launch_compact(cp, nq, last, s));
         if (last) break;
         begin = end;
         end = std::min<uint64_t>(n, ((end * g + 255) / 256) * 256);
+    }
+    if (float_l2) {  // exact (q-x)^2 distances of the kept candidates, final top-k
+        RescoreParams rp{};
+        rp.cand = bp.cand;
+        rp.cnt = cnt;
+        rp.tau = tau;
+        rp.cap = cap;
+        rp.k = k;
+        rp.queries = static_cast<const float*>(d_queries);
+        rp.rows = c->d_rows;
+        rp.pitch = c->pitch;
+        rp.dim = c->dim;
+        rp.dtype = c->dtype;
+        rp.index_base = c->index_base;
+        rp.out_scores = d_scores;
+        rp.out_indices = d_indices;
+        rp.out_raw = d_raw;
+        HIP_TRY(launch_rescore_l2(rp, nq, s));
     }
     if (ps) {
         HIP_TRY(hipEventRecord(ps->e[2], s));
@@ -423,11 +457,11 @@ int search_batched_path(const mvfgpu_corpus* c, uint8_t metric, const void* d_qu
 
 bool use_batched_path(const mvfgpu_corpus* c, uint8_t metric, uint32_t nq) {
     if (c->scan_path == 1) return false;
-    // Float32 / Float16: cosine and dot (batched L2 needs GEMM-form selection + exact re-scoring: not built yet);
+    // Float32 / Float16: every metric (L2 = GEMM-form selection with an error margin + exact re-scoring);
     // Int8: every metric (exact integers).  UInt8 has no unsigned MFMA: stays on K1.
-    const bool supported = ((c->dtype == MVF_DTYPE_FLOAT32 || c->dtype == MVF_DTYPE_FLOAT16) &&
-                            (metric == MVF_METRIC_COSINE || metric == MVF_METRIC_INNER_PRODUCT)) ||
-                           c->dtype == MVF_DTYPE_INT8;
+    bool supported = c->dtype == MVF_DTYPE_FLOAT32 || c->dtype == MVF_DTYPE_FLOAT16 || c->dtype == MVF_DTYPE_INT8;
+    if (metric == MVF_METRIC_L2 && !is_int_dtype(c->dtype) && (size_t)((c->dim + 7u) & ~7u) * 4 + kBatchCap * 4 > 64 * 1024)
+        supported = false;  // the re-scoring kernel keeps the query in LDS
     if (!supported) return false;
     return c->scan_path == 2 || nq >= 32;
 }

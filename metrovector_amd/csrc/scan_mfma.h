@@ -12,7 +12,9 @@ struct BatchParams {
     const float* qmat;          // [nq_pad][KP] f32 queries, zero padded (nq_pad multiple of 128)
     const float* qnorm;         // [nq_pad] sqrt(sum q^2)
     const unsigned char* rows;  // device rows
-    const float* xnorm;         // [n] sqrt(sum x^2) (cosine only)
+    const float* xnorm;         // [n] sqrt(sum x^2) (cosine)
+    const float* xx2;           // [n] sum x^2 (batched L2)
+    const float* xxmax;         // [1] max over rows of sum x^2 (batched L2 error margin)
     const uint32_t* tau;        // [nq_pad] order-key thresholds (0xFFFFFFFF = none yet)
     uint64_t* cand;             // [nq_pad][cap] composites
     uint32_t* cnt;              // [nq_pad] entries appended (may exceed cap: overflow)
@@ -31,6 +33,8 @@ struct Batch16Params {
     const float* qaux1;          // [nq_pad] f16: |q| (f32)
     const unsigned char* rows;
     const float* xnorm_f;        // [n] f16 rows: sqrt(sum x^2)
+    const float* xx2;            // [n] f16 rows: sum x^2 (batched L2)
+    const float* xxmax;          // [1] max over rows of sum x^2
     const int32_t* xnorm_i;      // [n] i8 rows: sum x^2
     const uint32_t* tau;
     uint64_t* cand;
@@ -49,6 +53,11 @@ struct CompactParams {
     uint32_t* tau;
     uint32_t* overflow;
     uint32_t cap, k;
+    // float L2 on the batched path: keys are the GEMM-form squared distance qq + xx - 2 dot, whose error is
+    // bounded by eps * (qq + xxmax); the compaction keeps everything within 2x that of the k-th value
+    const float* qnorm;   // [nq] |q|
+    const float* xxmax;   // [1]
+    float eps;
     // final stage only
     uint8_t metric, dtype;
     uint64_t index_base;
@@ -63,13 +72,33 @@ size_t scan_mfma_lds_bytes();
 hipError_t launch_scan_mfma_f32(const BatchParams& p, int metric, int num_cus, hipStream_t s);
 hipError_t launch_prep_queries(const float* q, uint32_t nq, uint32_t nq_pad, uint32_t dim, uint32_t KP, float* qmat,
                                float* qnorm, hipStream_t s);
-hipError_t launch_row_norms_f32(const unsigned char* rows, uint32_t n, uint32_t pitch, float* xnorm, hipStream_t s);
+hipError_t launch_row_norms_f32(const unsigned char* rows, uint32_t n, uint32_t pitch, float* xnorm, float* xx2,
+                                float* xxmax, hipStream_t s);
 hipError_t launch_compact(const CompactParams& p, uint32_t nq, bool final_stage, hipStream_t s);
+
+// batched float L2: margin-aware compaction + exact re-scoring of the kept candidates
+struct RescoreParams {
+    const uint64_t* cand;       // [nq][cap] sorted approximate composites, first cnt[q] valid
+    uint32_t* cnt;              // re-armed to 0
+    uint32_t* tau;              // re-armed to "none"
+    uint32_t cap, k;
+    const float* queries;       // device [nq][dim] f32 (the caller's queries)
+    const unsigned char* rows;
+    uint32_t pitch, dim;
+    uint8_t dtype;              // Float32 or Float16 rows
+    uint64_t index_base;
+    float* out_scores;
+    uint64_t* out_indices;
+    int32_t* out_raw;
+};
+hipError_t launch_compact_l2(const CompactParams& p, uint32_t nq, hipStream_t s);
+hipError_t launch_rescore_l2(const RescoreParams& p, uint32_t nq, hipStream_t s);
 
 uint32_t scan_mfma16_queries_per_block(int dtype);
 hipError_t launch_scan_mfma16(const Batch16Params& p, int dtype, int metric, int num_cus, hipStream_t s);
 hipError_t launch_prep_queries16(const void* q, int dtype, uint32_t nq, uint32_t nq_pad, uint32_t dim, uint32_t KPB,
                                  unsigned char* qprep, float* qaux0, float* qaux1, hipStream_t s);
-hipError_t launch_row_norms16(const unsigned char* rows, int dtype, uint32_t n, uint32_t pitch, void* out, hipStream_t s);
+hipError_t launch_row_norms16(const unsigned char* rows, int dtype, uint32_t n, uint32_t pitch, void* out, float* xx2,
+                              float* xxmax, hipStream_t s);
 
 }  // namespace mvf

@@ -33,6 +33,8 @@
 #include "bitonic.h"
 #include "mvf_common.h"
 
+#include <hip/hip_fp16.h>
+
 #include <cstdlib>
 
 namespace mvf {
@@ -91,8 +93,16 @@ __global__ void __launch_bounds__(256, 2) scan_mfma_f32_kernel(BatchParams p) {
             // 2e-6 relative margin (>> the rounding difference to the exact dot/(|q||x|)), so it never rejects a
             // row the exact test would accept; the exact key is only computed for rows that pass.
             const float ts = score_from_key(tau, METRIC);
-            const float tq = METRIC == MVF_METRIC_COSINE ? ts * qn : ts;
-            tql_s[tid] = tq - fabsf(tq) * 2e-6f;
+            if (METRIC == MVF_METRIC_L2) {
+                // batched L2 selects on the GEMM-form squared distance s2 = qq + xx - 2 dot (exact distances are
+                // re-scored afterwards); tau holds ord(thr).  s2 <= thr  <=>  2 dot - xx >= qq - thr.
+                const float qq = qn * qn;
+                const float cq = qq - ts;
+                tql_s[tid] = cq - fabsf(cq) * 2e-6f - (qq + p.xxmax[0]) * 4e-7f;
+            } else {
+                const float tq = METRIC == MVF_METRIC_COSINE ? ts * qn : ts;
+                tql_s[tid] = tq - fabsf(tq) * 2e-6f;
+            }
         }
     };
 
@@ -221,11 +231,12 @@ __global__ void __launch_bounds__(256, 2) scan_mfma_f32_kernel(BatchParams p) {
         for (int j = 0; j < 2; j++) {
             const uint32_t r = r0 + lane_r + j * 32;
             const bool rok = r < p.row_end;
-            float xn = 0.f, rx = 1.f;
+            float xn = 0.f, rx = 1.f, xx = 0.f;
             if (METRIC == MVF_METRIC_COSINE) {
                 if (rok) xn = p.xnorm[r];
                 rx = xn > 0.0f ? __builtin_amdgcn_rcpf(xn) : 0.0f;
             }
+            if (METRIC == MVF_METRIC_L2 && rok) xx = p.xx2[r];
 #pragma unroll
             for (int i = 0; i < 2; i++) {
                 uint32_t m = 0;
@@ -234,7 +245,9 @@ __global__ void __launch_bounds__(256, 2) scan_mfma_f32_kernel(BatchParams p) {
                     const f32x4 tql4 = *reinterpret_cast<const f32x4*>(tql_s + lane_q + i * 32 + 8 * g);
 #pragma unroll
                     for (int t = 0; t < 4; t++) {
-                        const float y = METRIC == MVF_METRIC_COSINE ? acc[i][j][4 * g + t] * rx : acc[i][j][4 * g + t];
+                        const float y = METRIC == MVF_METRIC_COSINE ? acc[i][j][4 * g + t] * rx
+                                        : METRIC == MVF_METRIC_L2   ? fmaf(2.0f, acc[i][j][4 * g + t], -xx)
+                                                                    : acc[i][j][4 * g + t];
                         m |= (y < tql4[t] ? 0u : 1u) << (4 * g + t);
                     }
                 }
@@ -249,6 +262,7 @@ __global__ void __launch_bounds__(256, 2) scan_mfma_f32_kernel(BatchParams p) {
                                 const float den = qn_s[ql] * xn;
                                 sc_ = den > 0.0f ? sc_ / den : 0.0f;
                             }
+                            if (METRIC == MVF_METRIC_L2) sc_ = qn_s[ql] * qn_s[ql] + xx - 2.0f * sc_;  // GEMM-form s2
                             const uint32_t key = key_from_score(sc_, METRIC);
                             const uint32_t q = q0 + ql;
                             if (q < p.nq && key <= tau_s[ql]) {
@@ -329,7 +343,8 @@ __global__ void prep_queries_kernel(const float* q, uint32_t nq, uint32_t nq_pad
 
 // ---- K4: row norms sqrt(sum x^2), one wave per row (f32 rows) ---------------------
 __global__ void __launch_bounds__(256) row_norms_f32_kernel(const unsigned char* rows, uint32_t n, uint32_t pitch,
-                                                             uint32_t V, float* xnorm) {
+                                                             uint32_t V, float* xnorm, float* xx2, float* xxmax) {
+    float mx = 0.f;
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = (blockIdx.x * 256u + threadIdx.x) >> 6, nwaves = (gridDim.x * 256u) >> 6;
     for (uint32_t r = wave; r < n; r += nwaves) {
@@ -343,8 +358,13 @@ __global__ void __launch_bounds__(256) row_norms_f32_kernel(const unsigned char*
             s = fmaf(x[3], x[3], s);
         }
         for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
-        if (lane == 0) xnorm[r] = sqrtf(s);
+        if (lane == 0) {
+            xnorm[r] = sqrtf(s);
+            xx2[r] = s;
+            if (s > mx) mx = s;  // NaN never wins: the margin uses finite rows only
+        }
     }
+    if (lane == 0 && mx > 0.f) atomicMax(reinterpret_cast<unsigned int*>(xxmax), __float_as_uint(mx));  // non-negative floats order as uints
 }
 
 // ---- candidate compaction: keep each query's k best, publish the new threshold ----
@@ -396,6 +416,115 @@ __global__ void __launch_bounds__(1024) compact_kernel(CompactParams p) {
     }
 }
 
+// ---- batched float L2: margin-aware compaction -------------------------------------------------------------
+// Keys are ord(s2~), s2~ = qq + xx - 2 dot with |s2~ - s2| <= delta = eps * (qq + xxmax).  With v_k the k-th
+// smallest s2~ seen, the true k-th best exact value is <= v_k + delta, and every true top-k row has
+// s2~ <= v_k + 2 delta: keep all of those (not just k), publish tau = ord(v_k + 2 delta).
+__global__ void __launch_bounds__(1024) compact_l2_kernel(CompactParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint64_t* buf = reinterpret_cast<uint64_t*>(smem);
+    __shared__ uint32_t keep_s;
+    const int tid = threadIdx.x;
+    const uint32_t q = blockIdx.x;
+    const uint32_t raw_cnt = p.cnt[q];
+    const uint32_t m = raw_cnt < p.cap ? raw_cnt : p.cap;
+    uint64_t* c = p.cand + (size_t)q * p.cap;
+    const uint32_t P2 = next_pow2(m < 2 ? 2 : m);
+    for (uint32_t i = tid; i < P2; i += 1024) buf[i] = i < m ? c[i] : kPadComposite;
+    if (tid == 0) keep_s = m;
+    __syncthreads();
+    bitonic_sort_u64<1024>(buf, P2, tid);
+    uint32_t tkey = kNanKey;
+    if (m >= p.k) {
+        const float vk = score_from_key((uint32_t)(buf[p.k - 1] >> 32), MVF_METRIC_L2);
+        const float qn = p.qnorm[q];
+        const float thr = vk + 2.0f * p.eps * (qn * qn + p.xxmax[0]);
+        tkey = key_from_score(thr, MVF_METRIC_L2);
+        if (tkey != kNanKey)
+            for (uint32_t i = p.k - 1 + tid; i < m; i += 1024)
+                if ((uint32_t)(buf[i] >> 32) <= tkey && (i + 1 == m || (uint32_t)(buf[i + 1] >> 32) > tkey)) keep_s = i + 1;
+    }
+    __syncthreads();
+    uint32_t keep = keep_s;
+    const uint32_t keep_cap = p.cap / 2;
+    bool over = raw_cnt > p.cap;
+    if (keep > keep_cap) {  // too many near-ties to carry: the host redoes this query exactly with K1
+        keep = keep_cap;
+        over = true;
+    }
+    for (uint32_t i = tid; i < keep; i += 1024) c[i] = buf[i];
+    if (tid == 0) {
+        if (over) p.overflow[q] = 1u;
+        p.cnt[q] = keep;
+        p.tau[q] = tkey;
+    }
+}
+
+// ---- batched float L2: exact re-scoring of the kept candidates + final top-k ---------------------------------
+// grid (nq); block 256 (4 waves); LDS: query f32[dim4] + composites[cap/2].  One wave per candidate row:
+// sum (q - x)^2 in f32 (fmaf, lane-strided + butterfly, like K1), sqrt, order key.
+__global__ void __launch_bounds__(256) rescore_l2_kernel(RescoreParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const uint32_t dim4 = (p.dim + 7u) & ~7u;  // zero-padded to a multiple of 8 (one f16 vector)
+    float* qs = reinterpret_cast<float*>(smem);
+    uint64_t* buf = reinterpret_cast<uint64_t*>(qs + dim4);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t q = blockIdx.x;
+    const uint32_t keep_cap = p.cap / 2;
+    const uint32_t m = min(p.cnt[q], keep_cap);
+    for (uint32_t e = tid; e < dim4; e += 256) qs[e] = e < p.dim ? p.queries[(size_t)q * p.dim + e] : 0.f;
+    __syncthreads();
+    const uint64_t* c = p.cand + (size_t)q * p.cap;
+    const uint32_t V = p.pitch / 16;
+    for (uint32_t ci = wave; ci < m; ci += 4) {
+        const uint32_t r = (uint32_t)c[ci];
+        const unsigned char* rp = p.rows + (size_t)r * p.pitch;
+        float s = 0.f;
+        for (uint32_t v = lane; v < V; v += 64) {
+            const u32x4 x = *reinterpret_cast<const u32x4*>(rp + (size_t)v * 16);
+            if (p.dtype == MVF_DTYPE_FLOAT32) {
+                const f32x4 qv = *reinterpret_cast<const f32x4*>(qs + v * 4);
+#pragma unroll
+                for (int w = 0; w < 4; w++) {
+                    const float t = qv[w] - __uint_as_float(x[w]);
+                    s = fmaf(t, t, s);
+                }
+            } else {
+#pragma unroll
+                for (int w = 0; w < 4; w++) {
+                    const float x0 = __half2float(__ushort_as_half((unsigned short)(x[w] & 0xFFFFu)));
+                    const float x1 = __half2float(__ushort_as_half((unsigned short)(x[w] >> 16)));
+                    const float t0 = qs[v * 8 + 2 * w] - x0, t1 = qs[v * 8 + 2 * w + 1] - x1;
+                    s = fmaf(t0, t0, s);
+                    s = fmaf(t1, t1, s);
+                }
+            }
+        }
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+        if (lane == 0) buf[ci] = ((uint64_t)key_from_score(sqrtf(s), MVF_METRIC_L2) << 32) | r;
+    }
+    const uint32_t P2 = next_pow2(m < 2 ? 2 : m);
+    for (uint32_t i = m + tid; i < P2; i += 256) buf[i] = kPadComposite;
+    __syncthreads();
+    bitonic_sort_u64<256>(buf, P2, tid);
+    for (uint32_t i = tid; i < p.k; i += 256) {
+        const uint32_t o = q * p.k + i;
+        const uint64_t comp = i < m ? buf[i] : kPadComposite;
+        if (comp == kPadComposite) {
+            p.out_scores[o] = pad_score(MVF_METRIC_L2);
+            p.out_indices[o] = ~0ull;
+        } else {
+            p.out_scores[o] = score_from_key((uint32_t)(comp >> 32), MVF_METRIC_L2);
+            p.out_indices[o] = p.index_base + (uint32_t)comp;
+        }
+        if (p.out_raw) p.out_raw[o] = 0;
+    }
+    if (tid == 0) {
+        p.cnt[q] = 0;
+        p.tau[q] = kNanKey;
+    }
+}
+
 }  // namespace
 
 size_t scan_mfma_lds_bytes() { return kLdsBytes; }
@@ -419,11 +548,16 @@ hipError_t launch_scan_mfma_f32(const BatchParams& p, int metric, int num_cus, h
         if (e == hipSuccess)
             e = hipFuncSetAttribute(reinterpret_cast<const void*>(&scan_mfma_f32_kernel<MVF_METRIC_INNER_PRODUCT>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&scan_mfma_f32_kernel<MVF_METRIC_L2>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
     if (metric == MVF_METRIC_COSINE)
         hipLaunchKernelGGL(scan_mfma_f32_kernel<MVF_METRIC_COSINE>, grid, dim3(256), kLdsBytes, s, p);
+    else if (metric == MVF_METRIC_L2)
+        hipLaunchKernelGGL(scan_mfma_f32_kernel<MVF_METRIC_L2>, grid, dim3(256), kLdsBytes, s, p);
     else
         hipLaunchKernelGGL(scan_mfma_f32_kernel<MVF_METRIC_INNER_PRODUCT>, grid, dim3(256), kLdsBytes, s, p);
     return hipGetLastError();
@@ -435,10 +569,22 @@ hipError_t launch_prep_queries(const float* q, uint32_t nq, uint32_t nq_pad, uin
     return hipGetLastError();
 }
 
-hipError_t launch_row_norms_f32(const unsigned char* rows, uint32_t n, uint32_t pitch, float* xnorm, hipStream_t s) {
+hipError_t launch_row_norms_f32(const unsigned char* rows, uint32_t n, uint32_t pitch, float* xnorm, float* xx2,
+                                float* xxmax, hipStream_t s) {
     if (n == 0) return hipSuccess;
     const uint32_t blocks = (uint32_t)std::min<uint64_t>(((uint64_t)n + 3) / 4, 256u * 8u);
-    hipLaunchKernelGGL(row_norms_f32_kernel, dim3(blocks), dim3(256), 0, s, rows, n, pitch, pitch / 16, xnorm);
+    hipLaunchKernelGGL(row_norms_f32_kernel, dim3(blocks), dim3(256), 0, s, rows, n, pitch, pitch / 16, xnorm, xx2, xxmax);
+    return hipGetLastError();
+}
+
+hipError_t launch_compact_l2(const CompactParams& p, uint32_t nq, hipStream_t s) {
+    hipLaunchKernelGGL(compact_l2_kernel, dim3(nq), dim3(1024), (size_t)p.cap * 8, s, p);
+    return hipGetLastError();
+}
+
+hipError_t launch_rescore_l2(const RescoreParams& p, uint32_t nq, hipStream_t s) {
+    const size_t lds = (size_t)((p.dim + 7u) & ~7u) * 4 + (size_t)(p.cap / 2) * 8;
+    hipLaunchKernelGGL(rescore_l2_kernel, dim3(nq), dim3(256), lds, s, p);
     return hipGetLastError();
 }
 

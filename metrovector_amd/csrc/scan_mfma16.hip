@@ -98,10 +98,18 @@ __global__ void __launch_bounds__(512, 2) scan_mfma16_kernel(Batch16Params p) {
             tau_s[tid] = tau;
             // Pre-filter threshold in ACCUMULATOR units (see scan_mfma.hip): a superset test, one or two ops per score.
             if constexpr (DT == MVF_DTYPE_FLOAT16) {
-                // score = acc * 2^-e [/ (|q||x|)] >= ts  <=>  acc [* 1/|x|] >= ts [* |q|] * 2^e
                 const float ts = score_from_key(tau, METRIC);
-                const float tq = (METRIC == MVF_METRIC_COSINE ? ts * qb : ts) / qa;
-                thr_s[tid] = tq - fabsf(tq) * 2e-6f;
+                if (METRIC == MVF_METRIC_L2) {
+                    // batched L2 selects on s2 = qq + xx - 2 dot, dot = acc * 2^-e (exact distances are re-scored
+                    // afterwards); tau holds ord(thr).  s2 <= thr  <=>  acc * 2^(1-e) - xx >= qq - thr.
+                    const float qq = qb * qb;
+                    const float cq = qq - ts;
+                    thr_s[tid] = cq - fabsf(cq) * 2e-6f - (qq + p.xxmax[0]) * 4e-7f;
+                } else {
+                    // score = acc * 2^-e [/ (|q||x|)] >= ts  <=>  acc [* 1/|x|] >= ts [* |q|] * 2^e
+                    const float tq = (METRIC == MVF_METRIC_COSINE ? ts * qb : ts) / qa;
+                    thr_s[tid] = tq - fabsf(tq) * 2e-6f;
+                }
             } else {
                 const int32_t qq = __float_as_int(qa);
                 if (METRIC == MVF_METRIC_INNER_PRODUCT) {
@@ -241,11 +249,12 @@ __global__ void __launch_bounds__(512, 2) scan_mfma16_kernel(Batch16Params p) {
         for (int j = 0; j < 2; j++) {
             const uint32_t r = r0 + lane_r + j * 32;
             const bool rok = r < p.row_end;
-            float xnf = 0.f, rx = 1.f;
+            float xnf = 0.f, rx = 1.f, xxf = 0.f;
             int32_t xxi = 0;
             if (rok) {
                 if constexpr (DT == MVF_DTYPE_FLOAT16) {
                     if (METRIC == MVF_METRIC_COSINE) xnf = p.xnorm_f[r];
+                    if (METRIC == MVF_METRIC_L2) xxf = p.xx2[r];
                 } else {
                     if (METRIC != MVF_METRIC_INNER_PRODUCT) xxi = p.xnorm_i[r];
                 }
@@ -260,11 +269,16 @@ __global__ void __launch_bounds__(512, 2) scan_mfma16_kernel(Batch16Params p) {
 #pragma unroll
                 for (int g = 0; g < 4; g++) {
                     const u32x4 th4 = *reinterpret_cast<const u32x4*>(thr_s + lane_q + i * 32 + 8 * g);
+                    u32x4 sc4 = u32x4{0, 0, 0, 0};
+                    if (DT == MVF_DTYPE_FLOAT16 && METRIC == MVF_METRIC_L2)
+                        sc4 = *reinterpret_cast<const u32x4*>(qa_s + lane_q + i * 32 + 8 * g);  // 2^-e per query
 #pragma unroll
                     for (int t = 0; t < 4; t++) {
                         bool pass;
                         if constexpr (DT == MVF_DTYPE_FLOAT16) {
-                            const float y = METRIC == MVF_METRIC_COSINE ? acc[i][j][4 * g + t] * rx : acc[i][j][4 * g + t];
+                            const float y = METRIC == MVF_METRIC_COSINE ? acc[i][j][4 * g + t] * rx
+                                            : METRIC == MVF_METRIC_L2   ? fmaf(acc[i][j][4 * g + t], 2.0f * __uint_as_float(sc4[t]), -xxf)
+                                                                        : acc[i][j][4 * g + t];
                             pass = !(y < __uint_as_float(th4[t]));
                         } else if (METRIC == MVF_METRIC_INNER_PRODUCT) {
                             pass = acc[i][j][4 * g + t] >= (int32_t)th4[t];
@@ -289,6 +303,7 @@ __global__ void __launch_bounds__(512, 2) scan_mfma16_kernel(Batch16Params p) {
                                     const float den = qb_s[ql] * xnf;
                                     sc_ = den > 0.0f ? sc_ / den : 0.0f;
                                 }
+                                if (METRIC == MVF_METRIC_L2) sc_ = qb_s[ql] * qb_s[ql] + xxf - 2.0f * sc_;  // GEMM-form s2
                                 key = key_from_score(sc_, METRIC);
                             } else {
                                 const int32_t dot = acc[i][j][e];
@@ -425,7 +440,8 @@ __global__ void prep_queries_i8_kernel(const int8_t* q, uint32_t nq, uint32_t nq
 
 // ---- K4 for the narrow types: one wave per row ----------------------------------------------
 __global__ void __launch_bounds__(256) row_norms_f16_kernel(const unsigned char* rows, uint32_t n, uint32_t pitch,
-                                                             uint32_t V, float* xnorm) {
+                                                             uint32_t V, float* xnorm, float* xx2, float* xxmax) {
+    float mx = 0.f;
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = (blockIdx.x * 256u + threadIdx.x) >> 6, nwaves = (gridDim.x * 256u) >> 6;
     for (uint32_t r = wave; r < n; r += nwaves) {
@@ -442,8 +458,13 @@ __global__ void __launch_bounds__(256) row_norms_f16_kernel(const unsigned char*
             }
         }
         for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
-        if (lane == 0) xnorm[r] = sqrtf(s);
+        if (lane == 0) {
+            xnorm[r] = sqrtf(s);
+            xx2[r] = s;
+            if (s > mx) mx = s;
+        }
     }
+    if (lane == 0 && mx > 0.f) atomicMax(reinterpret_cast<unsigned int*>(xxmax), __float_as_uint(mx));
 }
 
 __global__ void __launch_bounds__(256) row_norms_i8_kernel(const unsigned char* rows, uint32_t n, uint32_t pitch,
@@ -514,11 +535,13 @@ hipError_t launch_prep_queries16(const void* q, int dtype, uint32_t nq, uint32_t
     return hipGetLastError();
 }
 
-hipError_t launch_row_norms16(const unsigned char* rows, int dtype, uint32_t n, uint32_t pitch, void* out, hipStream_t s) {
+hipError_t launch_row_norms16(const unsigned char* rows, int dtype, uint32_t n, uint32_t pitch, void* out, float* xx2,
+                              float* xxmax, hipStream_t s) {
     if (n == 0) return hipSuccess;
     const uint32_t blocks = (uint32_t)std::min<uint64_t>(((uint64_t)n + 3) / 4, 256u * 8u);
     if (dtype == MVF_DTYPE_FLOAT16)
-        hipLaunchKernelGGL(row_norms_f16_kernel, dim3(blocks), dim3(256), 0, s, rows, n, pitch, pitch / 16, static_cast<float*>(out));
+        hipLaunchKernelGGL(row_norms_f16_kernel, dim3(blocks), dim3(256), 0, s, rows, n, pitch, pitch / 16, static_cast<float*>(out),
+                           xx2, xxmax);
     else
         hipLaunchKernelGGL(row_norms_i8_kernel, dim3(blocks), dim3(256), 0, s, rows, n, pitch, pitch / 16, static_cast<int32_t*>(out));
     return hipGetLastError();

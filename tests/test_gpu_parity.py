@@ -513,3 +513,61 @@ def test_batched_mfma_f16(oracle, metric, shape):
     for i in range(nq):
         sc, _, _ = oracle.scores(rows, 1, metric, q[i])
         assert_float_topk(metric, res.scores[i], res.indices[i], sc, rows32, q[i], k)
+
+
+# ---------------------------------------------------------------------------
+# K2 batched L2 on float spaces: GEMM-form selection with an error margin +
+# exact (q-x)^2 re-scoring of the kept candidates
+# ---------------------------------------------------------------------------
+
+@pytest.mark.parametrize("dtype", [0, 1])
+@pytest.mark.parametrize("shape", [(20000, 768, 130, 100), (5000, 100, 33, 10), (300, 64, 128, 500), (9000, 36, 40, 1)])
+def test_batched_l2_float(oracle, dtype, shape):
+    n, dim, nq, k = shape
+    rows = oracle.synth_rows(SEED, 0, n, dim, dtype)
+    q = oracle.synth_queries(SEED + 1, nq, dim, dtype)
+    with G.GpuCorpus.from_array(rows, index_base=3) as c:
+        c.set_scan_path(2)
+        res = c.search(q, k, G.L2)
+    rows32 = rows.astype(np.float32)
+    for i in range(nq):
+        sc, _, _ = oracle.scores(rows, dtype, 0, q[i])
+        assert_float_topk(0, res.scores[i], res.indices[i], sc, rows32, q[i], k, 3)
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
+def test_batched_l2_near_duplicates_are_exact(oracle, dtype):
+    """The GEMM form qq + xx - 2 dot cancels catastrophically for near neighbours (SURVEY.md §7 hard part 2):
+    queries that ARE corpus rows, or a hair away from them, must still get distances within 1e-5 of the
+    oracle (0 for the exact duplicate) — that is what the exact re-scoring is for."""
+    n, dim, nq, k = 30000, 256, 64, 10
+    rows = oracle.synth_rows(SEED, 0, n, dim, dtype)
+    rng = np.random.default_rng(4)
+    pick = rng.choice(n, nq, replace=False)
+    q = rows[pick].astype(np.float32)
+    q[1::2] += (rng.standard_normal((nq // 2, dim)) * 1e-4).astype(np.float32)   # tiny perturbations
+    with G.GpuCorpus.from_array(rows) as c:
+        c.set_scan_path(2)
+        res = c.search(q, k, G.L2)
+    assert (res.indices[:, 0] == pick.astype(np.uint64)).all()
+    assert (res.scores[0::2, 0] == 0.0).all()
+    rows32 = rows.astype(np.float32)
+    for i in range(nq):
+        sc, _, _ = oracle.scores(rows, dtype, 0, q[i])
+        assert_float_topk(0, res.scores[i], res.indices[i], sc, rows32, q[i], k)
+
+
+def test_batched_l2_heterogeneous_norms(oracle):
+    """Rows of very different magnitude inflate the error margin (it scales with the largest row norm): more
+    candidates are carried or the query is repaired by K1 — the answer must stay exact either way."""
+    n, dim, nq, k = 20000, 64, 40, 20
+    rows = oracle.synth_rows(SEED, 0, n, dim, 0)
+    rows[::7] *= 300.0
+    rows[5] *= 1e4
+    q = oracle.synth_queries(SEED + 1, nq, dim, 0)
+    with G.GpuCorpus.from_array(rows) as c:
+        c.set_scan_path(2)
+        res = c.search(q, k, G.L2)
+    for i in range(nq):
+        sc, _, _ = oracle.scores(rows, 0, 0, q[i])
+        assert_float_topk(0, res.scores[i], res.indices[i], sc, rows, q[i], k)
