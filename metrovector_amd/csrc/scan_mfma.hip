@@ -541,19 +541,12 @@ hipError_t launch_scan_mfma_f32(const BatchParams& p, int metric, int num_cus, h
     bool persistent = false;
     if (const char* e = getenv("MVF_K2_PERSISTENT")) persistent = atoi(e) != 0;
     const dim3 grid(persistent ? std::min(total, nls * 8u) : total);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&scan_mfma_f32_kernel<MVF_METRIC_COSINE>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes);
-        if (e == hipSuccess)
-            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&scan_mfma_f32_kernel<MVF_METRIC_INNER_PRODUCT>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes);
-        if (e == hipSuccess)
-            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&scan_mfma_f32_kernel<MVF_METRIC_L2>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    // > 64 KiB of dynamic LDS needs the attribute; it is per device, and one process may drive several devices
+    const void* fn = metric == MVF_METRIC_COSINE ? reinterpret_cast<const void*>(&scan_mfma_f32_kernel<MVF_METRIC_COSINE>)
+                     : metric == MVF_METRIC_L2   ? reinterpret_cast<const void*>(&scan_mfma_f32_kernel<MVF_METRIC_L2>)
+                                                 : reinterpret_cast<const void*>(&scan_mfma_f32_kernel<MVF_METRIC_INNER_PRODUCT>);
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes);
+    if (e != hipSuccess) return e;
     if (metric == MVF_METRIC_COSINE)
         hipLaunchKernelGGL(scan_mfma_f32_kernel<MVF_METRIC_COSINE>, grid, dim3(256), kLdsBytes, s, p);
     else if (metric == MVF_METRIC_L2)

@@ -486,17 +486,12 @@ __global__ void __launch_bounds__(256) row_norms_i8_kernel(const unsigned char* 
 
 template <int DT>
 hipError_t launch_dt(const Batch16Params& p, int metric, dim3 grid, hipStream_t s) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        const void* fns[3] = {reinterpret_cast<const void*>(&scan_mfma16_kernel<DT, MVF_METRIC_L2>),
-                              reinterpret_cast<const void*>(&scan_mfma16_kernel<DT, MVF_METRIC_INNER_PRODUCT>),
-                              reinterpret_cast<const void*>(&scan_mfma16_kernel<DT, MVF_METRIC_COSINE>)};
-        for (const void* f : fns) {
-            hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds16);
-            if (e != hipSuccess) return e;
-        }
-        attr_set = true;
-    }
+    // > 64 KiB of dynamic LDS needs the attribute; it is per device, and one process may drive several devices
+    const void* fn = metric == MVF_METRIC_L2 ? reinterpret_cast<const void*>(&scan_mfma16_kernel<DT, MVF_METRIC_L2>)
+                     : metric == MVF_METRIC_INNER_PRODUCT ? reinterpret_cast<const void*>(&scan_mfma16_kernel<DT, MVF_METRIC_INNER_PRODUCT>)
+                                                          : reinterpret_cast<const void*>(&scan_mfma16_kernel<DT, MVF_METRIC_COSINE>);
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds16);
+    if (e != hipSuccess) return e;
     switch (metric) {
     case MVF_METRIC_L2: hipLaunchKernelGGL((scan_mfma16_kernel<DT, MVF_METRIC_L2>), grid, dim3(512), kLds16, s, p); break;
     case MVF_METRIC_INNER_PRODUCT:
