@@ -37,6 +37,8 @@ hipError_t launch_select_final(const SelectParams& p, uint32_t nq, hipStream_t s
 hipError_t launch_merge_shards(const ShardMergeParams& p, hipStream_t s);
 hipError_t launch_synth_rows(unsigned char* rows, uint64_t n, uint32_t dim, uint32_t pitch, uint8_t dtype,
                              uint64_t seed, uint64_t row0, hipStream_t s);
+hipError_t launch_repack_rows(const unsigned char* src, unsigned char* dst, uint64_t n, uint32_t row_bytes, uint32_t pitch,
+                              hipStream_t s);
 hipError_t launch_synth_packed(void* out, uint64_t nelem, uint8_t dtype, uint64_t seed, hipStream_t s);
 
 }  // namespace mvf

@@ -186,6 +186,29 @@ __global__ void synth_rows_kernel(unsigned char* rows, uint64_t nvec, uint32_t V
     }
 }
 
+// Re-pitch tightly packed host rows (row_bytes each, uploaded with one 1-D copy) into the device layout
+// (pitch = row_bytes rounded up to 16, zero padded).  One thread per 16-B output vector; GRAN = 4 / 2 / 1 is the
+// widest access both layouts are aligned for.
+template <int GRAN>
+__global__ void repack_rows_kernel(const unsigned char* src, unsigned char* dst, uint64_t nvec, uint32_t V,
+                                   uint32_t row_bytes, uint32_t pitch) {
+    for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < nvec; t += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t r = t / V;
+        const uint32_t v = (uint32_t)(t % V);
+        const unsigned char* sp = src + r * row_bytes + (size_t)v * 16;
+        const uint32_t have = row_bytes - v * 16 < 16u ? row_bytes - v * 16 : 16u;
+        uint32_t w[4] = {0, 0, 0, 0};
+        if (GRAN == 4) {
+            for (uint32_t i = 0; i < have / 4; i++) w[i] = reinterpret_cast<const uint32_t*>(sp)[i];
+        } else if (GRAN == 2) {
+            for (uint32_t i = 0; i < have / 2; i++) w[i >> 1] |= (uint32_t)reinterpret_cast<const uint16_t*>(sp)[i] << (16 * (i & 1));
+        } else {
+            for (uint32_t i = 0; i < have; i++) w[i >> 2] |= (uint32_t)sp[i] << (8 * (i & 3));
+        }
+        *reinterpret_cast<uint4*>(dst + r * pitch + (size_t)v * 16) = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+}
+
 // Tightly packed elements (queries): one thread per element.
 __global__ void synth_packed_kernel(void* out, uint64_t nelem, uint8_t dtype, uint64_t base) {
     for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < nelem; t += (uint64_t)gridDim.x * blockDim.x) {
@@ -217,6 +240,19 @@ hipError_t launch_synth_rows(unsigned char* rows, uint64_t n, uint32_t dim, uint
     const uint64_t blocks = (nvec + 255) / 256;
     hipLaunchKernelGGL(synth_rows_kernel, dim3((unsigned)(blocks < 65536 ? blocks : 65536)), dim3(256), 0, s, rows, nvec,
                        V, dim, pitch, dtype, mix64(seed), row0);
+    return hipGetLastError();
+}
+
+hipError_t launch_repack_rows(const unsigned char* src, unsigned char* dst, uint64_t n, uint32_t row_bytes, uint32_t pitch,
+                              hipStream_t s) {
+    const uint32_t V = pitch / 16;
+    const uint64_t nvec = n * V;
+    if (nvec == 0) return hipSuccess;
+    const uint64_t blocks64 = (nvec + 255) / 256;
+    const dim3 grid((unsigned)(blocks64 < 65536 ? blocks64 : 65536));
+    if (row_bytes % 4 == 0) hipLaunchKernelGGL(repack_rows_kernel<4>, grid, dim3(256), 0, s, src, dst, nvec, V, row_bytes, pitch);
+    else if (row_bytes % 2 == 0) hipLaunchKernelGGL(repack_rows_kernel<2>, grid, dim3(256), 0, s, src, dst, nvec, V, row_bytes, pitch);
+    else hipLaunchKernelGGL(repack_rows_kernel<1>, grid, dim3(256), 0, s, src, dst, nvec, V, row_bytes, pitch);
     return hipGetLastError();
 }
 
