@@ -163,11 +163,36 @@ bool fb_vector(const FbView& v, size_t fpos, size_t elem, size_t* first, uint32_
     return true;
 }
 
+// strict UTF-8 check (the Rust verifier rejects footers whose strings are not valid UTF-8)
+bool utf8_valid(const uint8_t* p, size_t n) {
+    size_t i = 0;
+    while (i < n) {
+        const uint8_t c = p[i];
+        size_t need;
+        uint32_t cp;
+        if (c < 0x80) { i++; continue; }
+        else if ((c & 0xE0) == 0xC0) { need = 1; cp = c & 0x1F; }
+        else if ((c & 0xF0) == 0xE0) { need = 2; cp = c & 0x0F; }
+        else if ((c & 0xF8) == 0xF0) { need = 3; cp = c & 0x07; }
+        else return false;
+        if (n - i <= need) return false;
+        for (size_t k = 1; k <= need; k++) {
+            if ((p[i + k] & 0xC0) != 0x80) return false;
+            cp = (cp << 6) | (p[i + k] & 0x3F);
+        }
+        if ((need == 1 && cp < 0x80) || (need == 2 && cp < 0x800) || (need == 3 && cp < 0x10000)) return false;  // overlong
+        if (cp > 0x10FFFF || (cp >= 0xD800 && cp <= 0xDFFF)) return false;
+        i += need + 1;
+    }
+    return true;
+}
+
 bool fb_string(const FbView& v, size_t fpos, const char** s, uint32_t* len) {
     size_t first;
     uint32_t c;
     if (!fb_vector(v, fpos, 1, &first, &c)) return false;
     if (!v.in(first, (size_t)c + 1) || v.b[first + c] != 0) return false;  // NUL terminator (verifier rule)
+    if (!utf8_valid(v.b + first, c)) return false;
     *s = reinterpret_cast<const char*>(v.b + first);
     *len = c;
     return true;

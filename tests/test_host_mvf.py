@@ -234,3 +234,56 @@ def test_crc_and_half_helpers():
     assert h.mvf_crc32(buf, len(data)) == binascii.crc32(data)
     for x in (0.0, 1.0, -2.5, 3.14159, 65504.0, 1e-8, 1e10):
         assert h.mvf_f32_to_f16(x) == int(np.float32(x).astype(np.float16).view(np.uint16))
+
+
+def test_reader_survives_corrupted_footers():
+    """Untrusted input: random byte flips / truncations / splices in the footer region must give an MvfError
+    (or a still-valid file), never a crash or an out-of-bounds read (the same loop runs under ASan in CI notes)."""
+    import random
+    b = MvfBuilder()
+    b.add_vector_space("alpha", 4, VectorType.Dense, DistanceMetric.L2, DataType.Float32)
+    b.add_vectors("alpha", T)
+    b.add_vector_space("beta", 3, VectorType.Dense, DistanceMetric.Cosine, DataType.Float16)
+    b.add_vectors("beta", [[1, 2, 3], [4, 5, 6]])
+    b.add_metadata_column("ids", DataType.UInt32, struct.pack("<3I", 7, 8, 9))
+    img = b.build().to_bytes()
+    (footer_len,) = struct.unpack("<I", img[-8:-4])
+    fs = len(img) - 8 - footer_len
+    rng = random.Random(1234)
+    outcomes = {"ok": 0, "err": 0}
+    for trial in range(3000):
+        m = bytearray(img)
+        mode = trial % 4
+        if mode == 0:      # flip 1-4 bytes inside the footer
+            for _ in range(rng.randint(1, 4)):
+                m[rng.randrange(fs, len(m) - 8)] = rng.randrange(256)
+        elif mode == 1:    # overwrite a 4-byte offset/length with an extreme value
+            pos = rng.randrange(fs, len(m) - 12)
+            m[pos:pos + 4] = struct.pack("<I", rng.choice([0, 1, 0x7FFFFFFF, 0xFFFFFFFF, len(m), footer_len]))
+        elif mode == 2:    # truncate the file somewhere and re-attach a plausible tail
+            cut = rng.randrange(4, len(m) - 8)
+            m = m[:cut] + m[-8:]
+        else:              # lie about the footer length
+            m[-8:-4] = struct.pack("<I", rng.randrange(0, 2 * len(m)))
+        try:
+            r = MvfReader.from_bytes(bytes(m))
+            for name in r.vector_space_names():
+                s = r.vector_space(name)
+                s.name(), s.dimension(), s.total_vectors(), s.data_type()
+                try:
+                    if s.total_vectors():
+                        s.get_vector(0).as_bytes()
+                        s.map_vector_range(0, min(2, s.total_vectors()))
+                except E.MvfError:
+                    pass
+            try:
+                r.validate()
+                r.validate_with_checksum()
+            except E.MvfError:
+                pass
+            r.blocks(), r.metadata_column_names()
+            r.close()
+            outcomes["ok"] += 1
+        except E.MvfError:
+            outcomes["err"] += 1
+    assert outcomes["err"] > 500 and outcomes["ok"] > 0
