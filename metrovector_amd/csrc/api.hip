@@ -297,15 +297,16 @@ int search_batched_path(const mvfgpu_corpus* c, uint8_t metric, const void* d_qu
     HIP_TRY(c->bcand.reserve((size_t)nq_pad * cap * 8));
     const bool is_float = !is_int_dtype(c->dtype);
     const bool float_l2 = is_float && metric == MVF_METRIC_L2;
-    const bool need_norms = metric != MVF_METRIC_INNER_PRODUCT;
-    // K4 buffer: float rows: |x| [n], sum x^2 [n], max sum x^2 [1]; int8 rows: sum x^2 (i32) [n]
+    const bool need_norms = metric != MVF_METRIC_INNER_PRODUCT || c->dtype == MVF_DTYPE_UINT8;
+    // K4 buffer: float rows: |x| [n], sum x^2 [n], max sum x^2 [1]; Int8 rows: sum x^2 (i32) [n];
+    // UInt8 rows: sum (x-128)^2 [n], 128 * sum (x-128) [n]
     const size_t nn = std::max<uint32_t>(n, 1);
     if (need_norms && !c->xnorm_ready) {  // once per resident corpus
-        HIP_TRY(c->xnorm.reserve(is_float ? (2 * nn + 1) * 4 : nn * 4));
+        HIP_TRY(c->xnorm.reserve((2 * nn + 1) * 4));
         float* xn = static_cast<float*>(c->xnorm.p);
         if (is_float) HIP_TRY(hipMemsetAsync(xn + 2 * nn, 0, 4, s));
         if (wide) HIP_TRY(launch_row_norms_f32(c->d_rows, n, c->pitch, xn, xn + nn, xn + 2 * nn, s));
-        else HIP_TRY(launch_row_norms16(c->d_rows, c->dtype, n, c->pitch, c->xnorm.p, xn + nn, xn + 2 * nn, s));
+        else HIP_TRY(launch_row_norms16(c->d_rows, c->dtype, n, c->pitch, c->dim, c->xnorm.p, xn + nn, xn + 2 * nn, s));
         c->xnorm_ready = true;
     }
     const float* xx2 = is_float && c->xnorm.p ? static_cast<const float*>(c->xnorm.p) + nn : nullptr;
@@ -341,6 +342,8 @@ int search_batched_path(const mvfgpu_corpus* c, uint8_t metric, const void* d_qu
     hp.rows = c->d_rows;
     hp.xnorm_f = static_cast<const float*>(c->xnorm.p);
     hp.xnorm_i = static_cast<const int32_t*>(c->xnorm.p);
+    hp.xbias_i = c->xnorm.p ? static_cast<const int32_t*>(c->xnorm.p) + nn : nullptr;
+    hp.dim = c->dim;
     hp.xx2 = xx2;
     hp.xxmax = xxmax;
     hp.tau = tau;
@@ -458,8 +461,8 @@ int search_batched_path(const mvfgpu_corpus* c, uint8_t metric, const void* d_qu
 bool use_batched_path(const mvfgpu_corpus* c, uint8_t metric, uint32_t nq) {
     if (c->scan_path == 1) return false;
     // Float32 / Float16: every metric (L2 = GEMM-form selection with an error margin + exact re-scoring);
-    // Int8: every metric (exact integers).  UInt8 has no unsigned MFMA: stays on K1.
-    bool supported = c->dtype == MVF_DTYPE_FLOAT32 || c->dtype == MVF_DTYPE_FLOAT16 || c->dtype == MVF_DTYPE_INT8;
+    // Int8 / UInt8: every metric, exact integers (UInt8 rides the signed MFMA shifted by 128).
+    bool supported = true;
     if (metric == MVF_METRIC_L2 && !is_int_dtype(c->dtype) && (size_t)((c->dim + 7u) & ~7u) * 4 + kBatchCap * 4 > 64 * 1024)
         supported = false;  // the re-scoring kernel keeps the query in LDS
     if (!supported) return false;

@@ -35,7 +35,9 @@ struct Batch16Params {
     const float* xnorm_f;        // [n] f16 rows: sqrt(sum x^2)
     const float* xx2;            // [n] f16 rows: sum x^2 (batched L2)
     const float* xxmax;          // [1] max over rows of sum x^2
-    const int32_t* xnorm_i;      // [n] i8 rows: sum x^2
+    const int32_t* xnorm_i;      // [n] int rows: sum x^2 (UInt8: of the shifted values x-128)
+    const int32_t* xbias_i;      // [n] UInt8 rows: 128 * sum (x-128)
+    uint32_t dim;
     const uint32_t* tau;
     uint64_t* cand;
     uint32_t* cnt;
@@ -98,7 +100,7 @@ uint32_t scan_mfma16_queries_per_block(int dtype);
 hipError_t launch_scan_mfma16(const Batch16Params& p, int dtype, int metric, int num_cus, hipStream_t s);
 hipError_t launch_prep_queries16(const void* q, int dtype, uint32_t nq, uint32_t nq_pad, uint32_t dim, uint32_t KPB,
                                  unsigned char* qprep, float* qaux0, float* qaux1, hipStream_t s);
-hipError_t launch_row_norms16(const unsigned char* rows, int dtype, uint32_t n, uint32_t pitch, void* out, float* xx2,
-                              float* xxmax, hipStream_t s);
+hipError_t launch_row_norms16(const unsigned char* rows, int dtype, uint32_t n, uint32_t pitch, uint32_t dim, void* out,
+                              float* xx2, float* xxmax, hipStream_t s);  // UInt8: xx2 receives the int32 bias array
 
 }  // namespace mvf

@@ -56,12 +56,21 @@ template <> struct T16<MVF_DTYPE_INT8> {
     static constexpr int PLANES = 1, IT = 4;
     using Acc = i32x16;
 };
+// UInt8 rows ride the SIGNED int8 MFMA shifted by 128 (x_s = x_u - 128 = x_u ^ 0x80 as int8, same for q):
+//   dot_u = dot_s + 128 (Sq_s + Sx_s) + 16384 d,   L2_u = qq_s + xx_s - 2 dot_s (shift invariant),
+//   qq_u = qq_s + 256 Sq_s + 16384 d,  xx_u likewise — all exact integers, so the results stay bit-identical to
+//   K1's v_dot4_u32_u8 path.  Per row K4 stores xx_s and bx = 128 Sx_s; per query qq_s and cqq = 128 Sq_s + 16384 d.
+template <> struct T16<MVF_DTYPE_UINT8> {
+    static constexpr int PLANES = 1, IT = 4;
+    using Acc = i32x16;
+};
 
 template <int DT, int METRIC>
 __global__ void __launch_bounds__(512, 2) scan_mfma16_kernel(Batch16Params p) {
     using Tr = T16<DT>;
     constexpr int PLANES = Tr::PLANES, IT = Tr::IT;
     constexpr int BMQ = AROWS / PLANES;  // queries per block
+    constexpr bool U8 = DT == MVF_DTYPE_UINT8;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float* qa_s = reinterpret_cast<float*>(smem + 4 * TILE_B);    // [256] f16: 2^-e / i8: qq (as int)
     uint32_t* tau_s = reinterpret_cast<uint32_t*>(qa_s + 256);    // [256]
@@ -111,14 +120,18 @@ __global__ void __launch_bounds__(512, 2) scan_mfma16_kernel(Batch16Params p) {
                     thr_s[tid] = tq - fabsf(tq) * 2e-6f;
                 }
             } else {
-                const int32_t qq = __float_as_int(qa);
+                const int32_t qq = __float_as_int(qa);   // sum q^2 (UInt8: of the shifted query)
+                const int32_t cqq = __float_as_int(qb);  // UInt8: 128 Sq_s + 16384 d (>= 0); Int8: 0
                 if (METRIC == MVF_METRIC_INNER_PRODUCT) {
-                    thr_s[tid] = __int_as_float(raw_from_key(tau, METRIC));            // dot >= traw (exact)
+                    // dot_u = acc + bx + cqq >= traw  <=>  acc + bx >= traw - cqq   (exact; clamp the "no threshold" case)
+                    const int32_t traw = raw_from_key(tau, METRIC);
+                    thr_s[tid] = __int_as_float(traw < INT32_MIN + cqq ? INT32_MIN : traw - cqq);
                 } else if (METRIC == MVF_METRIC_L2) {
                     thr_s[tid] = __int_as_float(qq - raw_from_key(tau, METRIC));       // 2 dot - xx >= qq - traw (exact)
                 } else {
                     const float ts = score_from_key(tau, METRIC);
-                    const float tq = ts * sqrtf((float)qq);                            // dot * 1/|x| >= ts * |q|
+                    const int32_t qqu = U8 ? qq + 2 * cqq - 16384 * (int32_t)p.dim : qq;
+                    const float tq = ts * sqrtf((float)qqu);                           // dot * 1/|x| >= ts * |q|
                     thr_s[tid] = tq - fabsf(tq) * 2e-6f;
                 }
             }
@@ -181,8 +194,11 @@ __global__ void __launch_bounds__(512, 2) scan_mfma16_kernel(Batch16Params p) {
         unsigned char* bb = smem + stage * 2 * TILE_B + TILE_B;
         const bool vok = kt * 8 + sc < p.V;
 #pragma unroll
-        for (int i = 0; i < 4; i++)
-            *reinterpret_cast<u32x4*>(bb + (sr + 64 * i) * LDPB + sc * 16) = vok ? rb[i] : u32x4{0, 0, 0, 0};
+        for (int i = 0; i < 4; i++) {
+            u32x4 x = vok ? rb[i] : u32x4{0, 0, 0, 0};
+            if (U8) x ^= u32x4{0x80808080u, 0x80808080u, 0x80808080u, 0x80808080u};  // x_u -> x_s (k padding: q_s is 0 there)
+            *reinterpret_cast<u32x4*>(bb + (sr + 64 * i) * LDPB + sc * 16) = x;
+        }
     };
 
     typename Tr::Acc acc[IT][2];
@@ -250,17 +266,20 @@ __global__ void __launch_bounds__(512, 2) scan_mfma16_kernel(Batch16Params p) {
             const uint32_t r = r0 + lane_r + j * 32;
             const bool rok = r < p.row_end;
             float xnf = 0.f, rx = 1.f, xxf = 0.f;
-            int32_t xxi = 0;
+            int32_t xxi = 0, bx = 0, xxu = 0;  // xxi: sum x^2 (UInt8: shifted); bx: UInt8 128 Sx_s; xxu: UInt8 sum x_u^2
             if (rok) {
                 if constexpr (DT == MVF_DTYPE_FLOAT16) {
                     if (METRIC == MVF_METRIC_COSINE) xnf = p.xnorm_f[r];
                     if (METRIC == MVF_METRIC_L2) xxf = p.xx2[r];
                 } else {
                     if (METRIC != MVF_METRIC_INNER_PRODUCT) xxi = p.xnorm_i[r];
+                    if (U8 && METRIC != MVF_METRIC_L2) bx = p.xbias_i[r];
                 }
             }
+            if (U8) xxu = xxi + 2 * bx + 16384 * (int32_t)p.dim;
             if (METRIC == MVF_METRIC_COSINE) {
                 if constexpr (DT == MVF_DTYPE_FLOAT16) rx = xnf > 0.0f ? __builtin_amdgcn_rcpf(xnf) : 0.0f;
+                else if (U8) rx = xxu > 0 ? __builtin_amdgcn_rcpf(sqrtf((float)xxu)) : 0.0f;
                 else rx = xxi > 0 ? __builtin_amdgcn_rcpf(sqrtf((float)xxi)) : 0.0f;
             }
 #pragma unroll
@@ -272,6 +291,8 @@ __global__ void __launch_bounds__(512, 2) scan_mfma16_kernel(Batch16Params p) {
                     u32x4 sc4 = u32x4{0, 0, 0, 0};
                     if (DT == MVF_DTYPE_FLOAT16 && METRIC == MVF_METRIC_L2)
                         sc4 = *reinterpret_cast<const u32x4*>(qa_s + lane_q + i * 32 + 8 * g);  // 2^-e per query
+                    if (U8 && METRIC == MVF_METRIC_COSINE)
+                        sc4 = *reinterpret_cast<const u32x4*>(qb_s + lane_q + i * 32 + 8 * g);  // cqq per query
 #pragma unroll
                     for (int t = 0; t < 4; t++) {
                         bool pass;
@@ -281,11 +302,11 @@ __global__ void __launch_bounds__(512, 2) scan_mfma16_kernel(Batch16Params p) {
                                                                         : acc[i][j][4 * g + t];
                             pass = !(y < __uint_as_float(th4[t]));
                         } else if (METRIC == MVF_METRIC_INNER_PRODUCT) {
-                            pass = acc[i][j][4 * g + t] >= (int32_t)th4[t];
+                            pass = acc[i][j][4 * g + t] + bx >= (int32_t)th4[t];
                         } else if (METRIC == MVF_METRIC_L2) {
                             pass = 2 * acc[i][j][4 * g + t] - xxi >= (int32_t)th4[t];
                         } else {
-                            pass = !((float)acc[i][j][4 * g + t] * rx < __uint_as_float(th4[t]));
+                            pass = !((float)(acc[i][j][4 * g + t] + bx + (int32_t)sc4[t]) * rx < __uint_as_float(th4[t]));
                         }
                         m |= (pass ? 1u : 0u) << (4 * g + t);
                     }
@@ -306,14 +327,17 @@ __global__ void __launch_bounds__(512, 2) scan_mfma16_kernel(Batch16Params p) {
                                 if (METRIC == MVF_METRIC_L2) sc_ = qb_s[ql] * qb_s[ql] + xxf - 2.0f * sc_;  // GEMM-form s2
                                 key = key_from_score(sc_, METRIC);
                             } else {
-                                const int32_t dot = acc[i][j][e];
                                 const int32_t qq = __float_as_int(qa_s[ql]);
+                                const int32_t cqq = __float_as_int(qb_s[ql]);
+                                const int32_t dot = U8 ? acc[i][j][e] + bx + cqq : acc[i][j][e];  // dot in the space's own domain
                                 if (METRIC == MVF_METRIC_L2) {
-                                    key = key_from_raw(qq + xxi - 2 * dot, METRIC);
+                                    key = key_from_raw(qq + xxi - 2 * acc[i][j][e], METRIC);  // shift invariant
                                 } else if (METRIC == MVF_METRIC_INNER_PRODUCT) {
                                     key = key_from_raw(dot, METRIC);
                                 } else {
-                                    const float den = sqrtf((float)qq) * sqrtf((float)xxi);
+                                    const int32_t qqn = U8 ? qq + 2 * cqq - 16384 * (int32_t)p.dim : qq;
+                                    const int32_t xxn = U8 ? xxu : xxi;
+                                    const float den = sqrtf((float)qqn) * sqrtf((float)xxn);
                                     key = key_from_score(den > 0.0f ? (float)dot / den : 0.0f, METRIC);
                                 }
                             }
@@ -438,6 +462,34 @@ __global__ void prep_queries_i8_kernel(const int8_t* q, uint32_t nq, uint32_t nq
     }
 }
 
+// u8: shifted int8 copy (q ^ 0x80), zero padded in the SIGNED domain; qaux0 = bits of sum q_s^2,
+// qaux1 = bits of 128 * sum q_s + 16384 * dim.
+__global__ void prep_queries_u8_kernel(const uint8_t* q, uint32_t nq, uint32_t nq_pad, uint32_t dim, uint32_t KPB,
+                                       unsigned char* qprep, float* qaux0, float* qaux1) {
+    const uint32_t row = blockIdx.x;
+    __shared__ int red[8];
+    int ss = 0, su = 0;
+    for (uint32_t c = threadIdx.x; c < KPB; c += blockDim.x) {
+        const int v = (row < nq && c < dim) ? (int)q[(size_t)row * dim + c] - 128 : 0;
+        reinterpret_cast<int8_t*>(qprep)[(size_t)row * KPB + c] = (int8_t)v;
+        ss += v * v;
+        su += v;
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        ss += __shfl_xor(ss, off, 64);
+        su += __shfl_xor(su, off, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        red[threadIdx.x >> 6] = ss;
+        red[4 + (threadIdx.x >> 6)] = su;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        qaux0[row] = __int_as_float(red[0] + red[1] + red[2] + red[3]);
+        qaux1[row] = __int_as_float(128 * (red[4] + red[5] + red[6] + red[7]) + 16384 * (int)dim);
+    }
+}
+
 // ---- K4 for the narrow types: one wave per row ----------------------------------------------
 __global__ void __launch_bounds__(256) row_norms_f16_kernel(const unsigned char* rows, uint32_t n, uint32_t pitch,
                                                              uint32_t V, float* xnorm, float* xx2, float* xxmax) {
@@ -484,6 +536,37 @@ __global__ void __launch_bounds__(256) row_norms_i8_kernel(const unsigned char* 
     }
 }
 
+// UInt8 rows: xx[r] = sum (x-128)^2, xbias[r] = 128 * sum (x-128), over the row's REAL elements
+__global__ void __launch_bounds__(256) row_norms_u8_kernel(const unsigned char* rows, uint32_t n, uint32_t pitch,
+                                                            uint32_t V, uint32_t dim, int32_t* xx, int32_t* xbias) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t wave = (blockIdx.x * 256u + threadIdx.x) >> 6, nwaves = (gridDim.x * 256u) >> 6;
+    for (uint32_t r = wave; r < n; r += nwaves) {
+        const unsigned char* rp = rows + (size_t)r * pitch;
+        int s2 = 0, s1 = 0;
+        for (uint32_t v = lane; v < V; v += 64) {
+            const u32x4 x = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(rp + (size_t)v * 16));
+#pragma unroll
+            for (int w = 0; w < 4; w++) {
+                // bytes past `dim` inside the last vector are zero padding: keep them 0 in the signed domain too
+                const uint32_t e0 = v * 16 + w * 4;
+                uint32_t mask = e0 + 4 <= dim ? 0xFFFFFFFFu : e0 >= dim ? 0u : (0xFFFFFFFFu >> (8 * (4 - (dim - e0))));
+                const uint32_t xs = (x[w] ^ 0x80808080u) & mask;
+                s2 = __builtin_amdgcn_sdot4((int)xs, (int)xs, s2, false);
+                s1 = __builtin_amdgcn_sdot4((int)xs, 0x01010101, s1, false);
+            }
+        }
+        for (int off = 32; off > 0; off >>= 1) {
+            s2 += __shfl_xor(s2, off, 64);
+            s1 += __shfl_xor(s1, off, 64);
+        }
+        if (lane == 0) {
+            xx[r] = s2;
+            xbias[r] = 128 * s1;
+        }
+    }
+}
+
 template <int DT>
 hipError_t launch_dt(const Batch16Params& p, int metric, dim3 grid, hipStream_t s) {
     // > 64 KiB of dynamic LDS needs the attribute; it is per device, and one process may drive several devices
@@ -504,7 +587,7 @@ hipError_t launch_dt(const Batch16Params& p, int metric, dim3 grid, hipStream_t 
 
 }  // namespace
 
-uint32_t scan_mfma16_queries_per_block(int dtype) { return dtype == MVF_DTYPE_FLOAT16 ? 128u : 256u; }
+uint32_t scan_mfma16_queries_per_block(int dtype) { return dtype == MVF_DTYPE_FLOAT16 ? 128u : 256u; }  // Int8 / UInt8: 256
 
 hipError_t launch_scan_mfma16(const Batch16Params& p, int dtype, int metric, int num_cus, hipStream_t s) {
     // Grid: a multiple of 8 (one lane set per XCD).  Persistent (one block per CU, LDS-limited) or one tile per
@@ -516,6 +599,7 @@ hipError_t launch_scan_mfma16(const Batch16Params& p, int dtype, int metric, int
     if (const char* e = getenv("MVF_K2_PERSISTENT16")) persistent = atoi(e) != 0;
     const dim3 grid(persistent ? std::min(total, nls * 8u) : total);
     if (dtype == MVF_DTYPE_FLOAT16) return launch_dt<MVF_DTYPE_FLOAT16>(p, metric, grid, s);
+    if (dtype == MVF_DTYPE_UINT8) return launch_dt<MVF_DTYPE_UINT8>(p, metric, grid, s);
     return launch_dt<MVF_DTYPE_INT8>(p, metric, grid, s);
 }
 
@@ -524,19 +608,25 @@ hipError_t launch_prep_queries16(const void* q, int dtype, uint32_t nq, uint32_t
     if (dtype == MVF_DTYPE_FLOAT16)
         hipLaunchKernelGGL(prep_queries_f16_kernel, dim3(nq_pad), dim3(256), 0, s, static_cast<const float*>(q), nq, nq_pad,
                            dim, KPB, qprep, qaux0, qaux1);
+    else if (dtype == MVF_DTYPE_UINT8)
+        hipLaunchKernelGGL(prep_queries_u8_kernel, dim3(nq_pad), dim3(256), 0, s, static_cast<const uint8_t*>(q), nq, nq_pad,
+                           dim, KPB, qprep, qaux0, qaux1);
     else
         hipLaunchKernelGGL(prep_queries_i8_kernel, dim3(nq_pad), dim3(256), 0, s, static_cast<const int8_t*>(q), nq, nq_pad,
                            dim, KPB, qprep, qaux0, qaux1);
     return hipGetLastError();
 }
 
-hipError_t launch_row_norms16(const unsigned char* rows, int dtype, uint32_t n, uint32_t pitch, void* out, float* xx2,
-                              float* xxmax, hipStream_t s) {
+hipError_t launch_row_norms16(const unsigned char* rows, int dtype, uint32_t n, uint32_t pitch, uint32_t dim, void* out,
+                              float* xx2, float* xxmax, hipStream_t s) {
     if (n == 0) return hipSuccess;
     const uint32_t blocks = (uint32_t)std::min<uint64_t>(((uint64_t)n + 3) / 4, 256u * 8u);
     if (dtype == MVF_DTYPE_FLOAT16)
         hipLaunchKernelGGL(row_norms_f16_kernel, dim3(blocks), dim3(256), 0, s, rows, n, pitch, pitch / 16, static_cast<float*>(out),
                            xx2, xxmax);
+    else if (dtype == MVF_DTYPE_UINT8)
+        hipLaunchKernelGGL(row_norms_u8_kernel, dim3(blocks), dim3(256), 0, s, rows, n, pitch, pitch / 16, dim,
+                           static_cast<int32_t*>(out), reinterpret_cast<int32_t*>(xx2));
     else
         hipLaunchKernelGGL(row_norms_i8_kernel, dim3(blocks), dim3(256), 0, s, rows, n, pitch, pitch / 16, static_cast<int32_t*>(out));
     return hipGetLastError();

@@ -474,17 +474,38 @@ def test_cfg5_shard_12p5m_x_1024_f16_l2_batched(oracle):
 # Float16 on f16 MFMA with hi/lo-split queries
 # ---------------------------------------------------------------------------
 
+@pytest.mark.parametrize("dtype", [2, 3])
 @pytest.mark.parametrize("metric", [0, 1, 2])
-@pytest.mark.parametrize("shape", [(30000, 768, 256, 100), (5000, 100, 33, 10), (300, 64, 300, 500), (9001, 20, 40, 1)])
-def test_batched_mfma_int8_bit_exact(oracle, metric, shape):
+@pytest.mark.parametrize("shape", [(30000, 768, 256, 100), (5000, 100, 33, 10), (300, 64, 300, 500), (9001, 20, 40, 1),
+                                   (4000, 33, 64, 16)])
+def test_batched_mfma_int8_bit_exact(oracle, dtype, metric, shape):
+    """Int8 on the i32 MFMA, UInt8 on the same MFMA shifted by 128 with exact corrections: bit-exact vs the CPU."""
     n, dim, nq, k = shape
-    rows = oracle.synth_rows(SEED, 0, n, dim, 2)
-    q = oracle.synth_queries(SEED + 1, nq, dim, 2)
+    rows = oracle.synth_rows(SEED, 0, n, dim, dtype)
+    q = oracle.synth_queries(SEED + 1, nq, dim, dtype)
     with G.GpuCorpus.from_array(rows, index_base=5) as c:
         c.set_scan_path(2)
         res = c.search(q, k, metric)
-    osc, oidx, oraw = oracle.search(rows, 2, metric, q, k, index_base=5)
+    osc, oidx, oraw = oracle.search(rows, dtype, metric, q, k, index_base=5)
     assert_exact(res, osc, oidx, oraw)
+
+
+def test_batched_mfma_uint8_extremes(oracle):
+    """All-0 / all-255 rows and queries stress the shift corrections (sums at their extremes)."""
+    rng = np.random.default_rng(11)
+    rows = rng.integers(0, 256, (6000, 96), dtype=np.uint8)
+    rows[0] = 0
+    rows[1] = 255
+    rows[2, ::2] = 255
+    q = rng.integers(0, 256, (40, 96), dtype=np.uint8)
+    q[0] = 0
+    q[1] = 255
+    for metric in (0, 1, 2):
+        with G.GpuCorpus.from_array(rows) as c:
+            c.set_scan_path(2)
+            res = c.search(q, 50, metric)
+        osc, oidx, oraw = oracle.search(rows, 3, metric, q, 50)
+        assert_exact(res, osc, oidx, oraw)
 
 
 def test_batched_mfma_int8_ties(oracle):
