@@ -130,6 +130,13 @@ int mvfgpu_corpus_get_info(const mvfgpu_corpus* corpus, mvfgpu_corpus_info* out)
 int mvfgpu_corpus_read_rows(const mvfgpu_corpus* corpus, uint64_t first,
                             uint64_t count, void* out_rows);
 
+/* Gather arbitrary rows by GLOBAL index (as returned by a search) from HBM, tightly packed, in the order given:
+ * the payload of the reference's ScoredVector.vector (examples/similarity_search.rs:18,:159-163) without touching
+ * the file again.  Indices of UINT64_MAX (padding of a short result list) give zero rows; any other index outside
+ * [index_base, index_base + rows) -> MVF_ERR_INDEX_OUT_OF_BOUNDS. */
+int mvfgpu_corpus_gather_rows(const mvfgpu_corpus* corpus, const uint64_t* indices,
+                              uint64_t count, void* out_rows);
+
 /* ---- search -------------------------------------------------------------- */
 
 /*

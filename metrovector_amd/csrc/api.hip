@@ -680,6 +680,36 @@ int mvfgpu_corpus_read_rows(const mvfgpu_corpus* c, uint64_t first, uint64_t cou
     return MVF_OK;
 }
 
+int mvfgpu_corpus_gather_rows(const mvfgpu_corpus* c, const uint64_t* indices, uint64_t count, void* out_rows) {
+    if (!c || (count && (!indices || !out_rows))) return fail(MVF_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (count == 0) return MVF_OK;
+    if (count > 0xFFFFFFFFull) return fail(MVF_ERR_INVALID_ARGUMENT, "too many rows in one gather");
+    for (uint64_t i = 0; i < count; i++) {
+        const uint64_t g = indices[i];
+        if (g == ~0ull) continue;  // padding of a short result list: a zero row
+        if (g < c->index_base || g - c->index_base >= c->n) {
+            g_last_error = "Index out of bounds: " + std::to_string(g) + " >= " + std::to_string(c->index_base + c->n);
+            return MVF_ERR_INDEX_OUT_OF_BOUNDS;  // reference src/vectors/vector_space.rs:102-107
+        }
+    }
+    DeviceGuard guard(c->device);
+    if (!guard.ok) return fail(MVF_ERR_DEVICE, "hipSetDevice failed");
+    const uint32_t row_bytes = c->dim * elem_size(c->dtype);
+    std::lock_guard<std::mutex> host_lk(c->host_mu);
+    {
+        std::lock_guard<std::mutex> lk(c->mu);
+        if (c->has_done) HIP_TRY(hipEventSynchronize(c->ev_done));
+        HIP_TRY(c->h_i.reserve((size_t)count * 8));
+        HIP_TRY(c->h_q.reserve((size_t)count * row_bytes));
+    }
+    HIP_TRY(hipMemcpyAsync(c->h_i.p, indices, (size_t)count * 8, hipMemcpyHostToDevice, c->own_stream));
+    HIP_TRY(launch_gather_rows(c->d_rows, c->n, c->pitch, row_bytes, c->index_base, static_cast<const uint64_t*>(c->h_i.p),
+                               (uint32_t)count, static_cast<unsigned char*>(c->h_q.p), c->own_stream));
+    HIP_TRY(hipMemcpyAsync(out_rows, c->h_q.p, (size_t)count * row_bytes, hipMemcpyDeviceToHost, c->own_stream));
+    HIP_TRY(hipStreamSynchronize(c->own_stream));
+    return MVF_OK;
+}
+
 int mvfgpu_search_device(const mvfgpu_corpus* c, uint8_t metric, const void* d_queries, uint8_t query_dtype,
                          uint32_t query_dim, uint32_t nq, uint32_t k, float* d_scores, uint64_t* d_indices,
                          int32_t* d_raw, void* hip_stream) {

@@ -39,6 +39,8 @@ hipError_t launch_synth_rows(unsigned char* rows, uint64_t n, uint32_t dim, uint
                              uint64_t seed, uint64_t row0, hipStream_t s);
 hipError_t launch_repack_rows(const unsigned char* src, unsigned char* dst, uint64_t n, uint32_t row_bytes, uint32_t pitch,
                               hipStream_t s);
+hipError_t launch_gather_rows(const unsigned char* rows, uint64_t n, uint32_t pitch, uint32_t row_bytes, uint64_t index_base,
+                              const uint64_t* d_idx, uint32_t count, unsigned char* d_out, hipStream_t s);
 hipError_t launch_synth_packed(void* out, uint64_t nelem, uint8_t dtype, uint64_t seed, hipStream_t s);
 
 }  // namespace mvf

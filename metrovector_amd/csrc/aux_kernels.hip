@@ -11,6 +11,8 @@
 
 #include <hip/hip_fp16.h>
 
+#include <algorithm>
+
 namespace mvf {
 namespace {
 
@@ -209,6 +211,22 @@ __global__ void repack_rows_kernel(const unsigned char* src, unsigned char* dst,
     }
 }
 
+// Payload gather: rows[idx[i] - index_base] -> out[i] (tightly packed, row_bytes each); out-of-range / padding
+// indices give zero rows.  One wave per row, byte granular (result sets are tiny).
+__global__ void __launch_bounds__(256) gather_rows_kernel(const unsigned char* rows, uint64_t n, uint32_t pitch,
+                                                           uint32_t row_bytes, uint64_t index_base, const uint64_t* idx,
+                                                           uint32_t count, unsigned char* out) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t wave = (blockIdx.x * 256u + threadIdx.x) >> 6, nwaves = (gridDim.x * 256u) >> 6;
+    for (uint32_t i = wave; i < count; i += nwaves) {
+        const uint64_t g = idx[i];
+        const bool ok = g >= index_base && g - index_base < n;
+        const unsigned char* src = rows + (ok ? (g - index_base) : 0) * pitch;
+        unsigned char* dst = out + (size_t)i * row_bytes;
+        for (uint32_t b = lane; b < row_bytes; b += 64) dst[b] = ok ? src[b] : (unsigned char)0;
+    }
+}
+
 // Tightly packed elements (queries): one thread per element.
 __global__ void synth_packed_kernel(void* out, uint64_t nelem, uint8_t dtype, uint64_t base) {
     for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < nelem; t += (uint64_t)gridDim.x * blockDim.x) {
@@ -253,6 +271,14 @@ hipError_t launch_repack_rows(const unsigned char* src, unsigned char* dst, uint
     if (row_bytes % 4 == 0) hipLaunchKernelGGL(repack_rows_kernel<4>, grid, dim3(256), 0, s, src, dst, nvec, V, row_bytes, pitch);
     else if (row_bytes % 2 == 0) hipLaunchKernelGGL(repack_rows_kernel<2>, grid, dim3(256), 0, s, src, dst, nvec, V, row_bytes, pitch);
     else hipLaunchKernelGGL(repack_rows_kernel<1>, grid, dim3(256), 0, s, src, dst, nvec, V, row_bytes, pitch);
+    return hipGetLastError();
+}
+
+hipError_t launch_gather_rows(const unsigned char* rows, uint64_t n, uint32_t pitch, uint32_t row_bytes, uint64_t index_base,
+                              const uint64_t* d_idx, uint32_t count, unsigned char* d_out, hipStream_t s) {
+    if (count == 0) return hipSuccess;
+    const uint32_t blocks = std::min<uint32_t>((count + 3) / 4, 2048u);
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(blocks), dim3(256), 0, s, rows, n, pitch, row_bytes, index_base, d_idx, count, d_out);
     return hipGetLastError();
 }
 

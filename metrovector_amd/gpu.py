@@ -121,6 +121,16 @@ class GpuCorpus:
         _lib.gpu_check(_lib.gpu().mvfgpu_corpus_read_rows(self._h, first, count, out.ctypes.data_as(C.c_void_p)))
         return out
 
+    def gather_rows(self, indices) -> np.ndarray:
+        """Rows by GLOBAL index, in the order given (`mvfgpu_corpus_gather_rows`): the payload of the
+        reference's ScoredVector.vector, served from HBM."""
+        inf = self.info()
+        idx = np.ascontiguousarray(np.asarray(indices).reshape(-1), np.uint64)
+        out = np.empty((idx.size, inf.dimension), _NP_OF[inf.data_type])
+        _lib.gpu_check(_lib.gpu().mvfgpu_corpus_gather_rows(self._h, idx.ctypes.data_as(C.c_void_p), idx.size,
+                                                            out.ctypes.data_as(C.c_void_p)))
+        return out
+
     # ---- search ----------------------------------------------------------------
     def search(self, queries: np.ndarray, k: int, metric: int = L2) -> SearchResult:
         """Host-buffer search (`mvfgpu_search`)."""

@@ -61,15 +61,14 @@ def find_top_k_similar(space: VectorSpace, query, k: int, metric: int | None = N
     try:
         qd = _NP_OF[query_dtype_code(int(space.data_type()))]
         res = corpus.search(np.asarray(query, dtype=qd), k, metric)
+        valid = res.indices[0] != np.uint64(0xFFFFFFFFFFFFFFFF)  # fewer than k rows: the reference returns fewer items
+        rows = corpus.gather_rows(res.indices[0][valid])            # payload straight from HBM
     finally:
         if own:
             corpus.close()
+    dt = int(space.data_type())
     out = []
-    for idx, score in zip(res.indices[0], res.scores[0]):
-        if idx == np.uint64(0xFFFFFFFFFFFFFFFF):
-            break  # fewer than k rows: the reference simply returns fewer items
-        v = space.get_vector(int(idx))
-        dt = int(space.data_type())
-        payload = v.as_f32() if dt in (0, 1) else v.as_slice(_NP_OF[dt]).copy()
+    for idx, score, row in zip(res.indices[0][valid], res.scores[0][valid], rows):
+        payload = row.astype(np.float32) if dt in (0, 1) else row.copy()  # as Vector::as_f32 for float spaces
         out.append(ScoredVector(int(idx), float(score), payload))
     return out

@@ -592,3 +592,20 @@ def test_batched_l2_heterogeneous_norms(oracle):
     for i in range(nq):
         sc, _, _ = oracle.scores(rows, 0, 0, q[i])
         assert_float_topk(0, res.scores[i], res.indices[i], sc, rows, q[i], k)
+
+
+def test_gather_rows_payload(oracle):
+    """mvfgpu_corpus_gather_rows: the ScoredVector.vector payload served from HBM."""
+    for dtype, dim in ((0, 13), (1, 40), (2, 7), (3, 100)):
+        rows = oracle.synth_rows(SEED, 0, 5000, dim, dtype)
+        with G.GpuCorpus.from_array(rows, index_base=10_000) as c:
+            idx = np.array([10_000, 14_999, 12_345, 10_001, 12_345], np.uint64)
+            got = c.gather_rows(idx)
+            assert (got.view(np.uint8) == rows[(idx - 10_000).astype(np.int64)].view(np.uint8)).all()
+            pad = c.gather_rows(np.array([0xFFFFFFFFFFFFFFFF, 10_002], np.uint64))
+            assert (pad[0].view(np.uint8) == 0).all() and (pad[1].view(np.uint8) == rows[2].view(np.uint8)).all()
+            with pytest.raises(E.IndexOutOfBounds):
+                c.gather_rows(np.array([15_000], np.uint64))
+            with pytest.raises(E.IndexOutOfBounds):
+                c.gather_rows(np.array([9_999], np.uint64))
+            assert c.gather_rows(np.array([], np.uint64)).shape == (0, dim)
