@@ -139,20 +139,23 @@ __global__ void __launch_bounds__(512, 2) scan_mfma16_kernel(Batch16Params p) {
     };
 
     // ---- staging: thread -> 16-B chunk (row sr + 64*i, column sc) of each tile ----------
-    // Branch-free loads: rows past row_end read row 0 (their output columns are discarded in the epilogue);
+    // Branch-free loads: rows past row_end re-read a valid row (their output columns are discarded in the epilogue);
     // k beyond the row's pitch reads the row start and is zeroed with a select at LDS-store time.
     const int sr = tid >> 3, sc = tid & 7;
     uint32_t a_n = 0, a_kt = 0, b_n = 0, b_kt = 0;  // load cursors: (tile ordinal, k-tile) of the next A / B load
-    const unsigned char* asrc[4];
-    const unsigned char* xsrc[4];
+    // Addresses are kept as UNIFORM 64-bit bases (SGPR pairs) plus 32-bit per-lane offsets (global_load's
+    // saddr + voffset form): one VGPR serves all four A loads and four serve B, instead of sixteen for eight 64-bit
+    // pointers -- the int8 variants sit at the 256-VGPR limit.
+    const unsigned char* abase[4];  // uniform: row (plane_i, tile query (64 i) % BMQ) of the tile's prepared queries
+    const unsigned char* xbase[4];  // uniform: corpus row r0 + 64 i (r0 if that is past the end)
+    const uint32_t a_loff = (uint32_t)sr * p.KPB + (uint32_t)sc * 16u;
+    uint32_t x_loff[4];
     auto set_a_tile = [&](uint32_t n) {
         uint32_t nt, mt;
         slot_tile(n, nt, mt);
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const int ar = sr + 64 * i;  // LDS A row: plane = ar / BMQ, query = ar % BMQ
-            asrc[i] = p.qprep + ((size_t)(ar / BMQ) * p.nq_pad + mt * BMQ + (ar % BMQ)) * p.KPB + sc * 16;
-        }
+        for (int i = 0; i < 4; i++)  // LDS A row sr + 64 i: plane = (64 i) / BMQ, query = sr + (64 i) % BMQ (sr < 64 | BMQ)
+            abase[i] = p.qprep + ((size_t)((64 * i) / BMQ) * p.nq_pad + mt * BMQ + (64 * i) % BMQ) * p.KPB;
     };
     auto set_b_tile = [&](uint32_t n) {
         uint32_t nt, mt;
@@ -160,30 +163,46 @@ __global__ void __launch_bounds__(512, 2) scan_mfma16_kernel(Batch16Params p) {
         const uint32_t r0 = p.row_begin + nt * BROWS;
 #pragma unroll
         for (int i = 0; i < 4; i++) {
-            const uint32_t r = r0 + sr + 64 * i;
-            xsrc[i] = p.rows + (size_t)(r < p.row_end ? r : 0u) * p.pitch;
+            const uint32_t rb_ = r0 + 64 * i;
+            xbase[i] = p.rows + (size_t)(rb_ < p.row_end ? rb_ : r0) * p.pitch;
+            x_loff[i] = rb_ + sr < p.row_end ? (uint32_t)sr * p.pitch : 0u;  // rows past the end re-read a valid row
         }
     };
     // ra: A k-tile one ahead of the LDS stage being computed (queries are L2-hot).  B k-tiles are loaded TWO
     // ahead into alternating sets rb0/rb1: these MFMAs retire a k-tile in ~1 us, less than an HBM round trip.
     u32x4 ra[4], rb0[4], rb1[4];
-    auto load_a = [&]() {
+    // The loads of one k-tile are issued in PARTS between the k-steps rather than in one lump, so the CU's
+    // vector-memory front end (~64 B/clk; 64 KB per k-tile) works underneath the MFMAs.
+    auto load_a_part = [&](int i0, int i1) {
 #pragma unroll
-        for (int i = 0; i < 4; i++) ra[i] = *reinterpret_cast<const u32x4*>(asrc[i] + (size_t)a_kt * BKB);
+        for (int i = i0; i < i1; i++) ra[i] = *reinterpret_cast<const u32x4*>(abase[i] + (size_t)a_kt * BKB + a_loff);
+    };
+    auto advance_a = [&]() {
         if (++a_kt == p.KT) {
             a_kt = 0;
             if (++a_n < my_tiles) set_a_tile(a_n);
         }
     };
-    auto load_b = [&](u32x4 (&rb)[4]) {
+    auto load_b_part = [&](u32x4 (&rb)[4], int i0, int i1) {
         const uint32_t v = b_kt * 8 + sc;
-        const size_t xoff = v < p.V ? (size_t)v * 16 : 0;
+        const uint32_t xoff = v < p.V ? v * 16u : 0u;
 #pragma unroll
-        for (int i = 0; i < 4; i++) rb[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(xsrc[i] + xoff));
+        for (int i = i0; i < i1; i++)
+            rb[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(xbase[i] + (x_loff[i] + xoff)));
+    };
+    auto advance_b = [&]() {
         if (++b_kt == p.KT) {
             b_kt = 0;
             if (++b_n < my_tiles) set_b_tile(b_n);
         }
+    };
+    auto load_a = [&]() {
+        load_a_part(0, 4);
+        advance_a();
+    };
+    auto load_b = [&](u32x4 (&rb)[4]) {
+        load_b_part(rb, 0, 4);
+        advance_b();
     };
     auto store_a = [&](int stage) {
         unsigned char* a = smem + stage * 2 * TILE_B;
@@ -222,16 +241,18 @@ __global__ void __launch_bounds__(512, 2) scan_mfma16_kernel(Batch16Params p) {
     load_b(rb0);
     store_a(0);
     store_b(0, 0, rb0);
-    if (G > 1) {
-        load_a();
-        load_b(rb1);
-    }
-    if (G > 2) load_b(rb0);
+    // Loads past the last k-tile are NOT branched around: the cursors stay on the block's last tile (valid memory)
+    // and the data is never stored to a stage that is read.  Uniform control flow is what lets the compiler count
+    // outstanding loads exactly; with `if (more)` around them it fell back to s_waitcnt vmcnt(0) before every load
+    // group, i.e. each group waited out the full latency of the previous one (in-kernel stamps: 25 % of a k-tile).
+    load_a();
+    load_b(rb1);
+    load_b(rb0);
     __syncthreads();
 
     const int fr = lane & 31, fh = lane >> 5;
     // one k-step (32 bytes of k): IT*2*PLANES MFMAs
-    auto kstep = [&](const unsigned char* a, const unsigned char* bb, int ks) {
+    auto kstep = [&](const unsigned char* a, const unsigned char* bb, int ks) __attribute__((always_inline)) {
         u32x4 fb[2];
 #pragma unroll
         for (int j = 0; j < 2; j++) fb[j] = *reinterpret_cast<const u32x4*>(bb + j * 32 * LDPB + ks * 32);
@@ -256,7 +277,7 @@ __global__ void __launch_bounds__(512, 2) scan_mfma16_kernel(Batch16Params p) {
     // ---- epilogue of one finished tile (C/D map: col = lane&31 -> corpus row, row = (e&3)+8*(e>>2)+4*(lane>>5) -> query)
     // Fast path: one or two ops + a compare per score against the per-query pre-filter; the exact key and the
     // atomic append run only for 32x32 tiles where the wave-wide ballot found a candidate (rare).
-    auto epilogue = [&](uint32_t nt, uint32_t mt) {
+    auto epilogue = [&](uint32_t nt, uint32_t mt) __attribute__((always_inline)) {
         const uint32_t q0 = mt * BMQ, r0 = p.row_begin + nt * BROWS;
         // keep this address arithmetic inside the epilogue (hoisted out of the k-tile loop it costs VGPRs there)
         int lane_q = wm * (BMQ / 2) + 4 * fh, lane_r = wn * 64 + fr;
@@ -282,37 +303,54 @@ __global__ void __launch_bounds__(512, 2) scan_mfma16_kernel(Batch16Params p) {
                 else if (U8) rx = xxu > 0 ? __builtin_amdgcn_rcpf(sqrtf((float)xxu)) : 0.0f;
                 else rx = xxi > 0 ? __builtin_amdgcn_rcpf(sqrtf((float)xxi)) : 0.0f;
             }
+            const unsigned long long rokmask = __builtin_amdgcn_ballot_w64(rok);
+            const int32_t nxxi = -xxi;
+            // pre-filter test of accumulator element (i, 4g+t) against its query's threshold
+            auto passes = [&](int i, int g, int t, const u32x4& th4, const u32x4& sc4) __attribute__((always_inline)) -> bool {
+                if constexpr (DT == MVF_DTYPE_FLOAT16) {
+                    const float y = METRIC == MVF_METRIC_COSINE ? acc[i][j][4 * g + t] * rx
+                                    : METRIC == MVF_METRIC_L2   ? fmaf(acc[i][j][4 * g + t], 2.0f * __uint_as_float(sc4[t]), -xxf)
+                                                                : acc[i][j][4 * g + t];
+                    return !(y < __uint_as_float(th4[t]));
+                } else if (METRIC == MVF_METRIC_INNER_PRODUCT) {
+                    return acc[i][j][4 * g + t] + bx >= (int32_t)th4[t];
+                } else if (METRIC == MVF_METRIC_L2) {
+                    return (acc[i][j][4 * g + t] << 1) + nxxi >= (int32_t)th4[t];
+                } else {
+                    return !((float)(acc[i][j][4 * g + t] + bx + (int32_t)sc4[t]) * rx < __uint_as_float(th4[t]));
+                }
+            };
+            auto load_thr = [&](int i, int g, u32x4& th4, u32x4& sc4) __attribute__((always_inline)) {
+                th4 = *reinterpret_cast<const u32x4*>(thr_s + lane_q + i * 32 + 8 * g);
+                sc4 = u32x4{0, 0, 0, 0};
+                if (DT == MVF_DTYPE_FLOAT16 && METRIC == MVF_METRIC_L2)
+                    sc4 = *reinterpret_cast<const u32x4*>(qa_s + lane_q + i * 32 + 8 * g);  // 2^-e per query
+                if (U8 && METRIC == MVF_METRIC_COSINE)
+                    sc4 = *reinterpret_cast<const u32x4*>(qb_s + lane_q + i * 32 + 8 * g);  // cqq per query
+            };
 #pragma unroll
             for (int i = 0; i < IT; i++) {
-                uint32_t m = 0;
+                // Wave-level test first: each compare lands in an SGPR pair and the OR runs on the scalar unit, so a
+                // score costs the compare (plus its one or two arithmetic ops) of vector work.  Per-lane masks are
+                // only built for the rare 32x32 sub-tiles where some lane passed.
+                unsigned long long any = 0;
 #pragma unroll
                 for (int g = 0; g < 4; g++) {
-                    const u32x4 th4 = *reinterpret_cast<const u32x4*>(thr_s + lane_q + i * 32 + 8 * g);
-                    u32x4 sc4 = u32x4{0, 0, 0, 0};
-                    if (DT == MVF_DTYPE_FLOAT16 && METRIC == MVF_METRIC_L2)
-                        sc4 = *reinterpret_cast<const u32x4*>(qa_s + lane_q + i * 32 + 8 * g);  // 2^-e per query
-                    if (U8 && METRIC == MVF_METRIC_COSINE)
-                        sc4 = *reinterpret_cast<const u32x4*>(qb_s + lane_q + i * 32 + 8 * g);  // cqq per query
+                    u32x4 th4, sc4;
+                    load_thr(i, g, th4, sc4);
 #pragma unroll
-                    for (int t = 0; t < 4; t++) {
-                        bool pass;
-                        if constexpr (DT == MVF_DTYPE_FLOAT16) {
-                            const float y = METRIC == MVF_METRIC_COSINE ? acc[i][j][4 * g + t] * rx
-                                            : METRIC == MVF_METRIC_L2   ? fmaf(acc[i][j][4 * g + t], 2.0f * __uint_as_float(sc4[t]), -xxf)
-                                                                        : acc[i][j][4 * g + t];
-                            pass = !(y < __uint_as_float(th4[t]));
-                        } else if (METRIC == MVF_METRIC_INNER_PRODUCT) {
-                            pass = acc[i][j][4 * g + t] + bx >= (int32_t)th4[t];
-                        } else if (METRIC == MVF_METRIC_L2) {
-                            pass = 2 * acc[i][j][4 * g + t] - xxi >= (int32_t)th4[t];
-                        } else {
-                            pass = !((float)(acc[i][j][4 * g + t] + bx + (int32_t)sc4[t]) * rx < __uint_as_float(th4[t]));
-                        }
-                        m |= (pass ? 1u : 0u) << (4 * g + t);
-                    }
+                    for (int t = 0; t < 4; t++) any |= __builtin_amdgcn_ballot_w64(passes(i, g, t, th4, sc4));
                 }
-                if (!rok) m = 0;
-                if (__builtin_amdgcn_ballot_w64(m != 0) != 0) {  // wave-uniform: rare
+                if ((any & rokmask) != 0) {  // wave-uniform: rare
+                    uint32_t m = 0;
+#pragma unroll
+                    for (int g = 0; g < 4; g++) {
+                        u32x4 th4, sc4;
+                        load_thr(i, g, th4, sc4);
+#pragma unroll
+                        for (int t = 0; t < 4; t++) m |= (passes(i, g, t, th4, sc4) ? 1u : 0u) << (4 * g + t);
+                    }
+                    if (!rok) m = 0;
 #pragma unroll
                     for (int e = 0; e < 16; e++) {
                         if (m & (1u << e)) {
@@ -355,22 +393,25 @@ __global__ void __launch_bounds__(512, 2) scan_mfma16_kernel(Batch16Params p) {
 
     // one flat k-tile g; rb holds B k-tile g+1 on entry and receives B k-tile g+3.  The LDS stores of k-tile g+1 and
     // the global loads ride between the four k-steps so the matrix pipe only drains at the one barrier per k-tile.
-    auto ktile = [&](uint32_t g, u32x4 (&rb)[4]) {
+    auto ktile = [&](uint32_t g, u32x4 (&rb)[4]) __attribute__((always_inline)) {
         const int cur = g & 1;
         const unsigned char* a = smem + cur * 2 * TILE_B + (wm * (BMQ / 2) + fr) * LDPB + fh * 16;
         const unsigned char* bb = smem + cur * 2 * TILE_B + TILE_B + (wn * 64 + fr) * LDPB + fh * 16;
-        const bool more = g + 1 < G;
         const uint32_t next_kt = c_kt + 1 == p.KT ? 0u : c_kt + 1;
         kstep(a, bb, 0);
         __builtin_amdgcn_sched_barrier(0);
-        if (more) store_a(cur ^ 1);
+        store_a(cur ^ 1);
+        store_b(cur ^ 1, next_kt, rb);
+        load_a_part(0, 3);
         kstep(a, bb, 1);
         __builtin_amdgcn_sched_barrier(0);
-        if (more) store_b(cur ^ 1, next_kt, rb);
+        load_a_part(3, 4);
+        load_b_part(rb, 0, 2);
         kstep(a, bb, 2);
         __builtin_amdgcn_sched_barrier(0);
-        if (g + 2 < G) load_a();
-        if (g + 3 < G) load_b(rb);
+        load_b_part(rb, 2, 4);
+        advance_a();
+        advance_b();
         kstep(a, bb, 3);
         __syncthreads();
         if (++c_kt == p.KT) {  // tile finished: the next tile's first k-tile is already in LDS, its loads in flight
@@ -389,10 +430,12 @@ __global__ void __launch_bounds__(512, 2) scan_mfma16_kernel(Batch16Params p) {
             }
         }
     };
-    for (uint32_t g = 0; g < G; g += 2) {
+    uint32_t g = 0;
+    for (; g + 1 < G; g += 2) {
         ktile(g, rb1);
-        if (g + 1 < G) ktile(g + 1, rb0);
+        ktile(g + 1, rb0);
     }
+    if (g < G) ktile(g, rb1);
 }
 
 // ---- query preparation ---------------------------------------------------------------
