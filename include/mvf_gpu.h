@@ -195,6 +195,21 @@ int mvfgpu_merge_topk_device(const float* d_scores, const uint64_t* d_indices,
                              float* d_out_scores, uint64_t* d_out_indices,
                              int32_t* d_out_raw, int device, void* hip_stream);
 
+/*
+ * The same merge over PACKED lists, the form one all-gather delivers: shard l's
+ * list occupies MVFGPU_PACKED_LIST_BYTES(nq, k) bytes at d_packed + l * that,
+ * laid out { uint64 indices[nq*k]; float scores[nq*k]; int32 raw[nq*k] }.
+ * A rank points mvfgpu_search_device's three outputs into its own list and
+ * exchanges it with ONE collective instead of three (the exchange is
+ * latency-bound: 16 bytes per result).  d_packed must be 8-byte aligned.
+ */
+#define MVFGPU_PACKED_LIST_BYTES(nq, k) ((size_t)16 * (size_t)(nq) * (size_t)(k))
+int mvfgpu_merge_topk_packed_device(const void* d_packed, uint32_t nlists,
+                                    uint32_t nq, uint32_t k, uint8_t metric,
+                                    uint8_t data_type, float* d_out_scores,
+                                    uint64_t* d_out_indices, int32_t* d_out_raw,
+                                    int device, void* hip_stream);
+
 /* ---- utilities ----------------------------------------------------------- */
 
 /* Fill a device buffer [nq][dimension] with synthetic queries (query dtype of

@@ -73,13 +73,15 @@ def gpu() -> C.CDLL:
     lib.mvfgpu_search_device.argtypes = [vp, u8, vp, u8, u32, u32, u32, vp, vp, vp, vp]
     lib.mvfgpu_merge_topk_host.argtypes = [vp, vp, vp, u32, u32, u32, u8, u8, vp, vp, vp]
     lib.mvfgpu_merge_topk_device.argtypes = [vp, vp, vp, u32, u32, u32, u8, u8, vp, vp, vp, i32, vp]
+    lib.mvfgpu_merge_topk_packed_device.argtypes = [vp, u32, u32, u32, u8, u8, vp, vp, vp, i32, vp]
     lib.mvfgpu_synth_queries_device.argtypes = [vp, u32, u32, u8, u64, i32, vp]
     lib.mvfgpu_set_profiling.argtypes = [vp, i32]
     lib.mvfgpu_last_timing.argtypes = [vp, C.POINTER(Timing)]
     lib.mvfgpu_set_scan_path.argtypes = [vp, i32]
     for name in ("mvfgpu_device_count", "mvfgpu_corpus_create", "mvfgpu_corpus_create_synthetic",
                  "mvfgpu_corpus_get_info", "mvfgpu_corpus_read_rows", "mvfgpu_corpus_gather_rows", "mvfgpu_search", "mvfgpu_search_device",
-                 "mvfgpu_merge_topk_host", "mvfgpu_merge_topk_device", "mvfgpu_synth_queries_device",
+                 "mvfgpu_merge_topk_host", "mvfgpu_merge_topk_device", "mvfgpu_merge_topk_packed_device",
+                 "mvfgpu_synth_queries_device",
                  "mvfgpu_set_profiling", "mvfgpu_last_timing", "mvfgpu_set_scan_path"):
         getattr(lib, name).restype = C.c_int
     _gpu = lib

@@ -808,21 +808,26 @@ int mvfgpu_merge_topk_host(const float* scores, const uint64_t* indices, const i
     return MVF_OK;
 }
 
-int mvfgpu_merge_topk_device(const float* d_scores, const uint64_t* d_indices, const int32_t* d_raw, uint32_t nlists,
-                             uint32_t nq, uint32_t k, uint8_t metric, uint8_t data_type, float* d_out_scores,
-                             uint64_t* d_out_indices, int32_t* d_out_raw, int device, void* hip_stream) {
+namespace {
+int merge_topk_device_impl(const float* d_scores, const uint64_t* d_indices, const int32_t* d_raw, size_t ls_scores,
+                           size_t ls_indices, size_t ls_raw, uint32_t nlists, uint32_t nq, uint32_t k, uint8_t metric,
+                           uint8_t data_type, float* d_out_scores, uint64_t* d_out_indices, int32_t* d_out_raw, int device,
+                           void* hip_stream) {
     if (!d_scores || !d_indices || !d_out_scores || !d_out_indices) return fail(MVF_ERR_INVALID_ARGUMENT, "NULL buffer");
     if (metric != MVF_METRIC_L2 && metric != MVF_METRIC_INNER_PRODUCT && metric != MVF_METRIC_COSINE)
         return fail(MVF_ERR_INVALID_ARGUMENT, "unsupported distance metric code");
     if (nlists == 0 || nq == 0 || k == 0) return fail(MVF_ERR_INVALID_ARGUMENT, "nlists, nq and k must be > 0");
+    if ((uint64_t)nlists * k > kMergeMaxEntries) return fail(MVF_ERR_INVALID_ARGUMENT, "nlists * k exceeds 8192");
     const uint32_t P = next_pow2(std::max(2u, nlists * k));
-    if (P > kMergeMaxEntries) return fail(MVF_ERR_INVALID_ARGUMENT, "nlists * k exceeds 8192");
     DeviceGuard guard(device);
     if (!guard.ok) return fail(MVF_ERR_DEVICE, "hipSetDevice failed");
     ShardMergeParams p{};
     p.scores = d_scores;
     p.indices = d_indices;
     p.raw = d_raw;
+    p.ls_scores = ls_scores;
+    p.ls_indices = ls_indices;
+    p.ls_raw = ls_raw;
     p.nlists = nlists;
     p.nq = nq;
     p.k = k;
@@ -834,6 +839,28 @@ int mvfgpu_merge_topk_device(const float* d_scores, const uint64_t* d_indices, c
     p.out_raw = d_out_raw;
     HIP_TRY(launch_merge_shards(p, static_cast<hipStream_t>(hip_stream)));
     return MVF_OK;
+}
+}  // namespace
+
+int mvfgpu_merge_topk_device(const float* d_scores, const uint64_t* d_indices, const int32_t* d_raw, uint32_t nlists,
+                             uint32_t nq, uint32_t k, uint8_t metric, uint8_t data_type, float* d_out_scores,
+                             uint64_t* d_out_indices, int32_t* d_out_raw, int device, void* hip_stream) {
+    const size_t ls = (size_t)nq * k;
+    return merge_topk_device_impl(d_scores, d_indices, d_raw, ls, ls, ls, nlists, nq, k, metric, data_type, d_out_scores,
+                                  d_out_indices, d_out_raw, device, hip_stream);
+}
+
+int mvfgpu_merge_topk_packed_device(const void* d_packed, uint32_t nlists, uint32_t nq, uint32_t k, uint8_t metric,
+                                    uint8_t data_type, float* d_out_scores, uint64_t* d_out_indices, int32_t* d_out_raw,
+                                    int device, void* hip_stream) {
+    if (!d_packed) return fail(MVF_ERR_INVALID_ARGUMENT, "NULL buffer");
+    if ((reinterpret_cast<uintptr_t>(d_packed) & 7u) != 0) return fail(MVF_ERR_INVALID_ARGUMENT, "packed lists must be 8-byte aligned");
+    // one list = { u64 indices[nq k]; f32 scores[nq k]; i32 raw[nq k] } = 16 nq k bytes (MVFGPU_PACKED_LIST_BYTES)
+    const size_t n = (size_t)nq * k;
+    const unsigned char* b = static_cast<const unsigned char*>(d_packed);
+    return merge_topk_device_impl(reinterpret_cast<const float*>(b + 8 * n), reinterpret_cast<const uint64_t*>(b),
+                                  reinterpret_cast<const int32_t*>(b + 12 * n), 4 * n, 2 * n, 4 * n, nlists, nq, k, metric,
+                                  data_type, d_out_scores, d_out_indices, d_out_raw, device, hip_stream);
 }
 
 int mvfgpu_synth_queries_device(void* d_queries, uint32_t nq, uint32_t dimension, uint8_t data_type, uint64_t seed,

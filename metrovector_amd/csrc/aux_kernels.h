@@ -21,9 +21,10 @@ struct SelectParams {
 };
 
 struct ShardMergeParams {
-    const float* scores;      // [nlists][nq][k]
-    const uint64_t* indices;
-    const int32_t* raw;       // nullable
+    const float* scores;      // list l, query q, rank j at [l * ls_scores + q * k + j]
+    const uint64_t* indices;  //                           [l * ls_indices + q * k + j]
+    const int32_t* raw;       // nullable                  [l * ls_raw + q * k + j]
+    size_t ls_scores, ls_indices, ls_raw;  // list strides in ELEMENTS (nq * k each for three separate arrays)
     uint32_t nlists, nq, k, P;
     uint8_t metric, dtype;
     float* out_scores;        // [nq][k]

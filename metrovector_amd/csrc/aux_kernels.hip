@@ -121,9 +121,12 @@ __global__ void __launch_bounds__(256) merge_shards_kernel(ShardMergeParams p) {
         uint32_t ky = kNanKey, sl = 0;
         if (i < total) {
             const uint32_t l = i / p.k, j = i % p.k;
-            sl = (l * p.nq + q) * p.k + j;
-            id = p.indices[sl];
-            if (id != ~0ull) ky = use_raw ? key_from_raw(p.raw[sl], p.metric) : key_from_score(p.scores[sl], p.metric);
+            const size_t rem = (size_t)q * p.k + j;
+            sl = i;  // (list, rank) of the entry; the arrays are addressed through their own list strides
+            id = p.indices[l * p.ls_indices + rem];
+            if (id != ~0ull)
+                ky = use_raw ? key_from_raw(p.raw[l * p.ls_raw + rem], p.metric)
+                             : key_from_score(p.scores[l * p.ls_scores + rem], p.metric);
         }
         idx[i] = id;
         key[i] = ky;
@@ -155,9 +158,11 @@ __global__ void __launch_bounds__(256) merge_shards_kernel(ShardMergeParams p) {
             p.out_indices[o] = ~0ull;
             if (p.out_raw) p.out_raw[o] = 0;
         } else {
-            p.out_scores[o] = p.scores[slot[i]];
+            const uint32_t l = slot[i] / p.k, j = slot[i] % p.k;
+            const size_t rem = (size_t)q * p.k + j;
+            p.out_scores[o] = p.scores[l * p.ls_scores + rem];
             p.out_indices[o] = idx[i];
-            if (p.out_raw) p.out_raw[o] = p.raw ? p.raw[slot[i]] : 0;
+            if (p.out_raw) p.out_raw[o] = p.raw ? p.raw[l * p.ls_raw + rem] : 0;
         }
     }
 }

@@ -4,10 +4,11 @@ process per GPU, `torch.distributed` (backend "nccl" = RCCL over xGMI).
 The reference has no distributed code; this is the multi-GPU
 form of its scan (examples/similarity_search.rs:140-176): GPU g holds rows
 [g*ceil(N/G), min(N,(g+1)*ceil(N/G))) and searches them with global indices;
-the only exchange step is one all-gather of the per-shard top-k lists
-(nq*k entries per rank — latency-bound, ~1 MB at nq=1024,k=100), after which
-every rank merges G sorted lists:  merge(top-k per shard) == top-k(global),
-because selection is by a total order (score key, global index).
+the only exchange step is ONE all-gather of the per-shard top-k lists, packed
+as {u64 indices | f32 scores | i32 raw} = 16 bytes per result (nq*k results per
+rank — latency-bound, 1.6 MB at nq=1024,k=100), after which every rank merges
+G sorted lists:  merge(top-k per shard) == top-k(global), because selection
+is by a total order (score key, global index).
 
 torch is plumbing here (device buffers, streams, the collective); the scan
 and the merge run in libmvf_gpu.so.
@@ -47,13 +48,17 @@ def _all_gather(t, group):
 
 
 class ShardedSearcher:
-    """GPU path: local `mvfgpu_search_device` -> RCCL all-gather -> `mvfgpu_merge_topk_device`,
-    all on torch's current stream; results stay on the device."""
+    """GPU path: local `mvfgpu_search_device` -> one RCCL all-gather of the packed list ->
+    `mvfgpu_merge_topk_packed_device`, all on torch's current stream; results stay on the device.
 
-    def __init__(self, corpus: GpuCorpus, group=None):
+    always_exchange=True runs the collective and the merge at world size 1 as well (a 1-rank RCCL group):
+    it exists so the exchange path can be exercised on a single GPU."""
+
+    def __init__(self, corpus: GpuCorpus, group=None, always_exchange: bool = False):
         import torch
         self.corpus = corpus
         self.group = group
+        self.always_exchange = always_exchange
         inf = corpus.info()
         self.dtype = inf.data_type
         self.dim = inf.dimension
@@ -65,9 +70,14 @@ class ShardedSearcher:
         key = (nq, k, world)
         if key not in self._bufs:
             d = self.device
+            n = nq * k
+            # this rank's list in the packed layout of include/mvf_gpu.h (MVFGPU_PACKED_LIST_BYTES): int64 words
+            # [0, n) = indices, then n f32 scores, then n i32 raw; the three search outputs are views into it
+            mine = torch.empty(2 * n, dtype=torch.int64, device=d)
+            tail = mine[n:].view(torch.int32)
             self._bufs[key] = dict(
-                s=torch.empty((nq, k), dtype=torch.float32, device=d), i=torch.empty((nq, k), dtype=torch.int64, device=d),
-                r=torch.empty((nq, k), dtype=torch.int32, device=d),
+                mine=mine, i=mine[:n].view(nq, k), s=tail[:n].view(torch.float32).view(nq, k), r=tail[n:].view(nq, k),
+                all=torch.empty(world * 2 * n, dtype=torch.int64, device=d),
                 os=torch.empty((nq, k), dtype=torch.float32, device=d), oi=torch.empty((nq, k), dtype=torch.int64, device=d),
                 orr=torch.empty((nq, k), dtype=torch.int32, device=d))
         return self._bufs[key]
@@ -84,17 +94,18 @@ class ShardedSearcher:
         stream = torch.cuda.current_stream(self.device).cuda_stream
         self.corpus.search_device(d_queries.data_ptr(), query_dtype_code(self.dtype), d_queries.shape[1], nq, k, metric,
                                   b["s"].data_ptr(), b["i"].data_ptr(), b["r"].data_ptr(), stream)
-        if world == 1:
+        if world == 1 and not (self.always_exchange and dist.is_initialized()):
             return b["s"], b["i"], b["r"]
-        use_raw = self.dtype in (2, 3) and metric != 2
-        gs, w1 = _all_gather(b["s"], self.group)
-        gi, w2 = _all_gather(b["i"], self.group)
-        gr, w3 = _all_gather(b["r"], self.group) if use_raw else (None, None)
-        for w in (w1, w2, w3):
-            if w is not None:
-                w.wait()
-        _lib.gpu_check(_lib.gpu().mvfgpu_merge_topk_device(
-            gs.data_ptr(), gi.data_ptr(), gr.data_ptr() if gr is not None else None, world, nq, k, metric, self.dtype,
+        if dist.get_backend(self.group) == "gloo":
+            # rehearsal only (several ranks sharing one GPU, where RCCL refuses duplicate devices):
+            # stage the list through the host; the production backend is nccl (= RCCL)
+            host = torch.empty(b["all"].numel(), dtype=torch.int64)
+            dist.all_gather_into_tensor(host, b["mine"].cpu(), group=self.group)
+            b["all"].copy_(host)
+        else:
+            dist.all_gather_into_tensor(b["all"], b["mine"], group=self.group)  # enqueued on the current stream
+        _lib.gpu_check(_lib.gpu().mvfgpu_merge_topk_packed_device(
+            b["all"].data_ptr(), world, nq, k, metric, self.dtype,
             b["os"].data_ptr(), b["oi"].data_ptr(), b["orr"].data_ptr(), self.device.index or 0, C.c_void_p(stream)))
         return b["os"], b["oi"], b["orr"]
 

@@ -235,6 +235,19 @@ def test_device_pointer_api_and_shard_merge_device(oracle):
         # host merge of the same per-shard lists agrees with the device merge
         hm = G.merge_topk_host(S.cpu().numpy(), I.cpu().numpy().view(np.uint64), R.cpu().numpy(), metric, dtype)
         assert (hm.indices == gi).all()
+        # the same lists in the packed all-gather layout {u64 indices | f32 scores | i32 raw} per shard
+        nk = nq * k
+        packed = torch.empty((3, 2 * nk), dtype=torch.int64, device="cuda")
+        for j in range(3):
+            packed[j, :nk] = I[j].reshape(-1)
+            tail = packed[j, nk:].view(torch.int32)
+            tail[:nk] = S[j].reshape(-1).view(torch.int32)
+            tail[nk:] = R[j].reshape(-1)
+        PS, PI, PR = torch.empty_like(OS), torch.empty_like(OI), torch.empty_like(OR)
+        _lib.gpu_check(_lib.gpu().mvfgpu_merge_topk_packed_device(packed.data_ptr(), 3, nq, k, metric, dtype, PS.data_ptr(),
+                                                                  PI.data_ptr(), PR.data_ptr(), 0, C.c_void_p(stream)))
+        torch.cuda.synchronize()
+        assert torch.equal(PI, OI) and torch.equal(PS.view(torch.int32), OS.view(torch.int32)) and torch.equal(PR, OR)
 
 
 def test_concurrent_searches_on_one_handle(oracle):
@@ -404,6 +417,43 @@ print("rank", rank, "ok")
                          capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
     assert out.stdout.count("ok") == 2
+
+
+def test_sharded_searcher_exchange_on_rccl_single_rank(oracle, tmp_path):
+    """The exchange step on the PRODUCTION backend: a 1-rank nccl (= RCCL) group with always_exchange=True runs
+    search_device -> all_gather_into_tensor (RCCL, packed list) -> merge_topk_packed_device on cuda:0.
+    (More than one rank per GPU is refused by RCCL; the 2-rank rehearsal above stages through gloo.)"""
+    import subprocess
+    import sys
+    script = tmp_path / "rank.py"
+    script.write_text('''
+import os, sys, numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, %r)
+from metrovector_amd import gpu as G
+from metrovector_amd.sharded import ShardedSearcher
+from oracle import mvf_oracle as O
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+for dtype, metric, nq in ((0, 2, 1), (2, 1, 6), (1, 0, 40)):
+    n, dim, k = 20011, 64, 33
+    c = G.GpuCorpus.synthetic(n, dim, dtype, 777, device=0)
+    q = O.synth_queries(778, nq, dim, dtype)
+    tq = torch.from_numpy(q.copy()).cuda()
+    plain = [t.clone() for t in ShardedSearcher(c).search(tq, k, metric)]
+    ex = ShardedSearcher(c, always_exchange=True)
+    for _ in range(3):   # repeated searches reuse the packed buffers
+        got = ex.search(tq, k, metric)
+    torch.cuda.synchronize()
+    for a, b in zip(plain, got):
+        assert torch.equal(a.view(torch.int32) if a.dtype == torch.float32 else a, b.view(torch.int32) if b.dtype == torch.float32 else b)
+    c.close()
+dist.destroy_process_group()
+print("rccl ok")
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29741", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    out = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    assert "rccl ok" in out.stdout
 
 
 # ---------------------------------------------------------------------------
