@@ -277,7 +277,7 @@ int search_batched_path(const mvfgpu_corpus* c, uint8_t metric, const void* d_qu
     const uint32_t qpb = wide ? 128u : scan_mfma16_queries_per_block(c->dtype);
     const uint32_t KT = wide ? (c->dim + 31u) / 32u : (c->dim * elem_size(c->dtype) + 127u) / 128u;
     const uint32_t KPB = KT * 128u;                        // prepared query row, bytes (both layouts use 128-B k-tiles)
-    const uint32_t planes = c->dtype == MVF_DTYPE_FLOAT16 ? 2u : 1u;
+    const uint32_t planes = 1u;
     const uint32_t cap = kBatchCap;
     const uint32_t n = (uint32_t)c->n;
 
@@ -296,8 +296,10 @@ int search_batched_path(const mvfgpu_corpus* c, uint8_t metric, const void* d_qu
     uint32_t* overflow = cnt + c->bstate_slots;
     HIP_TRY(c->bcand.reserve((size_t)nq_pad * cap * 8));
     const bool is_float = !is_int_dtype(c->dtype);
-    const bool float_l2 = is_float && metric == MVF_METRIC_L2;
-    const bool need_norms = metric != MVF_METRIC_INNER_PRODUCT || c->dtype == MVF_DTYPE_UINT8;
+    // approximate selection + exact re-scoring: float L2 (GEMM-form distances) and every metric on Float16 rows
+    // (single f16 query plane); the other combinations carry final keys through the phases
+    const bool approx = is_float && (metric == MVF_METRIC_L2 || c->dtype == MVF_DTYPE_FLOAT16);
+    const bool need_norms = approx || metric != MVF_METRIC_INNER_PRODUCT || c->dtype == MVF_DTYPE_UINT8;
     // K4 buffer: float rows: |x| [n], sum x^2 [n], max sum x^2 [1]; Int8 rows: sum x^2 (i32) [n];
     // UInt8 rows: sum (x-128)^2 [n], 128 * sum (x-128) [n]
     const size_t nn = std::max<uint32_t>(n, 1);
@@ -373,8 +375,11 @@ int search_batched_path(const mvfgpu_corpus* c, uint8_t metric, const void* d_qu
     cp.out_raw = d_raw;
     cp.qnorm = wide ? qaux0 : qaux1;  // |q| (f32 path: qnorm; f16 path: second aux array)
     cp.xxmax = xxmax;
-    // bound of |GEMM-form - exact| squared distance relative to (qq + xx): f32 dot of `dim` terms plus the two norms
+    // bound of the approximate score's error in units of (qq + xx) [L2], 1 [cosine], |q||x| [inner product]:
+    // f32 accumulation of `dim` terms plus the norms, and on Float16 rows the query's rounding to f16 (2^-11 per
+    // element, relative; elements that land in the f16 subnormals add < 2^-39 of it)
     cp.eps = (float)(std::max<uint32_t>(c->dim, 64) + 16) * 1.1920929e-7f;
+    if (c->dtype == MVF_DTYPE_FLOAT16) cp.eps += 4.8828125e-4f * 1.001f;
 
     mvfgpu_timing tm{};
     tm.scan_kernel = 2;
@@ -407,13 +412,13 @@ int search_batched_path(const mvfgpu_corpus* c, uint8_t metric, const void* d_qu
             }
             tm.scan_launches++;
         }
-        if (float_l2) HIP_TRY(launch_compact_l2(cp, nq, s));
+        if (approx) HIP_TRY(launch_compact_margin(cp, nq, s));
         else HIP_TRY(launch_compact(cp, nq, last, s));
         if (last) break;
         begin = end;
         end = std::min<uint64_t>(n, ((end * g + 255) / 256) * 256);
     }
-    if (float_l2) {  // exact (q-x)^2 distances of the kept candidates, final top-k
+    if (approx) {  // exact scores of the kept candidates from the caller's f32 queries, final top-k
         RescoreParams rp{};
         rp.cand = bp.cand;
         rp.cnt = cnt;
@@ -429,7 +434,7 @@ int search_batched_path(const mvfgpu_corpus* c, uint8_t metric, const void* d_qu
         rp.out_scores = d_scores;
         rp.out_indices = d_indices;
         rp.out_raw = d_raw;
-        HIP_TRY(launch_rescore_l2(rp, nq, s));
+        HIP_TRY(launch_rescore(rp, metric, nq, s));
     }
     if (ps) {
         HIP_TRY(hipEventRecord(ps->e[2], s));
@@ -463,7 +468,8 @@ bool use_batched_path(const mvfgpu_corpus* c, uint8_t metric, uint32_t nq) {
     // Float32 / Float16: every metric (L2 = GEMM-form selection with an error margin + exact re-scoring);
     // Int8 / UInt8: every metric, exact integers (UInt8 rides the signed MFMA shifted by 128).
     bool supported = true;
-    if (metric == MVF_METRIC_L2 && !is_int_dtype(c->dtype) && (size_t)((c->dim + 7u) & ~7u) * 4 + kBatchCap * 4 > 64 * 1024)
+    if ((metric == MVF_METRIC_L2 || c->dtype == MVF_DTYPE_FLOAT16) && !is_int_dtype(c->dtype) &&
+        (size_t)((c->dim + 7u) & ~7u) * 4 + kBatchCap * 4 > 64 * 1024)
         supported = false;  // the re-scoring kernel keeps the query in LDS
     if (!supported) return false;
     return c->scan_path == 2 || nq >= 32;

@@ -55,10 +55,11 @@ struct CompactParams {
     uint32_t* tau;
     uint32_t* overflow;
     uint32_t cap, k;
-    // float L2 on the batched path: keys are the GEMM-form squared distance qq + xx - 2 dot, whose error is
-    // bounded by eps * (qq + xxmax); the compaction keeps everything within 2x that of the k-th value
+    // approximate selection (float L2; every metric on Float16 rows): keys carry a score whose error is bounded by
+    // eps * (qq + xxmax) [L2], eps [cosine], eps * |q| * sqrt(xxmax) [inner product]; the compaction keeps everything
+    // within 2x that of the k-th value (compact_margin_kernel)
     const float* qnorm;   // [nq] |q|
-    const float* xxmax;   // [1]
+    const float* xxmax;   // [1] max over rows of sum x^2
     float eps;
     // final stage only
     uint8_t metric, dtype;
@@ -78,7 +79,7 @@ hipError_t launch_row_norms_f32(const unsigned char* rows, uint32_t n, uint32_t 
                                 float* xxmax, hipStream_t s);
 hipError_t launch_compact(const CompactParams& p, uint32_t nq, bool final_stage, hipStream_t s);
 
-// batched float L2: margin-aware compaction + exact re-scoring of the kept candidates
+// approximate selection: margin-aware compaction + exact re-scoring of the kept candidates
 struct RescoreParams {
     const uint64_t* cand;       // [nq][cap] sorted approximate composites, first cnt[q] valid
     uint32_t* cnt;              // re-armed to 0
@@ -93,8 +94,8 @@ struct RescoreParams {
     uint64_t* out_indices;
     int32_t* out_raw;
 };
-hipError_t launch_compact_l2(const CompactParams& p, uint32_t nq, hipStream_t s);
-hipError_t launch_rescore_l2(const RescoreParams& p, uint32_t nq, hipStream_t s);
+hipError_t launch_compact_margin(const CompactParams& p, uint32_t nq, hipStream_t s);
+hipError_t launch_rescore(const RescoreParams& p, int metric, uint32_t nq, hipStream_t s);
 
 uint32_t scan_mfma16_queries_per_block(int dtype);
 hipError_t launch_scan_mfma16(const Batch16Params& p, int dtype, int metric, int num_cus, hipStream_t s);

@@ -416,11 +416,16 @@ __global__ void __launch_bounds__(1024) compact_kernel(CompactParams p) {
     }
 }
 
-// ---- batched float L2: margin-aware compaction -------------------------------------------------------------
-// Keys are ord(s2~), s2~ = qq + xx - 2 dot with |s2~ - s2| <= delta = eps * (qq + xxmax).  With v_k the k-th
-// smallest s2~ seen, the true k-th best exact value is <= v_k + delta, and every true top-k row has
-// s2~ <= v_k + 2 delta: keep all of those (not just k), publish tau = ord(v_k + 2 delta).
-__global__ void __launch_bounds__(1024) compact_l2_kernel(CompactParams p) {
+// ---- approximate selection: margin-aware compaction ---------------------------------------------------------
+// Keys are ord(s~) of an APPROXIMATE score with a proven bound |s~ - s| <= delta:
+//   float L2 (f32 and f16 rows): s~ = qq + xx - 2 dot (GEMM form),   delta = eps * (qq + xxmax)
+//   f16 rows, cosine:            s~ = dot~ / (|q| |x|),              delta = eps
+//   f16 rows, inner product:     s~ = dot~,                          delta = eps * |q| * sqrt(xxmax)
+// (f16 rows use ONE f16 query plane: |dot~ - dot| <= 2^-11 |q||x| by Cauchy-Schwarz, plus the f32 accumulation.)
+// With v_k the k-th best s~ seen, the true k-th best exact value is no worse than v_k -/+ delta, so every true
+// top-k row has s~ within 2 delta of v_k: keep all of those (not just k) and publish tau = ord(v_k -/+ 2 delta).
+// The kept rows are re-scored exactly at the end (rescore_kernel).
+__global__ void __launch_bounds__(1024) compact_margin_kernel(CompactParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint64_t* buf = reinterpret_cast<uint64_t*>(smem);
     __shared__ uint32_t keep_s;
@@ -436,10 +441,13 @@ __global__ void __launch_bounds__(1024) compact_l2_kernel(CompactParams p) {
     bitonic_sort_u64<1024>(buf, P2, tid);
     uint32_t tkey = kNanKey;
     if (m >= p.k) {
-        const float vk = score_from_key((uint32_t)(buf[p.k - 1] >> 32), MVF_METRIC_L2);
+        const float vk = score_from_key((uint32_t)(buf[p.k - 1] >> 32), p.metric);
         const float qn = p.qnorm[q];
-        const float thr = vk + 2.0f * p.eps * (qn * qn + p.xxmax[0]);
-        tkey = key_from_score(thr, MVF_METRIC_L2);
+        float thr;
+        if (p.metric == MVF_METRIC_L2) thr = vk + 2.0f * p.eps * (qn * qn + p.xxmax[0]);
+        else if (p.metric == MVF_METRIC_COSINE) thr = vk - 2.0f * p.eps;
+        else thr = vk - 2.0f * p.eps * qn * sqrtf(p.xxmax[0]);
+        tkey = key_from_score(thr, p.metric);
         if (tkey != kNanKey)
             for (uint32_t i = p.k - 1 + tid; i < m; i += 1024)
                 if ((uint32_t)(buf[i] >> 32) <= tkey && (i + 1 == m || (uint32_t)(buf[i + 1] >> 32) > tkey)) keep_s = i + 1;
@@ -460,48 +468,72 @@ __global__ void __launch_bounds__(1024) compact_l2_kernel(CompactParams p) {
     }
 }
 
-// ---- batched float L2: exact re-scoring of the kept candidates + final top-k ---------------------------------
-// grid (nq); block 256 (4 waves); LDS: query f32[dim4] + composites[cap/2].  One wave per candidate row:
-// sum (q - x)^2 in f32 (fmaf, lane-strided + butterfly, like K1), sqrt, order key.
-__global__ void __launch_bounds__(256) rescore_l2_kernel(RescoreParams p) {
+// ---- exact re-scoring of the kept candidates, final top-k ------------------------------------------------------
+// One block per query, one wave per candidate row: the score is recomputed from the caller's f32 query and the
+// stored row with K1's formulas (sqrt(sum (q-x)^2); sum q x; sum q x / (sqrt(qq) sqrt(xx))).
+template <int METRIC>
+__global__ void __launch_bounds__(256) rescore_kernel(RescoreParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t dim4 = (p.dim + 7u) & ~7u;  // zero-padded to a multiple of 8 (one f16 vector)
     float* qs = reinterpret_cast<float*>(smem);
     uint64_t* buf = reinterpret_cast<uint64_t*>(qs + dim4);
+    __shared__ float qq_part[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t q = blockIdx.x;
     const uint32_t keep_cap = p.cap / 2;
     const uint32_t m = min(p.cnt[q], keep_cap);
-    for (uint32_t e = tid; e < dim4; e += 256) qs[e] = e < p.dim ? p.queries[(size_t)q * p.dim + e] : 0.f;
+    float qq = 0.f;
+    for (uint32_t e = tid; e < dim4; e += 256) {
+        const float v = e < p.dim ? p.queries[(size_t)q * p.dim + e] : 0.f;
+        qs[e] = v;
+        qq = fmaf(v, v, qq);
+    }
+    if (METRIC == MVF_METRIC_COSINE) {
+        for (int off = 32; off > 0; off >>= 1) qq += __shfl_xor(qq, off, 64);
+        if (lane == 0) qq_part[wave] = qq;
+    }
     __syncthreads();
+    if (METRIC == MVF_METRIC_COSINE) qq = (qq_part[0] + qq_part[1]) + (qq_part[2] + qq_part[3]);
     const uint64_t* c = p.cand + (size_t)q * p.cap;
     const uint32_t V = p.pitch / 16;
     for (uint32_t ci = wave; ci < m; ci += 4) {
         const uint32_t r = (uint32_t)c[ci];
         const unsigned char* rp = p.rows + (size_t)r * p.pitch;
-        float s = 0.f;
+        float s = 0.f, xx = 0.f;
+        auto term = [&](float qv, float xv) __attribute__((always_inline)) {
+            if (METRIC == MVF_METRIC_L2) {
+                const float t = qv - xv;
+                s = fmaf(t, t, s);
+            } else {
+                s = fmaf(qv, xv, s);
+                if (METRIC == MVF_METRIC_COSINE) xx = fmaf(xv, xv, xx);
+            }
+        };
         for (uint32_t v = lane; v < V; v += 64) {
             const u32x4 x = *reinterpret_cast<const u32x4*>(rp + (size_t)v * 16);
             if (p.dtype == MVF_DTYPE_FLOAT32) {
                 const f32x4 qv = *reinterpret_cast<const f32x4*>(qs + v * 4);
 #pragma unroll
-                for (int w = 0; w < 4; w++) {
-                    const float t = qv[w] - __uint_as_float(x[w]);
-                    s = fmaf(t, t, s);
-                }
+                for (int w = 0; w < 4; w++) term(qv[w], __uint_as_float(x[w]));
             } else {
 #pragma unroll
                 for (int w = 0; w < 4; w++) {
-                    const float x0 = __half2float(__ushort_as_half((unsigned short)(x[w] & 0xFFFFu)));
-                    const float x1 = __half2float(__ushort_as_half((unsigned short)(x[w] >> 16)));
-                    const float t0 = qs[v * 8 + 2 * w] - x0, t1 = qs[v * 8 + 2 * w + 1] - x1;
-                    s = fmaf(t0, t0, s);
-                    s = fmaf(t1, t1, s);
+                    term(qs[v * 8 + 2 * w], __half2float(__ushort_as_half((unsigned short)(x[w] & 0xFFFFu))));
+                    term(qs[v * 8 + 2 * w + 1], __half2float(__ushort_as_half((unsigned short)(x[w] >> 16))));
                 }
             }
         }
-        for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
-        if (lane == 0) buf[ci] = ((uint64_t)key_from_score(sqrtf(s), MVF_METRIC_L2) << 32) | r;
+        for (int off = 32; off > 0; off >>= 1) {
+            s += __shfl_xor(s, off, 64);
+            if (METRIC == MVF_METRIC_COSINE) xx += __shfl_xor(xx, off, 64);
+        }
+        float sc = s;
+        if (METRIC == MVF_METRIC_L2) sc = sqrtf(s);
+        if (METRIC == MVF_METRIC_COSINE) {
+            const float den = sqrtf(qq) * sqrtf(xx);
+            sc = den > 0.0f ? s / den : 0.0f;
+        }
+        if (lane == 0) buf[ci] = ((uint64_t)key_from_score(sc, METRIC) << 32) | r;
     }
     const uint32_t P2 = next_pow2(m < 2 ? 2 : m);
     for (uint32_t i = m + tid; i < P2; i += 256) buf[i] = kPadComposite;
@@ -511,10 +543,10 @@ __global__ void __launch_bounds__(256) rescore_l2_kernel(RescoreParams p) {
         const uint32_t o = q * p.k + i;
         const uint64_t comp = i < m ? buf[i] : kPadComposite;
         if (comp == kPadComposite) {
-            p.out_scores[o] = pad_score(MVF_METRIC_L2);
+            p.out_scores[o] = pad_score(METRIC);
             p.out_indices[o] = ~0ull;
         } else {
-            p.out_scores[o] = score_from_key((uint32_t)(comp >> 32), MVF_METRIC_L2);
+            p.out_scores[o] = score_from_key((uint32_t)(comp >> 32), METRIC);
             p.out_indices[o] = p.index_base + (uint32_t)comp;
         }
         if (p.out_raw) p.out_raw[o] = 0;
@@ -570,14 +602,16 @@ hipError_t launch_row_norms_f32(const unsigned char* rows, uint32_t n, uint32_t 
     return hipGetLastError();
 }
 
-hipError_t launch_compact_l2(const CompactParams& p, uint32_t nq, hipStream_t s) {
-    hipLaunchKernelGGL(compact_l2_kernel, dim3(nq), dim3(1024), (size_t)p.cap * 8, s, p);
+hipError_t launch_compact_margin(const CompactParams& p, uint32_t nq, hipStream_t s) {
+    hipLaunchKernelGGL(compact_margin_kernel, dim3(nq), dim3(1024), (size_t)p.cap * 8, s, p);
     return hipGetLastError();
 }
 
-hipError_t launch_rescore_l2(const RescoreParams& p, uint32_t nq, hipStream_t s) {
+hipError_t launch_rescore(const RescoreParams& p, int metric, uint32_t nq, hipStream_t s) {
     const size_t lds = (size_t)((p.dim + 7u) & ~7u) * 4 + (size_t)(p.cap / 2) * 8;
-    hipLaunchKernelGGL(rescore_l2_kernel, dim3(nq), dim3(256), lds, s, p);
+    if (metric == MVF_METRIC_L2) hipLaunchKernelGGL(rescore_kernel<MVF_METRIC_L2>, dim3(nq), dim3(256), lds, s, p);
+    else if (metric == MVF_METRIC_COSINE) hipLaunchKernelGGL(rescore_kernel<MVF_METRIC_COSINE>, dim3(nq), dim3(256), lds, s, p);
+    else hipLaunchKernelGGL(rescore_kernel<MVF_METRIC_INNER_PRODUCT>, dim3(nq), dim3(256), lds, s, p);
     return hipGetLastError();
 }
 

@@ -14,11 +14,16 @@
 //             dot / L2 (qq + xx - 2 dot) / cosine, identical to K1 and the CPU.
 //   Float16 : the reference semantics are "f32 query x exactly-widened f16 row"
 //             (Vector::as_f32, src/vectors/vector.rs:81-89).  An f16 MFMA needs
-//             an f16 query, so each query is scaled by a power of two (max |q|
-//             into [2^14, 2^15)) and split q*2^e = hi + lo into two f16 planes;
-//             A rows = 128 queries x 2 planes; products of f16 pairs are exact in
-//             f32, so dot = (hi.x + lo.x) * 2^-e differs from the f32 dot by
-//             ~2^-22 relative — inside the 1e-5 tolerance.
+//             an f16 query: each query is scaled by a power of two (max |q| into
+//             [2^14, 2^15)) and ROUNDED to one f16 plane, q~ = f16(q 2^e).  This
+//             kernel only SELECTS with it: |q~.x 2^-e - q.x| <= 2^-11 |q||x|
+//             (Cauchy-Schwarz over the per-element rounding), so the scores are
+//             approximate with a proven bound; compact_margin_kernel keeps
+//             every row within twice that bound of the k-th and rescore_kernel
+//             recomputes the kept rows from the f32 query (scan_mfma.hip).  An
+//             exact hi+lo two-plane split needs twice the MFMA, LDS and L2
+//             traffic for precision that only ~k rows per query ever use.
+//             A rows = 256 queries, like Int8.
 //
 // k-tile = 128 bytes per row (128 int8 / 64 f16), 4 MFMA k-steps of 32 bytes;
 // LDS rows padded to 144 B (conflict-free ds_read_b128); two LDS stages; the
@@ -49,7 +54,7 @@ constexpr size_t kLds16 = (size_t)4 * TILE_B + 4 * 256 * 4;  // stages + qaux0 +
 
 template <int DT> struct T16;
 template <> struct T16<MVF_DTYPE_FLOAT16> {
-    static constexpr int PLANES = 2, IT = 2;  // i-tiles (32 queries) per wave
+    static constexpr int PLANES = 1, IT = 4;  // i-tiles (32 queries) per wave
     using Acc = f32x16;
 };
 template <> struct T16<MVF_DTYPE_INT8> {
@@ -439,7 +444,7 @@ __global__ void __launch_bounds__(512, 2) scan_mfma16_kernel(Batch16Params p) {
 }
 
 // ---- query preparation ---------------------------------------------------------------
-// f16: per query, scale = 2^e with max|q|*2^e in [2^14, 2^15); planes hi = f16(q*2^e), lo = f16(q*2^e - hi).
+// f16: per query, scale = 2^e with max|q|*2^e in [2^14, 2^15); one plane q~ = f16(q*2^e) (round to nearest).
 //      qaux0 = 2^-e, qaux1 = |q| (f32 norm of the ORIGINAL query).
 __global__ void prep_queries_f16_kernel(const float* q, uint32_t nq, uint32_t nq_pad, uint32_t dim, uint32_t KPB,
                                         unsigned char* qprep, float* qaux0, float* qaux1) {
@@ -472,12 +477,9 @@ __global__ void prep_queries_f16_kernel(const float* q, uint32_t nq, uint32_t nq
     }
     const float up = ldexpf(1.0f, e), down = ldexpf(1.0f, -e);
     __half* hi = reinterpret_cast<__half*>(qprep + (size_t)row * KPB);
-    __half* lo = reinterpret_cast<__half*>(qprep + ((size_t)nq_pad + row) * KPB);
     for (uint32_t c = threadIdx.x; c < KP; c += blockDim.x) {
         float v = (row < nq && c < dim) ? q[(size_t)row * dim + c] * up : 0.f;
-        const __half h = __float2half_rn(v);
-        hi[c] = h;
-        lo[c] = __float2half_rn(v - __half2float(h));
+        hi[c] = __float2half_rn(v);
     }
     if (threadIdx.x == 0) {
         qaux0[row] = down;
@@ -630,7 +632,7 @@ hipError_t launch_dt(const Batch16Params& p, int metric, dim3 grid, hipStream_t 
 
 }  // namespace
 
-uint32_t scan_mfma16_queries_per_block(int dtype) { return dtype == MVF_DTYPE_FLOAT16 ? 128u : 256u; }  // Int8 / UInt8: 256
+uint32_t scan_mfma16_queries_per_block(int) { return 256u; }
 
 hipError_t launch_scan_mfma16(const Batch16Params& p, int dtype, int metric, int num_cus, hipStream_t s) {
     // Grid: a multiple of 8 (one lane set per XCD).  Persistent (one block per CU, LDS-limited) or one tile per

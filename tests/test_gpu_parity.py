@@ -586,6 +586,32 @@ def test_batched_mfma_f16(oracle, metric, shape):
         assert_float_topk(metric, res.scores[i], res.indices[i], sc, rows32, q[i], k)
 
 
+@pytest.mark.parametrize("metric", [0, 1, 2])
+@pytest.mark.parametrize("cluster", [300, 3000])
+def test_batched_f16_dense_cluster_at_the_kth_rank(oracle, metric, cluster):
+    """Float16 rows are SELECTED with one f16 query plane (score error up to 2^-11 |q||x|) and the kept rows
+    re-scored exactly.  A cluster of near-identical rows around the k-th rank has score gaps far below that
+    error: 300 rows ride inside the margin and are re-scored; 3000 exceed the candidate budget and the query is
+    repaired by the streaming kernel.  Either way the answer must be the exact one."""
+    n, dim, nq, k = 20000, 192, 40, 50
+    rows = oracle.synth_rows(SEED, 0, n, dim, 1).astype(np.float32)
+    rng = np.random.default_rng(11)
+    base = rng.standard_normal(dim).astype(np.float32)
+    where = rng.choice(n, cluster, replace=False)
+    rows[where] = base * 0.5 + rng.standard_normal((cluster, dim)).astype(np.float32) * 1.5e-3
+    rows = rows.astype(np.float16)
+    q = (base[None, :] + rng.standard_normal((nq, dim)).astype(np.float32) * 1e-2).astype(np.float32)
+    with G.GpuCorpus.from_array(rows) as c:
+        c.set_scan_path(2)
+        res = c.search(q, k, metric)
+    rows32 = rows.astype(np.float32)
+    members = set(where.tolist())
+    for i in range(nq):
+        sc, _, _ = oracle.scores(rows, 1, metric, q[i])
+        assert_float_topk(metric, res.scores[i], res.indices[i], sc, rows32, q[i], k)
+        assert set(res.indices[i].tolist()) <= members
+
+
 # ---------------------------------------------------------------------------
 # K2 batched L2 on float spaces: GEMM-form selection with an error margin +
 # exact (q-x)^2 re-scoring of the kept candidates
