@@ -84,6 +84,7 @@ struct mvfgpu_corpus {
     mutable std::mutex host_mu;  // serialises the host-buffer API's device mirrors
     mutable DevBuf cand;                  // scratch: per-block candidate lists (K1)
     mutable DevBuf bq, bstate, bcand, xnorm;  // K2: padded queries + norms; tau/cnt/overflow; candidates; row norms
+    mutable DevBuf repair;                // K2 overflow repair: gathered queries + their results
     mutable bool xnorm_ready = false;
     mutable uint32_t bstate_slots = 0;    // queries the K2 state arrays are armed for
     mutable DevBuf h_q, h_s, h_i, h_r;    // device mirrors for the host-buffer API
@@ -449,14 +450,29 @@ int search_batched_path(const mvfgpu_corpus* c, uint8_t metric, const void* d_qu
     bool any = false;
     for (uint32_t q = 0; q < nq; q++) any |= flags[q] != 0;
     if (any) {
+        // Repair: the flagged queries are gathered so that K1 takes them four per pass over the corpus.
         HIP_TRY(hipMemsetAsync(overflow, 0, (size_t)nq_pad * 4, s));
-        const uint32_t qes = is_int_dtype(c->dtype) ? 1u : 4u;
-        for (uint32_t q = 0; q < nq; q++) {
-            if (!flags[q]) continue;
-            int rc = search_stream_path(c, metric, static_cast<const unsigned char*>(d_queries) + (size_t)q * c->dim * qes,
-                                        1, k, d_scores + (size_t)q * k, d_indices + (size_t)q * k,
-                                        d_raw ? d_raw + (size_t)q * k : nullptr, s, /*profile=*/false);
-            if (rc != MVF_OK) return rc;
+        std::vector<uint32_t> redo;
+        for (uint32_t q = 0; q < nq; q++)
+            if (flags[q]) redo.push_back(q);
+        const size_t nf = redo.size();
+        const size_t qbytes = (size_t)c->dim * (is_int_dtype(c->dtype) ? 1u : 4u);
+        const size_t qarea = (nf * qbytes + 15u) & ~(size_t)15u, nres = nf * k;
+        HIP_TRY(c->repair.reserve(qarea + nres * 16));
+        unsigned char* gq = static_cast<unsigned char*>(c->repair.p);
+        uint64_t* ti = reinterpret_cast<uint64_t*>(gq + qarea);
+        float* ts = reinterpret_cast<float*>(ti + nres);
+        int32_t* tr = reinterpret_cast<int32_t*>(ts + nres);
+        for (size_t i = 0; i < nf; i++)
+            HIP_TRY(hipMemcpyAsync(gq + i * qbytes, static_cast<const unsigned char*>(d_queries) + redo[i] * qbytes, qbytes,
+                                   hipMemcpyDeviceToDevice, s));
+        int rc = search_stream_path(c, metric, gq, (uint32_t)nf, k, ts, ti, tr, s, /*profile=*/false);
+        if (rc != MVF_OK) return rc;
+        for (size_t i = 0; i < nf; i++) {
+            const size_t o = (size_t)redo[i] * k;
+            HIP_TRY(hipMemcpyAsync(d_scores + o, ts + i * k, (size_t)k * 4, hipMemcpyDeviceToDevice, s));
+            HIP_TRY(hipMemcpyAsync(d_indices + o, ti + i * k, (size_t)k * 8, hipMemcpyDeviceToDevice, s));
+            if (d_raw) HIP_TRY(hipMemcpyAsync(d_raw + o, tr + i * k, (size_t)k * 4, hipMemcpyDeviceToDevice, s));
         }
         HIP_TRY(hipStreamSynchronize(s));
     }
