@@ -488,7 +488,17 @@ bool use_batched_path(const mvfgpu_corpus* c, uint8_t metric, uint32_t nq) {
         (size_t)((c->dim + 7u) & ~7u) * 4 + kBatchCap * 4 > 64 * 1024)
         supported = false;  // the re-scoring kernel keeps the query in LDS
     if (!supported) return false;
-    return c->scan_path == 2 || nq >= 32;
+    if (c->scan_path == 2) return true;
+    // K1 costs one HBM pass per 4 queries (8.4 / 9.8 / 8.7 ms on 10M x 768 f32 / 12.5M x 1024 f16 / 50M x 768 int8),
+    // K2 a flat padded-tile time up to 128 / 256 queries (30 / 8.2 / 14 ms on the same corpora) plus ~0.2 ms of
+    // phase launches and the final flag read-back: measured crossovers on >= 1 GB of rows; small corpora keep K1
+    // until the batch is MFMA-sized.
+    const uint64_t bytes = c->n * (uint64_t)c->dim * elem_size(c->dtype);
+    const uint32_t threshold = bytes < (1ull << 30)              ? 32u
+                               : c->dtype == MVF_DTYPE_FLOAT32 ? 13u
+                               : c->dtype == MVF_DTYPE_FLOAT16 ? 4u
+                                                               : 5u;
+    return nq >= threshold;
 }
 
 int check_query_args(const mvfgpu_corpus* c, uint8_t metric, const void* queries, uint8_t query_dtype,
