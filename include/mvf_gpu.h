@@ -165,7 +165,7 @@ int mvfgpu_search(const mvfgpu_corpus* corpus, uint8_t metric,
  * This is the timed region of bench.py and the producer of the per-shard
  * lists that RCCL all-gathers.  d_raw may be NULL.
  * Small batches run the streaming kernel and return without waiting (below
- * 32 queries on corpora under 1 GiB; below 13 / 4 / 5 queries on larger
+ * 32 queries on corpora under 1 GiB; below 8 / 4 / 5 queries on larger
  * Float32 / Float16 / Int8-UInt8 corpora — the measured crossovers; one
  * query always streams).  Larger batches run the MFMA path, whose
  * last step reads back per-query overflow flags (an adversarially ordered

@@ -273,9 +273,9 @@ int search_stream_path(const mvfgpu_corpus* c, uint8_t metric, const void* d_que
 int search_batched_path(const mvfgpu_corpus* c, uint8_t metric, const void* d_queries, uint32_t nq, uint32_t k,
                         float* d_scores, uint64_t* d_indices, int32_t* d_raw, hipStream_t s) {
     const bool wide = c->dtype == MVF_DTYPE_FLOAT32;       // f32 rows: 128x128x32-float tiles
-    const uint32_t nq_pad = (nq + 255u) & ~255u;
     const uint32_t tile_rows = wide ? 128u : 256u;
-    const uint32_t qpb = wide ? 128u : scan_mfma16_queries_per_block(c->dtype);
+    const uint32_t qpb = wide ? 128u : scan_mfma16_queries_per_block(c->dtype);  // queries per block tile
+    const uint32_t nq_pad = (nq + qpb - 1u) / qpb * qpb;
     const uint32_t KT = wide ? (c->dim + 31u) / 32u : (c->dim * elem_size(c->dtype) + 127u) / 128u;
     const uint32_t KPB = KT * 128u;                        // prepared query row, bytes (both layouts use 128-B k-tiles)
     const uint32_t planes = 1u;
@@ -490,12 +490,12 @@ bool use_batched_path(const mvfgpu_corpus* c, uint8_t metric, uint32_t nq) {
     if (!supported) return false;
     if (c->scan_path == 2) return true;
     // K1 costs one HBM pass per 4 queries (8.4 / 9.8 / 8.7 ms on 10M x 768 f32 / 12.5M x 1024 f16 / 50M x 768 int8),
-    // K2 a flat padded-tile time up to 128 / 256 queries (30 / 8.2 / 14 ms on the same corpora) plus ~0.2 ms of
+    // K2 a flat padded-tile time up to 128 / 256 queries (16 / 8.2 / 14 ms on the same corpora) plus ~0.2 ms of
     // phase launches and the final flag read-back: measured crossovers on >= 1 GB of rows; small corpora keep K1
     // until the batch is MFMA-sized.
     const uint64_t bytes = c->n * (uint64_t)c->dim * elem_size(c->dtype);
     const uint32_t threshold = bytes < (1ull << 30)              ? 32u
-                               : c->dtype == MVF_DTYPE_FLOAT32 ? 13u
+                               : c->dtype == MVF_DTYPE_FLOAT32 ? 8u
                                : c->dtype == MVF_DTYPE_FLOAT16 ? 4u
                                                                : 5u;
     return nq >= threshold;
