@@ -402,6 +402,7 @@ int search_batched_path(const mvfgpu_corpus* c, uint8_t metric, const void* d_qu
             bp.row_begin = hp.row_begin = (uint32_t)begin;
             bp.row_end = hp.row_end = (uint32_t)end;
             bp.ntiles = hp.ntiles = (uint32_t)((end - begin + tile_rows - 1) / tile_rows);
+            bp.direct = hp.direct = (begin == 0 && end - begin <= cap) ? 1u : 0u;
             if (ps && last) HIP_TRY(hipEventRecord(ps->e[0], s));
             if (wide) HIP_TRY(launch_scan_mfma_f32(bp, metric, c->num_cus, s));
             else HIP_TRY(launch_scan_mfma16(hp, c->dtype, metric, c->num_cus, s));
@@ -413,6 +414,7 @@ int search_batched_path(const mvfgpu_corpus* c, uint8_t metric, const void* d_qu
             }
             tm.scan_launches++;
         }
+        cp.direct_cnt = (begin == 0 && end > begin && end - begin <= cap) ? (uint32_t)(end - begin) : 0u;
         if (approx) HIP_TRY(launch_compact_margin(cp, nq, s));
         else HIP_TRY(launch_compact(cp, nq, last, s));
         if (last) break;

@@ -24,6 +24,7 @@ struct BatchParams {
     uint32_t row_begin, row_end;  // rows of this launch (phase)
     uint32_t ntiles, mtiles;      // ceil((row_end-row_begin)/128), nq_pad/128
     uint32_t cap;
+    uint32_t direct;              // phase 0 (row_end - row_begin <= cap): candidate slot = row - row_begin, no counter
 };
 
 // K2 for 16-byte-operand MFMAs (Float16 / Int8 rows), scan_mfma16.hip
@@ -47,6 +48,7 @@ struct Batch16Params {
     uint32_t row_begin, row_end;
     uint32_t ntiles, mtiles;     // ceil(rows/256), nq_pad / queries-per-block
     uint32_t cap;
+    uint32_t direct;             // phase 0: candidate slot = row - row_begin, no counter
 };
 
 struct CompactParams {
@@ -55,6 +57,7 @@ struct CompactParams {
     uint32_t* tau;
     uint32_t* overflow;
     uint32_t cap, k;
+    uint32_t direct_cnt;  // != 0 after a direct phase: every query holds exactly this many candidates (cnt[] untouched)
     // approximate selection (float L2; every metric on Float16 rows): keys carry a score whose error is bounded by
     // eps * (qq + xxmax) [L2], eps [cosine], eps * |q| * sqrt(xxmax) [inner product]; the compaction keeps everything
     // within 2x that of the k-th value (compact_margin_kernel)

@@ -251,6 +251,7 @@ __global__ void __launch_bounds__(256, 2) scan_mfma_f32_kernel(BatchParams p) {
                         m |= (y < tql4[t] ? 0u : 1u) << (4 * g + t);
                     }
                 }
+                if (p.direct) m = 0xFFFFu;  // phase 0: every (query, row) pair is a candidate, whatever its score
                 if (!rok) m = 0;
                 if (__builtin_amdgcn_ballot_w64(m != 0) != 0) {  // wave-uniform: rare
 #pragma unroll
@@ -265,8 +266,10 @@ __global__ void __launch_bounds__(256, 2) scan_mfma_f32_kernel(BatchParams p) {
                             if (METRIC == MVF_METRIC_L2) sc_ = qn_s[ql] * qn_s[ql] + xx - 2.0f * sc_;  // GEMM-form s2
                             const uint32_t key = key_from_score(sc_, METRIC);
                             const uint32_t q = q0 + ql;
-                            if (q < p.nq && key <= tau_s[ql]) {
-                                const uint32_t slot_i = atomicAdd(&p.cnt[q], 1u);
+                            if (q < p.nq && (p.direct || key <= tau_s[ql])) {
+                                // phase 0 (rows <= cap, no threshold yet): the slot is the row's offset -- 32 lanes
+                                // bumping one counter per query is what made that 4096-row phase cost milliseconds
+                                const uint32_t slot_i = p.direct ? r - p.row_begin : atomicAdd(&p.cnt[q], 1u);
                                 if (slot_i < p.cap) p.cand[(size_t)q * p.cap + slot_i] = ((uint64_t)key << 32) | r;
                             }
                         }
@@ -396,7 +399,7 @@ __global__ void __launch_bounds__(1024) compact_kernel(CompactParams p) {
     uint64_t* buf = reinterpret_cast<uint64_t*>(smem);
     const int tid = threadIdx.x;
     const uint32_t q = blockIdx.x;
-    const uint32_t raw_cnt = p.cnt[q];
+    const uint32_t raw_cnt = p.direct_cnt ? p.direct_cnt : p.cnt[q];  // direct phase: every row of it, no counter
     const uint32_t m = raw_cnt < p.cap ? raw_cnt : p.cap;
     uint64_t* c = p.cand + (size_t)q * p.cap;
     const uint32_t P2 = next_pow2(m < 2 ? 2 : m);
@@ -431,7 +434,7 @@ __global__ void __launch_bounds__(1024) compact_margin_kernel(CompactParams p) {
     __shared__ uint32_t keep_s;
     const int tid = threadIdx.x;
     const uint32_t q = blockIdx.x;
-    const uint32_t raw_cnt = p.cnt[q];
+    const uint32_t raw_cnt = p.direct_cnt ? p.direct_cnt : p.cnt[q];  // direct phase: every row of it, no counter
     const uint32_t m = raw_cnt < p.cap ? raw_cnt : p.cap;
     uint64_t* c = p.cand + (size_t)q * p.cap;
     const uint32_t P2 = next_pow2(m < 2 ? 2 : m);

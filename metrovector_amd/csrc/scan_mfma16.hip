@@ -70,7 +70,10 @@ template <> struct T16<MVF_DTYPE_UINT8> {
     using Acc = i32x16;
 };
 
-template <int DT, int METRIC>
+// DIRECT = the phase-0 instantiation (rows <= cap, no threshold yet): every (query, row) pair is a candidate and its
+// slot is the row's offset -- no pre-filter, no counter.  A separate instantiation so the steady-state variants
+// (at the 256-VGPR limit) carry none of it.
+template <int DT, int METRIC, bool DIRECT>
 __global__ void __launch_bounds__(512, 2) scan_mfma16_kernel(Batch16Params p) {
     using Tr = T16<DT>;
     constexpr int PLANES = Tr::PLANES, IT = Tr::IT;
@@ -346,6 +349,7 @@ __global__ void __launch_bounds__(512, 2) scan_mfma16_kernel(Batch16Params p) {
 #pragma unroll
                     for (int t = 0; t < 4; t++) any |= __builtin_amdgcn_ballot_w64(passes(i, g, t, th4, sc4));
                 }
+                if (DIRECT) any = ~0ull;
                 if ((any & rokmask) != 0) {  // wave-uniform: rare
                     uint32_t m = 0;
 #pragma unroll
@@ -355,6 +359,7 @@ __global__ void __launch_bounds__(512, 2) scan_mfma16_kernel(Batch16Params p) {
 #pragma unroll
                         for (int t = 0; t < 4; t++) m |= (passes(i, g, t, th4, sc4) ? 1u : 0u) << (4 * g + t);
                     }
+                    if (DIRECT) m = 0xFFFFu;
                     if (!rok) m = 0;
 #pragma unroll
                     for (int e = 0; e < 16; e++) {
@@ -385,8 +390,8 @@ __global__ void __launch_bounds__(512, 2) scan_mfma16_kernel(Batch16Params p) {
                                 }
                             }
                             const uint32_t q = q0 + ql;
-                            if (q < p.nq && key <= tau_s[ql]) {
-                                const uint32_t slot_i = atomicAdd(&p.cnt[q], 1u);
+                            if (q < p.nq && (DIRECT || key <= tau_s[ql])) {
+                                const uint32_t slot_i = DIRECT ? r - p.row_begin : atomicAdd(&p.cnt[q], 1u);
                                 if (slot_i < p.cap) p.cand[(size_t)q * p.cap + slot_i] = ((uint64_t)key << 32) | r;
                             }
                         }
@@ -612,22 +617,25 @@ __global__ void __launch_bounds__(256) row_norms_u8_kernel(const unsigned char* 
     }
 }
 
-template <int DT>
-hipError_t launch_dt(const Batch16Params& p, int metric, dim3 grid, hipStream_t s) {
+template <int DT, int METRIC>
+hipError_t launch_dtm(const Batch16Params& p, dim3 grid, hipStream_t s) {
     // > 64 KiB of dynamic LDS needs the attribute; it is per device, and one process may drive several devices
-    const void* fn = metric == MVF_METRIC_L2 ? reinterpret_cast<const void*>(&scan_mfma16_kernel<DT, MVF_METRIC_L2>)
-                     : metric == MVF_METRIC_INNER_PRODUCT ? reinterpret_cast<const void*>(&scan_mfma16_kernel<DT, MVF_METRIC_INNER_PRODUCT>)
-                                                          : reinterpret_cast<const void*>(&scan_mfma16_kernel<DT, MVF_METRIC_COSINE>);
+    const void* fn = p.direct ? reinterpret_cast<const void*>(&scan_mfma16_kernel<DT, METRIC, true>)
+                              : reinterpret_cast<const void*>(&scan_mfma16_kernel<DT, METRIC, false>);
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds16);
     if (e != hipSuccess) return e;
-    switch (metric) {
-    case MVF_METRIC_L2: hipLaunchKernelGGL((scan_mfma16_kernel<DT, MVF_METRIC_L2>), grid, dim3(512), kLds16, s, p); break;
-    case MVF_METRIC_INNER_PRODUCT:
-        hipLaunchKernelGGL((scan_mfma16_kernel<DT, MVF_METRIC_INNER_PRODUCT>), grid, dim3(512), kLds16, s, p);
-        break;
-    default: hipLaunchKernelGGL((scan_mfma16_kernel<DT, MVF_METRIC_COSINE>), grid, dim3(512), kLds16, s, p); break;
-    }
+    if (p.direct) hipLaunchKernelGGL((scan_mfma16_kernel<DT, METRIC, true>), grid, dim3(512), kLds16, s, p);
+    else hipLaunchKernelGGL((scan_mfma16_kernel<DT, METRIC, false>), grid, dim3(512), kLds16, s, p);
     return hipGetLastError();
+}
+
+template <int DT>
+hipError_t launch_dt(const Batch16Params& p, int metric, dim3 grid, hipStream_t s) {
+    switch (metric) {
+    case MVF_METRIC_L2: return launch_dtm<DT, MVF_METRIC_L2>(p, grid, s);
+    case MVF_METRIC_INNER_PRODUCT: return launch_dtm<DT, MVF_METRIC_INNER_PRODUCT>(p, grid, s);
+    default: return launch_dtm<DT, MVF_METRIC_COSINE>(p, grid, s);
+    }
 }
 
 }  // namespace
