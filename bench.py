@@ -36,6 +36,26 @@ sys.path.insert(0, ROOT)
 SEED = 0x4D564631  # "MVF1"
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 MFMA_F32_PEAK_TF = 157.3  # same guide: dense f32-input MFMA peak (v_mfma_f32_32x32x2_f32)
+MFMA_F16_PEAK_TF = 2500.0  # same guide: ~2.5 PF dense bf16/f16 (v_mfma_f32_32x32x16_f16)
+MFMA_I8_PEAK_TOPS = 5000.0  # same guide: int8 = 2x the bf16 rate per clock (v_mfma_i32_32x32x32_i8)
+
+
+def mfma_roofline(tm, dtype):
+    """Roofline of the batched path's dominant launch (the LAST, largest phase) from the live HIP-event timing.
+    tm.scan_kernel: 2 = f32 MFMA kernel on Float32 rows, 3 = f16/int8 kernel on the stored rows, 4 = f16 kernel on
+    the scaled-f16 shadow of a Float32 corpus (selection; the kept rows are re-scored exactly)."""
+    ach = tm.scan_flops / (tm.scan_ms_avg * 1e-3) / 1e12
+    if tm.scan_kernel == 2:
+        peak, unit, kernel = MFMA_F32_PEAK_TF, "TFLOP/s", "scan_mfma_f32_kernel (last phase)"
+    elif tm.scan_kernel == 3 and dtype in (2, 3):
+        peak, unit, kernel = MFMA_I8_PEAK_TOPS, "TOP/s", "scan_mfma16_kernel<int8> (last phase)"
+    else:
+        peak, unit = MFMA_F16_PEAK_TF, "TFLOP/s"
+        kernel = "scan_mfma16_kernel<f16> (last phase)" + (" on the f16 shadow of the f32 rows" if tm.scan_kernel == 4 else "")
+    return {"bound": "mfma", "achieved": ach, "peak": peak, "unit": unit, "frac": ach / peak, "traffic": None,
+            "kernel": kernel, "kernel_ms_avg": tm.scan_ms_avg, "launches_timed": tm.samples,
+            "scan_launches_per_search": tm.scan_launches, "algorithmic_flops_per_launch": float(tm.scan_flops),
+            "algorithmic_bytes_per_launch": float(tm.scan_bytes)}
 
 
 def parse_args():
@@ -189,15 +209,8 @@ def main():
         }
         # ---- roofline of the dominant kernel (rank 0's shard) ---------------------------
         alg_bytes = float(args.rows) * args.dim * es  # N*d*es per launch
-        if tm.samples and tm.scan_ms_avg > 0 and tm.scan_kernel == 2:
-            # batched path: the timed launch is the LAST (largest) phase of the MFMA scan
-            ach = tm.scan_flops / (tm.scan_ms_avg * 1e-3) / 1e12
-            result["roofline"] = {"bound": "mfma", "achieved": ach, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
-                                  "frac": ach / MFMA_F32_PEAK_TF, "traffic": None,
-                                  "kernel": "scan_mfma_f32_kernel (last phase)", "kernel_ms_avg": tm.scan_ms_avg,
-                                  "launches_timed": tm.samples, "scan_launches_per_search": tm.scan_launches,
-                                  "algorithmic_flops_per_launch": float(tm.scan_flops),
-                                  "algorithmic_bytes_per_launch": float(tm.scan_bytes)}
+        if tm.samples and tm.scan_ms_avg > 0 and tm.scan_kernel >= 2:
+            result["roofline"] = mfma_roofline(tm, args.dtype)
         elif tm.samples and tm.scan_ms_avg > 0:
             ach = alg_bytes / (tm.scan_ms_avg * 1e-3) / 1e9
             result["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -239,41 +252,44 @@ def main():
                 if cb:
                     result["cpu_baseline"] = cb
             # ---- the metric's second leg: the same resident corpus, 1024 batched queries (MFMA path) ----------
+            # Two ways, same results: the default (f16 MFMA kernel selecting on the scaled-f16 shadow of the rows,
+            # kept rows re-scored exactly from the f32 rows) and the exact f32 MFMA kernel on the rows themselves.
             if args.queries == 1 and args.dtype == 0 and not args.no_batched:
                 nqb, bsteps = 1024, 5
                 dqb = torch.empty((nqb, args.dim), dtype=qdt, device=f"cuda:{local_rank}")
                 _lib.gpu_check(_lib.gpu().mvfgpu_synth_queries_device(dqb.data_ptr(), nqb, args.dim, args.dtype, SEED + 1,
                                                                       local_rank, None))
-                searcher.search(dqb, args.k, args.metric)  # warm-up (also computes the row norms once)
-                torch.cuda.synchronize()
-                corpus.set_profiling(True)
-                t0 = time.perf_counter()
-                for _ in range(bsteps):
-                    outb = searcher.search(dqb, args.k, args.metric)
-                torch.cuda.synchronize()
-                eb = time.perf_counter() - t0
-                tmb = corpus.last_timing()
-                corpus.set_profiling(False)
-                leg = {"workload": f"{args.rows // 1_000_000}M x {args.dim} {dtname} {mname}, {nqb} batched queries, top-{args.k}",
-                       "value": float(nqb) * args.rows * bsteps / eb, "unit": "distance-ops/s", "steps": bsteps,
-                       "ms_per_step": eb / bsteps * 1e3}
-                if tmb.samples and tmb.scan_ms_avg > 0 and tmb.scan_kernel == 2:
-                    achb = tmb.scan_flops / (tmb.scan_ms_avg * 1e-3) / 1e12
-                    leg["roofline"] = {"bound": "mfma", "achieved": achb, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
-                                       "frac": achb / MFMA_F32_PEAK_TF, "kernel": "scan_mfma_f32_kernel (last phase)",
-                                       "kernel_ms_avg": tmb.scan_ms_avg, "launches_timed": tmb.samples,
-                                       "algorithmic_flops_per_launch": float(tmb.scan_flops)}
-                    tp = os.path.join(ROOT, "profiles", "r01_bench_n1_q1024_hbm_traffic.json")
-                    if os.path.exists(tp):
-                        leg["roofline"]["traffic"] = json.load(open(tp))["roofline_traffic_bytes_per_launch"]
+                sel = [0, nqb // 3, 2 * nqb // 3, nqb - 1]
+                oidx = None
                 if not args.no_recall:
-                    qb = dqb.cpu().numpy()
-                    sel = [0, nqb // 3, 2 * nqb // 3, nqb - 1]
-                    osc, oidx = oracle_topk_full(args, oracle, qb[sel])
-                    gi = outb[1].cpu().numpy().view(np.uint64)[sel]
-                    leg["recall_at_k"] = sum(len(set(a.tolist()) & set(b.tolist())) for a, b in zip(gi, oidx)) / oidx.size
-                    leg["recall_queries_checked"] = len(sel)
-                result["batched_q1024"] = leg
+                    osc, oidx = oracle_topk_full(args, oracle, dqb.cpu().numpy()[sel])
+                for name, path in (("batched_q1024", 0), ("batched_q1024_f32_mfma", 2)):
+                    corpus.set_scan_path(path)
+                    searcher.search(dqb, args.k, args.metric)  # warm-up (builds the row norms / the shadow once)
+                    torch.cuda.synchronize()
+                    corpus.set_profiling(True)
+                    t0 = time.perf_counter()
+                    for _ in range(bsteps):
+                        outb = searcher.search(dqb, args.k, args.metric)
+                    torch.cuda.synchronize()
+                    eb = time.perf_counter() - t0
+                    tmb = corpus.last_timing()
+                    corpus.set_profiling(False)
+                    leg = {"workload": f"{args.rows // 1_000_000}M x {args.dim} {dtname} {mname}, {nqb} batched queries, top-{args.k}",
+                           "scan_path": "automatic" if path == 0 else "2 (exact f32 MFMA on the stored rows)",
+                           "value": float(nqb) * args.rows * bsteps / eb, "unit": "distance-ops/s", "steps": bsteps,
+                           "ms_per_step": eb / bsteps * 1e3}
+                    if tmb.samples and tmb.scan_ms_avg > 0 and tmb.scan_kernel >= 2:
+                        leg["roofline"] = mfma_roofline(tmb, args.dtype)
+                        tp = os.path.join(ROOT, "profiles", "r01_bench_n1_q1024_hbm_traffic.json")
+                        if tmb.scan_kernel == 2 and os.path.exists(tp):
+                            leg["roofline"]["traffic"] = json.load(open(tp))["roofline_traffic_bytes_per_launch"]
+                    if oidx is not None:
+                        gi = outb[1].cpu().numpy().view(np.uint64)[sel]
+                        leg["recall_at_k"] = sum(len(set(a.tolist()) & set(b.tolist())) for a, b in zip(gi, oidx)) / oidx.size
+                        leg["recall_queries_checked"] = len(sel)
+                    result[name] = leg
+                corpus.set_scan_path(0)
         print(json.dumps(result), flush=True)
 
     corpus.close()

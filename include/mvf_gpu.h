@@ -76,7 +76,9 @@ typedef struct mvfgpu_timing {
     float scan_ms_avg;   /* mean over the (up to 64) newest profiled searches */
     float select_ms_avg;
     uint32_t samples;    /* searches averaged */
-    uint32_t scan_kernel; /* 1 = streaming (K1), 2 = MFMA batched (K2) */
+    uint32_t scan_kernel; /* 1 = streaming (K1); MFMA batched (K2): 2 = f32 kernel on Float32 rows,
+                             3 = f16/int8 kernel on the stored rows, 4 = f16 kernel on the f16 shadow of a
+                             Float32 corpus */
     uint32_t scan_launches; /* scan launches of one search (timing covers the first) */
     uint64_t scan_bytes; /* algorithmic bytes one scan launch reads */
     uint64_t scan_flops; /* algorithmic flops of one scan launch (2*nq*rows*dim) */
@@ -165,9 +167,10 @@ int mvfgpu_search(const mvfgpu_corpus* corpus, uint8_t metric,
  * This is the timed region of bench.py and the producer of the per-shard
  * lists that RCCL all-gathers.  d_raw may be NULL.
  * Small batches run the streaming kernel and return without waiting (below
- * 32 queries on corpora under 1 GiB; below 8 / 4 / 5 queries on larger
- * Float32 / Float16 / Int8-UInt8 corpora — the measured crossovers; one
- * query always streams).  Larger batches run the MFMA path, whose
+ * 32 queries on corpora under 1 GiB; on larger ones below 2 queries for
+ * Float16 and shadowed Float32, 8 for Float32 without the shadow, 5 for
+ * Int8/UInt8 — the measured crossovers; one query always streams).  Larger
+ * batches run the MFMA path, whose
  * last step reads back per-query overflow flags (an adversarially ordered
  * corpus can overflow a candidate buffer; such queries are redone exactly by
  * the streaming kernel): that call returns after the stream has drained.
@@ -224,7 +227,18 @@ int mvfgpu_set_profiling(mvfgpu_corpus* corpus, int enabled);
 int mvfgpu_last_timing(const mvfgpu_corpus* corpus, mvfgpu_timing* out);
 
 /* Force a scan path for A/B measurements and tests: 0 = automatic,
- * 1 = streaming kernel (K1) for every nq, 2 = MFMA batched kernel (K2). */
+ * 1 = streaming kernel (K1) for every nq, 2 = MFMA batched kernel (K2) on the
+ * stored rows, 3 = K2 with the f16 shadow on Float32 corpora (same as 2 on
+ * the other types).
+ *
+ * The f16 shadow: batched searches on a Float32 corpus select candidates with
+ * the f16 MFMA kernel on a scaled-f16 copy of the rows (built on the first
+ * such search, +50 % of the corpus' device memory; skipped automatically when
+ * that would leave < 2 GiB free, or with MVF_F16_SHADOW=0 in the environment),
+ * keep every row whose approximate score is within a proven error bound of
+ * the k-th, and re-score the kept rows from the stored f32 rows and the f32
+ * query.  Scores and order are those of the exact path; only the selection
+ * arithmetic differs (~4x faster than the exact f32 MFMA kernel). */
 int mvfgpu_set_scan_path(mvfgpu_corpus* corpus, int path);
 
 #ifdef __cplusplus

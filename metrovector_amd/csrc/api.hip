@@ -85,6 +85,8 @@ struct mvfgpu_corpus {
     mutable DevBuf cand;                  // scratch: per-block candidate lists (K1)
     mutable DevBuf bq, bstate, bcand, xnorm;  // K2: padded queries + norms; tau/cnt/overflow; candidates; row norms
     mutable DevBuf repair;                // K2 overflow repair: gathered queries + their results
+    mutable DevBuf shadow, xscale;        // Float32 corpora: scaled-f16 shadow rows (selection only) + 2^-s_r per row
+    mutable int shadow_state = 0;         // 0 not built yet, 1 ready, -1 unavailable (no memory)
     mutable bool xnorm_ready = false;
     mutable uint32_t bstate_slots = 0;    // queries the K2 state arrays are armed for
     mutable DevBuf h_q, h_s, h_i, h_r;    // device mirrors for the host-buffer API
@@ -266,17 +268,62 @@ int search_stream_path(const mvfgpu_corpus* c, uint8_t metric, const void* d_que
 }
 
 
+// ---- scaled-f16 shadow of a Float32 corpus (selection only) -----------------------------------------------------
+uint32_t shadow_pitch(uint32_t dim) { return (dim * 2u + 15u) & ~15u; }
+
+bool shadow_enabled() {  // MVF_F16_SHADOW=0 keeps Float32 corpora on the exact f32 MFMA kernel
+    const char* e = getenv("MVF_F16_SHADOW");
+    return !e || atoi(e) != 0;
+}
+
+// Built on the first batched search (like the row norms): +50 % of the corpus' HBM.  In automatic mode it is skipped
+// when that would leave less than 2 GiB free on the device; scan path 3 insists.
+hipError_t ensure_shadow(const mvfgpu_corpus* c, hipStream_t s) {
+    if (c->shadow_state != 0) return hipSuccess;
+    const size_t need = (size_t)std::max<uint64_t>(c->n, 1) * shadow_pitch(c->dim);
+    if (c->scan_path != 3) {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < need + ((size_t)2 << 30)) {
+            c->shadow_state = -1;
+            return hipSuccess;
+        }
+    }
+    if (c->shadow.reserve(need) != hipSuccess || c->xscale.reserve((size_t)std::max<uint64_t>(c->n, 1) * 4) != hipSuccess) {
+        (void)hipGetLastError();
+        c->shadow.release();
+        c->xscale.release();
+        c->shadow_state = -1;
+        return hipSuccess;
+    }
+    hipError_t e = launch_shadow_f16(c->d_rows, (uint32_t)c->n, c->pitch, c->dim, static_cast<unsigned char*>(c->shadow.p),
+                                     shadow_pitch(c->dim), static_cast<float*>(c->xscale.p), s);
+    if (e == hipSuccess) c->shadow_state = 1;
+    return e;
+}
+
 // K2 path: MFMA batched scan in geometric phases with per-query candidate
 // compaction between them (scan_mfma.hip for Float32 rows, scan_mfma16.hip for
 // Float16 / Int8 rows).  Blocking at the end: the overflow flags are read back
 // and any flagged query is redone exactly with K1.
 int search_batched_path(const mvfgpu_corpus* c, uint8_t metric, const void* d_queries, uint32_t nq, uint32_t k,
                         float* d_scores, uint64_t* d_indices, int32_t* d_raw, hipStream_t s) {
-    const bool wide = c->dtype == MVF_DTYPE_FLOAT32;       // f32 rows: 128x128x32-float tiles
+    // Float32 rows: either the exact f32 MFMA kernel on the rows themselves, or -- 4x faster -- the f16 kernel on a
+    // scaled-f16 SHADOW copy that only selects candidates (error bound below); the kept rows are re-scored from the
+    // f32 rows and the f32 query either way, so results do not depend on which one ran.
+    bool use_shadow = false;
+    const bool rescore_fits = (size_t)((c->dim + 7u) & ~7u) * 4 + kBatchCap * 4 <= 64 * 1024;  // query + candidates in LDS
+    if (c->dtype == MVF_DTYPE_FLOAT32 && c->scan_path != 2 && shadow_enabled() && rescore_fits) {
+        HIP_TRY(ensure_shadow(c, s));
+        use_shadow = c->shadow_state == 1;
+    }
+    const bool wide = c->dtype == MVF_DTYPE_FLOAT32 && !use_shadow;  // f32 rows: 128x128x32-float tiles
+    const uint8_t kdtype = use_shadow ? (uint8_t)MVF_DTYPE_FLOAT16 : c->dtype;  // element type the scan kernel reads
+    const unsigned char* krows = use_shadow ? static_cast<const unsigned char*>(c->shadow.p) : c->d_rows;
+    const uint32_t kpitch = use_shadow ? shadow_pitch(c->dim) : c->pitch;
     const uint32_t tile_rows = wide ? 128u : 256u;
-    const uint32_t qpb = wide ? 128u : scan_mfma16_queries_per_block(c->dtype);  // queries per block tile
+    const uint32_t qpb = wide ? 128u : scan_mfma16_queries_per_block(kdtype);  // queries per block tile
     const uint32_t nq_pad = (nq + qpb - 1u) / qpb * qpb;
-    const uint32_t KT = wide ? (c->dim + 31u) / 32u : (c->dim * elem_size(c->dtype) + 127u) / 128u;
+    const uint32_t KT = wide ? (c->dim + 31u) / 32u : (c->dim * elem_size(kdtype) + 127u) / 128u;
     const uint32_t KPB = KT * 128u;                        // prepared query row, bytes (both layouts use 128-B k-tiles)
     const uint32_t planes = 1u;
     const uint32_t cap = kBatchCap;
@@ -299,7 +346,7 @@ int search_batched_path(const mvfgpu_corpus* c, uint8_t metric, const void* d_qu
     const bool is_float = !is_int_dtype(c->dtype);
     // approximate selection + exact re-scoring: float L2 (GEMM-form distances) and every metric on Float16 rows
     // (single f16 query plane); the other combinations carry final keys through the phases
-    const bool approx = is_float && (metric == MVF_METRIC_L2 || c->dtype == MVF_DTYPE_FLOAT16);
+    const bool approx = is_float && (metric == MVF_METRIC_L2 || kdtype == MVF_DTYPE_FLOAT16);
     const bool need_norms = approx || metric != MVF_METRIC_INNER_PRODUCT || c->dtype == MVF_DTYPE_UINT8;
     // K4 buffer: float rows: |x| [n], sum x^2 [n], max sum x^2 [1]; Int8 rows: sum x^2 (i32) [n];
     // UInt8 rows: sum (x-128)^2 [n], 128 * sum (x-128) [n]
@@ -308,7 +355,8 @@ int search_batched_path(const mvfgpu_corpus* c, uint8_t metric, const void* d_qu
         HIP_TRY(c->xnorm.reserve((2 * nn + 1) * 4));
         float* xn = static_cast<float*>(c->xnorm.p);
         if (is_float) HIP_TRY(hipMemsetAsync(xn + 2 * nn, 0, 4, s));
-        if (wide) HIP_TRY(launch_row_norms_f32(c->d_rows, n, c->pitch, xn, xn + nn, xn + 2 * nn, s));
+        // norms always come from the STORED rows (a shadow only feeds the dot products)
+        if (c->dtype == MVF_DTYPE_FLOAT32) HIP_TRY(launch_row_norms_f32(c->d_rows, n, c->pitch, xn, xn + nn, xn + 2 * nn, s));
         else HIP_TRY(launch_row_norms16(c->d_rows, c->dtype, n, c->pitch, c->dim, c->xnorm.p, xn + nn, xn + 2 * nn, s));
         c->xnorm_ready = true;
     }
@@ -318,7 +366,7 @@ int search_batched_path(const mvfgpu_corpus* c, uint8_t metric, const void* d_qu
         HIP_TRY(launch_prep_queries(static_cast<const float*>(d_queries), nq, nq_pad, c->dim, KPB / 4,
                                     reinterpret_cast<float*>(qprep), qaux0, s));
     else
-        HIP_TRY(launch_prep_queries16(d_queries, c->dtype, nq, nq_pad, c->dim, KPB, qprep, qaux0, qaux1, s));
+        HIP_TRY(launch_prep_queries16(d_queries, kdtype, nq, nq_pad, c->dim, KPB, qprep, qaux0, qaux1, s));
 
     BatchParams bp{};
     bp.qmat = reinterpret_cast<const float*>(qprep);
@@ -342,7 +390,8 @@ int search_batched_path(const mvfgpu_corpus* c, uint8_t metric, const void* d_qu
     hp.qprep = qprep;
     hp.qaux0 = qaux0;
     hp.qaux1 = qaux1;
-    hp.rows = c->d_rows;
+    hp.rows = krows;
+    hp.xscale = use_shadow ? static_cast<const float*>(c->xscale.p) : nullptr;
     hp.xnorm_f = static_cast<const float*>(c->xnorm.p);
     hp.xnorm_i = static_cast<const int32_t*>(c->xnorm.p);
     hp.xbias_i = c->xnorm.p ? static_cast<const int32_t*>(c->xnorm.p) + nn : nullptr;
@@ -352,8 +401,8 @@ int search_batched_path(const mvfgpu_corpus* c, uint8_t metric, const void* d_qu
     hp.tau = tau;
     hp.cand = bp.cand;
     hp.cnt = cnt;
-    hp.pitch = c->pitch;
-    hp.V = c->V;
+    hp.pitch = kpitch;
+    hp.V = kpitch / 16;
     hp.KPB = KPB;
     hp.KT = KT;
     hp.nq = nq;
@@ -380,10 +429,11 @@ int search_batched_path(const mvfgpu_corpus* c, uint8_t metric, const void* d_qu
     // f32 accumulation of `dim` terms plus the norms, and on Float16 rows the query's rounding to f16 (2^-11 per
     // element, relative; elements that land in the f16 subnormals add < 2^-39 of it)
     cp.eps = (float)(std::max<uint32_t>(c->dim, 64) + 16) * 1.1920929e-7f;
-    if (c->dtype == MVF_DTYPE_FLOAT16) cp.eps += 4.8828125e-4f * 1.001f;
+    if (kdtype == MVF_DTYPE_FLOAT16) cp.eps += 4.8828125e-4f * 1.001f;
+    if (use_shadow) cp.eps += 4.8828125e-4f * 1.001f;  // the shadow rows' own rounding (same bound, per element of x)
 
     mvfgpu_timing tm{};
-    tm.scan_kernel = 2;
+    tm.scan_kernel = wide ? 2u : use_shadow ? 4u : 3u;
     mvfgpu_corpus::ProfSlot* ps = nullptr;
     if (c->profiling) {
         ps = &c->prof[c->prof_next % mvfgpu_corpus::kProfSlots];
@@ -405,11 +455,11 @@ int search_batched_path(const mvfgpu_corpus* c, uint8_t metric, const void* d_qu
             bp.direct = hp.direct = (begin == 0 && end - begin <= cap) ? 1u : 0u;
             if (ps && last) HIP_TRY(hipEventRecord(ps->e[0], s));
             if (wide) HIP_TRY(launch_scan_mfma_f32(bp, metric, c->num_cus, s));
-            else HIP_TRY(launch_scan_mfma16(hp, c->dtype, metric, c->num_cus, s));
+            else HIP_TRY(launch_scan_mfma16(hp, kdtype, metric, c->num_cus, s));
             if (ps && last) {
                 HIP_TRY(hipEventRecord(ps->e[1], s));
                 ps->scanned = true;
-                tm.scan_bytes = (end - begin) * c->dim * elem_size(c->dtype);
+                tm.scan_bytes = (end - begin) * c->dim * elem_size(kdtype);
                 tm.scan_flops = 2ull * nq * (end - begin) * c->dim;
             }
             tm.scan_launches++;
@@ -490,16 +540,18 @@ bool use_batched_path(const mvfgpu_corpus* c, uint8_t metric, uint32_t nq) {
         (size_t)((c->dim + 7u) & ~7u) * 4 + kBatchCap * 4 > 64 * 1024)
         supported = false;  // the re-scoring kernel keeps the query in LDS
     if (!supported) return false;
-    if (c->scan_path == 2) return true;
-    // K1 costs one HBM pass per 4 queries (8.4 / 9.8 / 8.7 ms on 10M x 768 f32 / 12.5M x 1024 f16 / 50M x 768 int8),
-    // K2 a flat padded-tile time up to 128 / 256 queries (16 / 8.2 / 14 ms on the same corpora) plus ~0.2 ms of
-    // phase launches and the final flag read-back: measured crossovers on >= 1 GB of rows; small corpora keep K1
-    // until the batch is MFMA-sized.
+    if (c->scan_path >= 2) return true;
+    // K1 takes 2..4 queries per HBM pass (8.4 / 9.8 / 8.7 ms on 10M x 768 f32 / 12.5M x 1024 f16 / 50M x 768 int8);
+    // K2 costs a flat padded-tile time up to 128 / 256 queries (f32 kernel 16 ms, f16 kernel 6.4 ms on the f32
+    // corpus' shadow and 8.2 ms on the f16 corpus, int8 14 ms) plus ~0.2 ms of phase launches and the final flag
+    // read-back: measured crossovers on >= 1 GiB of rows; small corpora keep K1 until the batch is MFMA-sized.
     const uint64_t bytes = c->n * (uint64_t)c->dim * elem_size(c->dtype);
-    const uint32_t threshold = bytes < (1ull << 30)              ? 32u
-                               : c->dtype == MVF_DTYPE_FLOAT32 ? 8u
-                               : c->dtype == MVF_DTYPE_FLOAT16 ? 4u
-                                                               : 5u;
+    const bool shadowed = c->dtype == MVF_DTYPE_FLOAT32 && shadow_enabled() && c->shadow_state >= 0 &&  // runs as Float16
+                          (size_t)((c->dim + 7u) & ~7u) * 4 + kBatchCap * 4 <= 64 * 1024;
+    const uint32_t threshold = bytes < (1ull << 30)                           ? 32u
+                               : c->dtype == MVF_DTYPE_FLOAT32 && !shadowed ? 8u
+                               : is_int_dtype(c->dtype)                     ? 5u
+                                                                            : 2u;
     return nq >= threshold;
 }
 
@@ -672,6 +724,9 @@ void mvfgpu_corpus_destroy(mvfgpu_corpus* c) {
         c->bstate.release();
         c->bcand.release();
         c->xnorm.release();
+        c->repair.release();
+        c->shadow.release();
+        c->xscale.release();
         c->h_q.release();
         c->h_s.release();
         c->h_i.release();
@@ -954,7 +1009,7 @@ int mvfgpu_last_timing(const mvfgpu_corpus* c, mvfgpu_timing* out) {
 
 int mvfgpu_set_scan_path(mvfgpu_corpus* c, int path) {
     if (!c) return fail(MVF_ERR_INVALID_ARGUMENT, "corpus is NULL");
-    if (path < 0 || path > 2) return fail(MVF_ERR_INVALID_ARGUMENT, "path must be 0, 1 or 2");
+    if (path < 0 || path > 3) return fail(MVF_ERR_INVALID_ARGUMENT, "path must be 0, 1, 2 or 3");
     std::lock_guard<std::mutex> lk(c->mu);
     c->scan_path = path;
     return MVF_OK;

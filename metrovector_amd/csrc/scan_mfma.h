@@ -29,13 +29,14 @@ struct BatchParams {
 
 // K2 for 16-byte-operand MFMAs (Float16 / Int8 rows), scan_mfma16.hip
 struct Batch16Params {
-    const unsigned char* qprep;  // f16: [2 planes][nq_pad][KPB] hi/lo halves; i8: [nq_pad][KPB] int8; zero padded
+    const unsigned char* qprep;  // [nq_pad][KPB]: f16: one plane f16(q 2^e); i8: int8; zero padded
     const float* qaux0;          // [nq_pad] f16: 2^-e (undo of the query scale); i8: bit pattern of i32 sum q^2
     const float* qaux1;          // [nq_pad] f16: |q| (f32)
     const unsigned char* rows;
     const float* xnorm_f;        // [n] f16 rows: sqrt(sum x^2)
     const float* xx2;            // [n] f16 rows: sum x^2 (batched L2)
     const float* xxmax;          // [1] max over rows of sum x^2
+    const float* xscale;         // [n] or NULL: rows are the scaled-f16 shadow of a Float32 corpus, row r times xscale[r]
     const int32_t* xnorm_i;      // [n] int rows: sum x^2 (UInt8: of the shifted values x-128)
     const int32_t* xbias_i;      // [n] UInt8 rows: 128 * sum (x-128)
     uint32_t dim;
@@ -104,6 +105,8 @@ uint32_t scan_mfma16_queries_per_block(int dtype);
 hipError_t launch_scan_mfma16(const Batch16Params& p, int dtype, int metric, int num_cus, hipStream_t s);
 hipError_t launch_prep_queries16(const void* q, int dtype, uint32_t nq, uint32_t nq_pad, uint32_t dim, uint32_t KPB,
                                  unsigned char* qprep, float* qaux0, float* qaux1, hipStream_t s);
+hipError_t launch_shadow_f16(const unsigned char* rows32, uint32_t n, uint32_t pitch32, uint32_t dim, unsigned char* rows16,
+                             uint32_t pitch16, float* xscale, hipStream_t s);
 hipError_t launch_row_norms16(const unsigned char* rows, int dtype, uint32_t n, uint32_t pitch, uint32_t dim, void* out,
                               float* xx2, float* xxmax, hipStream_t s);  // UInt8: xx2 receives the int32 bias array
 

@@ -73,7 +73,9 @@ template <> struct T16<MVF_DTYPE_UINT8> {
 // DIRECT = the phase-0 instantiation (rows <= cap, no threshold yet): every (query, row) pair is a candidate and its
 // slot is the row's offset -- no pre-filter, no counter.  A separate instantiation so the steady-state variants
 // (at the 256-VGPR limit) carry none of it.
-template <int DT, int METRIC, bool DIRECT>
+// XS (Float16 only) = the rows are the scaled-f16 SHADOW of a Float32 corpus: row r was multiplied by 2^s_r before
+// rounding and p.xscale[r] = 2^-s_r undoes it in the epilogue; norms come from the f32 rows.
+template <int DT, int METRIC, bool DIRECT, bool XS>
 __global__ void __launch_bounds__(512, 2) scan_mfma16_kernel(Batch16Params p) {
     using Tr = T16<DT>;
     constexpr int PLANES = Tr::PLANES, IT = Tr::IT;
@@ -294,12 +296,13 @@ __global__ void __launch_bounds__(512, 2) scan_mfma16_kernel(Batch16Params p) {
         for (int j = 0; j < 2; j++) {
             const uint32_t r = r0 + lane_r + j * 32;
             const bool rok = r < p.row_end;
-            float xnf = 0.f, rx = 1.f, xxf = 0.f;
+            float xnf = 0.f, rx = 1.f, xxf = 0.f, rs = 1.f;
             int32_t xxi = 0, bx = 0, xxu = 0;  // xxi: sum x^2 (UInt8: shifted); bx: UInt8 128 Sx_s; xxu: UInt8 sum x_u^2
             if (rok) {
                 if constexpr (DT == MVF_DTYPE_FLOAT16) {
                     if (METRIC == MVF_METRIC_COSINE) xnf = p.xnorm_f[r];
                     if (METRIC == MVF_METRIC_L2) xxf = p.xx2[r];
+                    if constexpr (XS) rs = p.xscale[r];
                 } else {
                     if (METRIC != MVF_METRIC_INNER_PRODUCT) xxi = p.xnorm_i[r];
                     if (U8 && METRIC != MVF_METRIC_L2) bx = p.xbias_i[r];
@@ -307,7 +310,7 @@ __global__ void __launch_bounds__(512, 2) scan_mfma16_kernel(Batch16Params p) {
             }
             if (U8) xxu = xxi + 2 * bx + 16384 * (int32_t)p.dim;
             if (METRIC == MVF_METRIC_COSINE) {
-                if constexpr (DT == MVF_DTYPE_FLOAT16) rx = xnf > 0.0f ? __builtin_amdgcn_rcpf(xnf) : 0.0f;
+                if constexpr (DT == MVF_DTYPE_FLOAT16) rx = xnf > 0.0f ? rs * __builtin_amdgcn_rcpf(xnf) : 0.0f;
                 else if (U8) rx = xxu > 0 ? __builtin_amdgcn_rcpf(sqrtf((float)xxu)) : 0.0f;
                 else rx = xxi > 0 ? __builtin_amdgcn_rcpf(sqrtf((float)xxi)) : 0.0f;
             }
@@ -316,9 +319,10 @@ __global__ void __launch_bounds__(512, 2) scan_mfma16_kernel(Batch16Params p) {
             // pre-filter test of accumulator element (i, 4g+t) against its query's threshold
             auto passes = [&](int i, int g, int t, const u32x4& th4, const u32x4& sc4) __attribute__((always_inline)) -> bool {
                 if constexpr (DT == MVF_DTYPE_FLOAT16) {
-                    const float y = METRIC == MVF_METRIC_COSINE ? acc[i][j][4 * g + t] * rx
-                                    : METRIC == MVF_METRIC_L2   ? fmaf(acc[i][j][4 * g + t], 2.0f * __uint_as_float(sc4[t]), -xxf)
-                                                                : acc[i][j][4 * g + t];
+                    const float a = XS && METRIC != MVF_METRIC_COSINE ? acc[i][j][4 * g + t] * rs : acc[i][j][4 * g + t];
+                    const float y = METRIC == MVF_METRIC_COSINE ? a * rx
+                                    : METRIC == MVF_METRIC_L2   ? fmaf(a, 2.0f * __uint_as_float(sc4[t]), -xxf)
+                                                                : a;
                     return !(y < __uint_as_float(th4[t]));
                 } else if (METRIC == MVF_METRIC_INNER_PRODUCT) {
                     return acc[i][j][4 * g + t] + bx >= (int32_t)th4[t];
@@ -368,6 +372,7 @@ __global__ void __launch_bounds__(512, 2) scan_mfma16_kernel(Batch16Params p) {
                             uint32_t key;
                             if constexpr (DT == MVF_DTYPE_FLOAT16) {
                                 float sc_ = acc[i][j][e] * qa_s[ql];  // undo the power-of-two query scale (exact)
+                                if constexpr (XS) sc_ *= rs;            // ... and the shadow row's
                                 if (METRIC == MVF_METRIC_COSINE) {
                                     const float den = qb_s[ql] * xnf;
                                     sc_ = den > 0.0f ? sc_ / den : 0.0f;
@@ -569,6 +574,52 @@ __global__ void __launch_bounds__(256) row_norms_f16_kernel(const unsigned char*
     if (lane == 0 && mx > 0.f) atomicMax(reinterpret_cast<unsigned int*>(xxmax), __float_as_uint(mx));
 }
 
+// Scaled-f16 SHADOW of a Float32 corpus, used for selection only (api.hip): row r is multiplied by 2^s_r with
+// max|x| 2^s_r in [2^14, 2^15) -- nothing overflows f16 and every element keeps 11 significant bits relative to
+// itself (elements more than 2^29 below the row's largest fall into the f16 subnormals: absolute error 2^-25, i.e.
+// < 2^-39 of the largest) -- and rounded to nearest; xscale[r] = 2^-s_r.  Rows holding Inf keep s_r = 0.
+__global__ void __launch_bounds__(256) shadow_f16_kernel(const unsigned char* rows32, uint32_t n, uint32_t pitch32,
+                                                          uint32_t dim, unsigned char* rows16, uint32_t pitch16,
+                                                          float* xscale) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t wave = (blockIdx.x * 256u + threadIdx.x) >> 6, nwaves = (gridDim.x * 256u) >> 6;
+    const uint32_t V32 = pitch32 / 16, V16 = pitch16 / 16;
+    for (uint32_t r = wave; r < n; r += nwaves) {
+        const unsigned char* rp = rows32 + (size_t)r * pitch32;
+        float mx = 0.f;
+        for (uint32_t v = lane; v < V32; v += 64) {
+            const u32x4 x = *reinterpret_cast<const u32x4*>(rp + (size_t)v * 16);
+#pragma unroll
+            for (int w = 0; w < 4; w++) mx = fmaxf(mx, fabsf(__uint_as_float(x[w])));
+        }
+        for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+        int sh = 0;
+        if (mx > 0.f && mx < 3.0e38f) {
+            int ex;
+            (void)frexpf(mx, &ex);  // mx = m * 2^ex, m in [0.5, 1)
+            sh = 15 - ex;
+        }
+        unsigned char* op = rows16 + (size_t)r * pitch16;
+        for (uint32_t v = lane; v < V16; v += 64) {  // one 16-B f16 vector = two f32 vectors
+            u32x4 o;
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const uint32_t v32 = 2 * v + h;
+                u32x4 x = u32x4{0, 0, 0, 0};
+                if (v32 < V32) x = *reinterpret_cast<const u32x4*>(rp + (size_t)v32 * 16);  // f32 padding is zero
+#pragma unroll
+                for (int w = 0; w < 2; w++) {
+                    const unsigned short lo = __half_as_ushort(__float2half_rn(ldexpf(__uint_as_float(x[2 * w]), sh)));
+                    const unsigned short hi = __half_as_ushort(__float2half_rn(ldexpf(__uint_as_float(x[2 * w + 1]), sh)));
+                    o[2 * h + w] = (uint32_t)lo | ((uint32_t)hi << 16);
+                }
+            }
+            *reinterpret_cast<u32x4*>(op + (size_t)v * 16) = o;
+        }
+        if (lane == 0) xscale[r] = ldexpf(1.0f, -sh);
+    }
+}
+
 __global__ void __launch_bounds__(256) row_norms_i8_kernel(const unsigned char* rows, uint32_t n, uint32_t pitch,
                                                             uint32_t V, int32_t* xx) {
     const uint32_t lane = threadIdx.x & 63;
@@ -620,12 +671,12 @@ __global__ void __launch_bounds__(256) row_norms_u8_kernel(const unsigned char* 
 template <int DT, int METRIC>
 hipError_t launch_dtm(const Batch16Params& p, dim3 grid, hipStream_t s) {
     // > 64 KiB of dynamic LDS needs the attribute; it is per device, and one process may drive several devices
-    const void* fn = p.direct ? reinterpret_cast<const void*>(&scan_mfma16_kernel<DT, METRIC, true>)
-                              : reinterpret_cast<const void*>(&scan_mfma16_kernel<DT, METRIC, false>);
-    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds16);
+    void (*fn)(Batch16Params) = p.direct ? &scan_mfma16_kernel<DT, METRIC, true, false> : &scan_mfma16_kernel<DT, METRIC, false, false>;
+    if constexpr (DT == MVF_DTYPE_FLOAT16)
+        if (p.xscale) fn = p.direct ? &scan_mfma16_kernel<DT, METRIC, true, true> : &scan_mfma16_kernel<DT, METRIC, false, true>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds16);
     if (e != hipSuccess) return e;
-    if (p.direct) hipLaunchKernelGGL((scan_mfma16_kernel<DT, METRIC, true>), grid, dim3(512), kLds16, s, p);
-    else hipLaunchKernelGGL((scan_mfma16_kernel<DT, METRIC, false>), grid, dim3(512), kLds16, s, p);
+    hipLaunchKernelGGL(fn, grid, dim3(512), kLds16, s, p);
     return hipGetLastError();
 }
 
@@ -667,6 +718,14 @@ hipError_t launch_prep_queries16(const void* q, int dtype, uint32_t nq, uint32_t
     else
         hipLaunchKernelGGL(prep_queries_i8_kernel, dim3(nq_pad), dim3(256), 0, s, static_cast<const int8_t*>(q), nq, nq_pad,
                            dim, KPB, qprep, qaux0, qaux1);
+    return hipGetLastError();
+}
+
+hipError_t launch_shadow_f16(const unsigned char* rows32, uint32_t n, uint32_t pitch32, uint32_t dim, unsigned char* rows16,
+                             uint32_t pitch16, float* xscale, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    const uint32_t blocks = (uint32_t)std::min<uint64_t>(((uint64_t)n + 3) / 4, 256u * 16u);
+    hipLaunchKernelGGL(shadow_f16_kernel, dim3(blocks), dim3(256), 0, s, rows32, n, pitch32, dim, rows16, pitch16, xscale);
     return hipGetLastError();
 }
 

@@ -73,7 +73,8 @@ def assert_float_topk(metric, got_scores, got_idx, all_scores, rows_f32, q_f32, 
         btol = TOL
     else:
         xn, qn = norms(rows_f32, q_f32)
-        btol = TOL * float(xn.max() * qn)
+        xfin = xn[np.isfinite(xn)]           # rows holding Inf / NaN have no meaningful norm
+        btol = TOL * float((xfin.max() if xfin.size else 0.0) * qn)
     btol *= 2
     must = set(np.nonzero(key < kth - btol)[0].tolist())
     may = set(np.nonzero(key <= kth + btol)[0].tolist())

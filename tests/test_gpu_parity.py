@@ -347,6 +347,80 @@ def test_batched_mfma_path(oracle, metric, shape):
     assert recall_at_k(res.indices, ref.indices) >= 0.999
 
 
+# ---------------------------------------------------------------------------
+# K2 on Float32 corpora through the scaled-f16 SHADOW (scan path 3): the f16 MFMA kernel only selects, the kept
+# rows are re-scored from the f32 rows -- results must be those of the exact paths
+# ---------------------------------------------------------------------------
+
+@pytest.mark.parametrize("metric", [0, 1, 2])
+@pytest.mark.parametrize("shape", [(20000, 768, 200, 100), (5000, 100, 33, 10), (300, 64, 128, 500), (9000, 36, 40, 1),
+                                   (4097, 128, 32, 64)])
+def test_batched_f32_shadow_path(oracle, metric, shape):
+    n, dim, nq, k = shape
+    rows = oracle.synth_rows(SEED, 0, n, dim, 0)
+    q = oracle.synth_queries(SEED + 1, nq, dim, 0)
+    q[0] *= 1e6
+    q[1] *= 1e-9
+    with G.GpuCorpus.from_array(rows, index_base=77) as c:
+        c.set_scan_path(3)
+        c.set_profiling(True)
+        res = c.search(q, k, metric)
+        assert c.last_timing().scan_kernel == 4       # the shadow really ran
+        c.set_profiling(False)
+        c.set_scan_path(2)
+        exact = c.search(q, k, metric)                # exact f32 MFMA kernel
+    for i in range(nq):
+        sc, _, _ = oracle.scores(rows, 0, metric, q[i])
+        assert_float_topk(metric, res.scores[i], res.indices[i], sc, rows, q[i], k, 77)
+    assert recall_at_k(res.indices, exact.indices) >= 0.999
+
+
+def test_batched_f32_shadow_row_dynamic_range(oracle):
+    """Rows spanning 60 orders of magnitude, elements far below their row's largest, zero rows, and rows holding
+    Inf / NaN: every row is scaled by its own power of two before it is rounded to f16, and whatever the shadow
+    loses the re-scoring restores."""
+    n, dim, nq, k = 12000, 96, 36, 25
+    rng = np.random.default_rng(21)
+    rows = oracle.synth_rows(SEED, 0, n, dim, 0)
+    rows *= (10.0 ** rng.uniform(-30, 30, n)).astype(np.float32)[:, None]
+    rows[::11, ::3] *= 1e-7                       # tiny elements next to large ones
+    rows[5] = 0.0
+    rows[17, 3] = np.inf
+    rows[23, 0] = np.nan
+    rows[29] = 1.0e35                             # sum x^2 overflows, the dot products do not
+    q = oracle.synth_queries(SEED + 1, nq, dim, 0)
+    for metric in (2, 1, 0):
+        with G.GpuCorpus.from_array(rows) as c:
+            c.set_scan_path(3)
+            res = c.search(q, k, metric)
+        for i in range(nq):
+            sc, _, _ = oracle.scores(rows, 0, metric, q[i])
+            assert_float_topk(metric, res.scores[i], res.indices[i], sc, rows, q[i], k)
+
+
+@pytest.mark.parametrize("metric", [0, 1, 2])
+@pytest.mark.parametrize("cluster", [300, 3000])
+def test_batched_f32_shadow_dense_cluster_at_the_kth_rank(oracle, metric, cluster):
+    """As the Float16 case below: score gaps inside the cluster are far smaller than the shadow's error bound
+    (2^-10 |q||x|), so the cluster either rides in the margin and is re-scored, or overflows the candidate
+    budget and the query is repaired by the streaming kernel."""
+    n, dim, nq, k = 20000, 192, 40, 50
+    rows = oracle.synth_rows(SEED, 0, n, dim, 0)
+    rng = np.random.default_rng(12)
+    base = rng.standard_normal(dim).astype(np.float32)
+    where = rng.choice(n, cluster, replace=False)
+    rows[where] = base * 0.5 + rng.standard_normal((cluster, dim)).astype(np.float32) * 1.5e-3
+    q = (base[None, :] + rng.standard_normal((nq, dim)).astype(np.float32) * 1e-2).astype(np.float32)
+    with G.GpuCorpus.from_array(rows) as c:
+        c.set_scan_path(3)
+        res = c.search(q, k, metric)
+    members = set(where.tolist())
+    for i in range(nq):
+        sc, _, _ = oracle.scores(rows, 0, metric, q[i])
+        assert_float_topk(metric, res.scores[i], res.indices[i], sc, rows, q[i], k)
+        assert set(res.indices[i].tolist()) <= members
+
+
 def test_batched_path_single_query_forced(oracle):
     rows = oracle.synth_rows(SEED, 0, 3000, 96, 0)
     q = oracle.synth_queries(SEED + 1, 1, 96, 0)
