@@ -268,6 +268,18 @@ int search_stream_path(const mvfgpu_corpus* c, uint8_t metric, const void* d_que
 }
 
 
+// The f16/int8 MFMA kernel: scan_mfma16_dma.hip (LDS-DMA ring, 16x16 MFMA shape) by default; MVF_K2_DMA=0 selects the
+// register-staged scan_mfma16.hip (kept as the A/B reference: same results, ~7 % slower).
+bool k2_dma_enabled() {
+    const char* e = getenv("MVF_K2_DMA");
+    return !e || atoi(e) != 0;
+}
+
+bool k2_dma_persistent(uint8_t) {  // measured: int8 15 % and f16 5 % faster with one persistent block per CU
+    if (const char* e = getenv("MVF_K2_PERSISTENT16")) return atoi(e) != 0;
+    return true;
+}
+
 // ---- scaled-f16 shadow of a Float32 corpus (selection only) -----------------------------------------------------
 uint32_t shadow_pitch(uint32_t dim) { return (dim * 2u + 15u) & ~15u; }
 
@@ -321,18 +333,22 @@ int search_batched_path(const mvfgpu_corpus* c, uint8_t metric, const void* d_qu
     const unsigned char* krows = use_shadow ? static_cast<const unsigned char*>(c->shadow.p) : c->d_rows;
     const uint32_t kpitch = use_shadow ? shadow_pitch(c->dim) : c->pitch;
     const uint32_t tile_rows = wide ? 128u : 256u;
-    const uint32_t qpb = wide ? 128u : scan_mfma16_queries_per_block(kdtype);  // queries per block tile
+    const bool dma = !wide && k2_dma_enabled();            // LDS-DMA kernel (default) or the register-staged one
+    const uint32_t qpb = wide ? 128u : dma ? scan_mfma16_dma_queries_per_block() : scan_mfma16_queries_per_block(kdtype);
     const uint32_t nq_pad = (nq + qpb - 1u) / qpb * qpb;
-    const uint32_t KT = wide ? (c->dim + 31u) / 32u : (c->dim * elem_size(kdtype) + 127u) / 128u;
-    const uint32_t KPB = KT * 128u;                        // prepared query row, bytes (both layouts use 128-B k-tiles)
+    const uint32_t ktb = dma ? 64u : 128u;                  // k-tile bytes of the f16/int8 kernel in use
+    const uint32_t KT = wide ? (c->dim + 31u) / 32u : (c->dim * elem_size(kdtype) + ktb - 1u) / ktb;
+    const uint32_t KPB = KT * ktb;                         // prepared query row, bytes
     const uint32_t planes = 1u;
     const uint32_t cap = kBatchCap;
     const uint32_t n = (uint32_t)c->n;
 
-    HIP_TRY(c->bq.reserve((size_t)planes * nq_pad * KPB + (size_t)nq_pad * 8));
+    HIP_TRY(c->bq.reserve((size_t)planes * nq_pad * KPB + (size_t)nq_pad * 8 + 64));
     unsigned char* qprep = static_cast<unsigned char*>(c->bq.p);
     float* qaux0 = reinterpret_cast<float*>(qprep + (size_t)planes * nq_pad * KPB);
     float* qaux1 = qaux0 + nq_pad;
+    unsigned char* zeros = reinterpret_cast<unsigned char*>(qaux1 + nq_pad);  // 64 zero bytes
+    HIP_TRY(hipMemsetAsync(zeros, 0, 64, s));
     if (c->bstate_slots < nq_pad) {
         HIP_TRY(c->bstate.reserve((size_t)nq_pad * 12));
         HIP_TRY(hipMemsetAsync(c->bstate.p, 0xFF, (size_t)nq_pad * 4, s));                                  // tau
@@ -392,6 +408,7 @@ int search_batched_path(const mvfgpu_corpus* c, uint8_t metric, const void* d_qu
     hp.qaux1 = qaux1;
     hp.rows = krows;
     hp.xscale = use_shadow ? static_cast<const float*>(c->xscale.p) : nullptr;
+    hp.zeros = zeros;
     hp.xnorm_f = static_cast<const float*>(c->xnorm.p);
     hp.xnorm_i = static_cast<const int32_t*>(c->xnorm.p);
     hp.xbias_i = c->xnorm.p ? static_cast<const int32_t*>(c->xnorm.p) + nn : nullptr;
@@ -455,6 +472,7 @@ int search_batched_path(const mvfgpu_corpus* c, uint8_t metric, const void* d_qu
             bp.direct = hp.direct = (begin == 0 && end - begin <= cap) ? 1u : 0u;
             if (ps && last) HIP_TRY(hipEventRecord(ps->e[0], s));
             if (wide) HIP_TRY(launch_scan_mfma_f32(bp, metric, c->num_cus, s));
+            else if (dma) HIP_TRY(launch_scan_mfma16_dma(hp, kdtype, metric, c->num_cus, k2_dma_persistent(kdtype), s));
             else HIP_TRY(launch_scan_mfma16(hp, kdtype, metric, c->num_cus, s));
             if (ps && last) {
                 HIP_TRY(hipEventRecord(ps->e[1], s));
@@ -508,6 +526,7 @@ int search_batched_path(const mvfgpu_corpus* c, uint8_t metric, const void* d_qu
         for (uint32_t q = 0; q < nq; q++)
             if (flags[q]) redo.push_back(q);
         const size_t nf = redo.size();
+        if (getenv("MVF_DEBUG_REPAIR")) fprintf(stderr, "[mvfgpu] K2 overflow repair: %zu of %u queries redone by K1\n", nf, nq);
         const size_t qbytes = (size_t)c->dim * (is_int_dtype(c->dtype) ? 1u : 4u);
         const size_t qarea = (nf * qbytes + 15u) & ~(size_t)15u, nres = nf * k;
         HIP_TRY(c->repair.reserve(qarea + nres * 16));

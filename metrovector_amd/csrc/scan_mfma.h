@@ -37,6 +37,7 @@ struct Batch16Params {
     const float* xx2;            // [n] f16 rows: sum x^2 (batched L2)
     const float* xxmax;          // [1] max over rows of sum x^2
     const float* xscale;         // [n] or NULL: rows are the scaled-f16 shadow of a Float32 corpus, row r times xscale[r]
+    const unsigned char* zeros;  // >= 16 zero bytes (LDS-DMA kernel: source of k beyond a row's pitch)
     const int32_t* xnorm_i;      // [n] int rows: sum x^2 (UInt8: of the shifted values x-128)
     const int32_t* xbias_i;      // [n] UInt8 rows: 128 * sum (x-128)
     uint32_t dim;
@@ -44,7 +45,7 @@ struct Batch16Params {
     uint64_t* cand;
     uint32_t* cnt;
     uint32_t pitch, V;
-    uint32_t KPB, KT;            // padded row bytes of qprep, k-tiles of 128 bytes
+    uint32_t KPB, KT;            // padded row bytes of qprep, k-tiles (128 bytes; 64 for the LDS-DMA kernel)
     uint32_t nq, nq_pad;
     uint32_t row_begin, row_end;
     uint32_t ntiles, mtiles;     // ceil(rows/256), nq_pad / queries-per-block
@@ -103,6 +104,8 @@ hipError_t launch_rescore(const RescoreParams& p, int metric, uint32_t nq, hipSt
 
 uint32_t scan_mfma16_queries_per_block(int dtype);
 hipError_t launch_scan_mfma16(const Batch16Params& p, int dtype, int metric, int num_cus, hipStream_t s);
+uint32_t scan_mfma16_dma_queries_per_block();
+hipError_t launch_scan_mfma16_dma(const Batch16Params& p, int dtype, int metric, int num_cus, bool persistent, hipStream_t s);
 hipError_t launch_prep_queries16(const void* q, int dtype, uint32_t nq, uint32_t nq_pad, uint32_t dim, uint32_t KPB,
                                  unsigned char* qprep, float* qaux0, float* qaux1, hipStream_t s);
 hipError_t launch_shadow_f16(const unsigned char* rows32, uint32_t n, uint32_t pitch32, uint32_t dim, unsigned char* rows16,

@@ -1,4 +1,5 @@
-// scan_mfma16.hip — K2 for the narrow types: Float16 rows on
+// scan_mfma16.hip — K2 for the narrow types, REGISTER-STAGED variant (MVF_K2_DMA=0; the default is the LDS-DMA
+// ring of scan_mfma16_dma.hip, same results, ~7 % faster — this one is kept as its A/B reference): Float16 rows on
 // v_mfma_f32_32x32x16_f16 and Int8 rows on v_mfma_i32_32x32x32_i8.  Both
 // instructions take 16 bytes per lane per operand, so staging, LDS image and
 // fragment fetches are byte-identical; only the MFMA, the accumulator type and
@@ -40,35 +41,12 @@
 namespace mvf {
 namespace {
 
-typedef _Float16 half8 __attribute__((ext_vector_type(8)));
-typedef int i32x4 __attribute__((ext_vector_type(4)));
-typedef int i32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+#include "scan_mfma16_common.inc"
 
-constexpr int AROWS = 256, BROWS = 256;     // LDS rows per operand tile
 constexpr int BKB = 128;                    // k-tile bytes per row
 constexpr int LDPB = BKB + 16;              // padded LDS row pitch in bytes
 constexpr int TILE_B = AROWS * LDPB;        // bytes per operand tile per stage
 constexpr size_t kLds16 = (size_t)4 * TILE_B + 4 * 256 * 4;  // stages + qaux0 + tau + qaux1 + prefilter
-
-template <int DT> struct T16;
-template <> struct T16<MVF_DTYPE_FLOAT16> {
-    static constexpr int PLANES = 1, IT = 4;  // i-tiles (32 queries) per wave
-    using Acc = f32x16;
-};
-template <> struct T16<MVF_DTYPE_INT8> {
-    static constexpr int PLANES = 1, IT = 4;
-    using Acc = i32x16;
-};
-// UInt8 rows ride the SIGNED int8 MFMA shifted by 128 (x_s = x_u - 128 = x_u ^ 0x80 as int8, same for q):
-//   dot_u = dot_s + 128 (Sq_s + Sx_s) + 16384 d,   L2_u = qq_s + xx_s - 2 dot_s (shift invariant),
-//   qq_u = qq_s + 256 Sq_s + 16384 d,  xx_u likewise — all exact integers, so the results stay bit-identical to
-//   K1's v_dot4_u32_u8 path.  Per row K4 stores xx_s and bx = 128 Sx_s; per query qq_s and cqq = 128 Sq_s + 16384 d.
-template <> struct T16<MVF_DTYPE_UINT8> {
-    static constexpr int PLANES = 1, IT = 4;
-    using Acc = i32x16;
-};
 
 // DIRECT = the phase-0 instantiation (rows <= cap, no threshold yet): every (query, row) pair is a candidate and its
 // slot is the row's offset -- no pre-filter, no counter.  A separate instantiation so the steady-state variants
@@ -108,45 +86,7 @@ __global__ void __launch_bounds__(512, 2) scan_mfma16_kernel(Batch16Params p) {
     if (my_tiles == 0) return;
     const uint32_t G = my_tiles * p.KT;
 
-    auto load_query_consts = [&](uint32_t q0) {
-        if (tid < BMQ) {
-            const float qa = p.qaux0[q0 + tid], qb = p.qaux1[q0 + tid];
-            const uint32_t tau = p.tau[q0 + tid];
-            qa_s[tid] = qa;
-            qb_s[tid] = qb;
-            tau_s[tid] = tau;
-            // Pre-filter threshold in ACCUMULATOR units (see scan_mfma.hip): a superset test, one or two ops per score.
-            if constexpr (DT == MVF_DTYPE_FLOAT16) {
-                const float ts = score_from_key(tau, METRIC);
-                if (METRIC == MVF_METRIC_L2) {
-                    // batched L2 selects on s2 = qq + xx - 2 dot, dot = acc * 2^-e (exact distances are re-scored
-                    // afterwards); tau holds ord(thr).  s2 <= thr  <=>  acc * 2^(1-e) - xx >= qq - thr.
-                    const float qq = qb * qb;
-                    const float cq = qq - ts;
-                    thr_s[tid] = cq - fabsf(cq) * 2e-6f - (qq + p.xxmax[0]) * 4e-7f;
-                } else {
-                    // score = acc * 2^-e [/ (|q||x|)] >= ts  <=>  acc [* 1/|x|] >= ts [* |q|] * 2^e
-                    const float tq = (METRIC == MVF_METRIC_COSINE ? ts * qb : ts) / qa;
-                    thr_s[tid] = tq - fabsf(tq) * 2e-6f;
-                }
-            } else {
-                const int32_t qq = __float_as_int(qa);   // sum q^2 (UInt8: of the shifted query)
-                const int32_t cqq = __float_as_int(qb);  // UInt8: 128 Sq_s + 16384 d (>= 0); Int8: 0
-                if (METRIC == MVF_METRIC_INNER_PRODUCT) {
-                    // dot_u = acc + bx + cqq >= traw  <=>  acc + bx >= traw - cqq   (exact; clamp the "no threshold" case)
-                    const int32_t traw = raw_from_key(tau, METRIC);
-                    thr_s[tid] = __int_as_float(traw < INT32_MIN + cqq ? INT32_MIN : traw - cqq);
-                } else if (METRIC == MVF_METRIC_L2) {
-                    thr_s[tid] = __int_as_float(qq - raw_from_key(tau, METRIC));       // 2 dot - xx >= qq - traw (exact)
-                } else {
-                    const float ts = score_from_key(tau, METRIC);
-                    const int32_t qqu = U8 ? qq + 2 * cqq - 16384 * (int32_t)p.dim : qq;
-                    const float tq = ts * sqrtf((float)qqu);                           // dot * 1/|x| >= ts * |q|
-                    thr_s[tid] = tq - fabsf(tq) * 2e-6f;
-                }
-            }
-        }
-    };
+    auto load_query_consts = [&](uint32_t q0) { load_query_consts16<DT, METRIC>(p, q0, tid, qa_s, qb_s, tau_s, thr_s); };
 
     // ---- staging: thread -> 16-B chunk (row sr + 64*i, column sc) of each tile ----------
     // Branch-free loads: rows past row_end re-read a valid row (their output columns are discarded in the epilogue);
@@ -284,126 +224,8 @@ __global__ void __launch_bounds__(512, 2) scan_mfma16_kernel(Batch16Params p) {
         }
     };
 
-    // ---- epilogue of one finished tile (C/D map: col = lane&31 -> corpus row, row = (e&3)+8*(e>>2)+4*(lane>>5) -> query)
-    // Fast path: one or two ops + a compare per score against the per-query pre-filter; the exact key and the
-    // atomic append run only for 32x32 tiles where the wave-wide ballot found a candidate (rare).
     auto epilogue = [&](uint32_t nt, uint32_t mt) __attribute__((always_inline)) {
-        const uint32_t q0 = mt * BMQ, r0 = p.row_begin + nt * BROWS;
-        // keep this address arithmetic inside the epilogue (hoisted out of the k-tile loop it costs VGPRs there)
-        int lane_q = wm * (BMQ / 2) + 4 * fh, lane_r = wn * 64 + fr;
-        asm volatile("" : "+v"(lane_q), "+v"(lane_r));
-#pragma unroll
-        for (int j = 0; j < 2; j++) {
-            const uint32_t r = r0 + lane_r + j * 32;
-            const bool rok = r < p.row_end;
-            float xnf = 0.f, rx = 1.f, xxf = 0.f, rs = 1.f;
-            int32_t xxi = 0, bx = 0, xxu = 0;  // xxi: sum x^2 (UInt8: shifted); bx: UInt8 128 Sx_s; xxu: UInt8 sum x_u^2
-            if (rok) {
-                if constexpr (DT == MVF_DTYPE_FLOAT16) {
-                    if (METRIC == MVF_METRIC_COSINE) xnf = p.xnorm_f[r];
-                    if (METRIC == MVF_METRIC_L2) xxf = p.xx2[r];
-                    if constexpr (XS) rs = p.xscale[r];
-                } else {
-                    if (METRIC != MVF_METRIC_INNER_PRODUCT) xxi = p.xnorm_i[r];
-                    if (U8 && METRIC != MVF_METRIC_L2) bx = p.xbias_i[r];
-                }
-            }
-            if (U8) xxu = xxi + 2 * bx + 16384 * (int32_t)p.dim;
-            if (METRIC == MVF_METRIC_COSINE) {
-                if constexpr (DT == MVF_DTYPE_FLOAT16) rx = xnf > 0.0f ? rs * __builtin_amdgcn_rcpf(xnf) : 0.0f;
-                else if (U8) rx = xxu > 0 ? __builtin_amdgcn_rcpf(sqrtf((float)xxu)) : 0.0f;
-                else rx = xxi > 0 ? __builtin_amdgcn_rcpf(sqrtf((float)xxi)) : 0.0f;
-            }
-            const unsigned long long rokmask = __builtin_amdgcn_ballot_w64(rok);
-            const int32_t nxxi = -xxi;
-            // pre-filter test of accumulator element (i, 4g+t) against its query's threshold
-            auto passes = [&](int i, int g, int t, const u32x4& th4, const u32x4& sc4) __attribute__((always_inline)) -> bool {
-                if constexpr (DT == MVF_DTYPE_FLOAT16) {
-                    const float a = XS && METRIC != MVF_METRIC_COSINE ? acc[i][j][4 * g + t] * rs : acc[i][j][4 * g + t];
-                    const float y = METRIC == MVF_METRIC_COSINE ? a * rx
-                                    : METRIC == MVF_METRIC_L2   ? fmaf(a, 2.0f * __uint_as_float(sc4[t]), -xxf)
-                                                                : a;
-                    return !(y < __uint_as_float(th4[t]));
-                } else if (METRIC == MVF_METRIC_INNER_PRODUCT) {
-                    return acc[i][j][4 * g + t] + bx >= (int32_t)th4[t];
-                } else if (METRIC == MVF_METRIC_L2) {
-                    return (acc[i][j][4 * g + t] << 1) + nxxi >= (int32_t)th4[t];
-                } else {
-                    return !((float)(acc[i][j][4 * g + t] + bx + (int32_t)sc4[t]) * rx < __uint_as_float(th4[t]));
-                }
-            };
-            auto load_thr = [&](int i, int g, u32x4& th4, u32x4& sc4) __attribute__((always_inline)) {
-                th4 = *reinterpret_cast<const u32x4*>(thr_s + lane_q + i * 32 + 8 * g);
-                sc4 = u32x4{0, 0, 0, 0};
-                if (DT == MVF_DTYPE_FLOAT16 && METRIC == MVF_METRIC_L2)
-                    sc4 = *reinterpret_cast<const u32x4*>(qa_s + lane_q + i * 32 + 8 * g);  // 2^-e per query
-                if (U8 && METRIC == MVF_METRIC_COSINE)
-                    sc4 = *reinterpret_cast<const u32x4*>(qb_s + lane_q + i * 32 + 8 * g);  // cqq per query
-            };
-#pragma unroll
-            for (int i = 0; i < IT; i++) {
-                // Wave-level test first: each compare lands in an SGPR pair and the OR runs on the scalar unit, so a
-                // score costs the compare (plus its one or two arithmetic ops) of vector work.  Per-lane masks are
-                // only built for the rare 32x32 sub-tiles where some lane passed.
-                unsigned long long any = 0;
-#pragma unroll
-                for (int g = 0; g < 4; g++) {
-                    u32x4 th4, sc4;
-                    load_thr(i, g, th4, sc4);
-#pragma unroll
-                    for (int t = 0; t < 4; t++) any |= __builtin_amdgcn_ballot_w64(passes(i, g, t, th4, sc4));
-                }
-                if (DIRECT) any = ~0ull;
-                if ((any & rokmask) != 0) {  // wave-uniform: rare
-                    uint32_t m = 0;
-#pragma unroll
-                    for (int g = 0; g < 4; g++) {
-                        u32x4 th4, sc4;
-                        load_thr(i, g, th4, sc4);
-#pragma unroll
-                        for (int t = 0; t < 4; t++) m |= (passes(i, g, t, th4, sc4) ? 1u : 0u) << (4 * g + t);
-                    }
-                    if (DIRECT) m = 0xFFFFu;
-                    if (!rok) m = 0;
-#pragma unroll
-                    for (int e = 0; e < 16; e++) {
-                        if (m & (1u << e)) {
-                            const int ql = lane_q + i * 32 + (e & 3) + 8 * (e >> 2);
-                            uint32_t key;
-                            if constexpr (DT == MVF_DTYPE_FLOAT16) {
-                                float sc_ = acc[i][j][e] * qa_s[ql];  // undo the power-of-two query scale (exact)
-                                if constexpr (XS) sc_ *= rs;            // ... and the shadow row's
-                                if (METRIC == MVF_METRIC_COSINE) {
-                                    const float den = qb_s[ql] * xnf;
-                                    sc_ = den > 0.0f ? sc_ / den : 0.0f;
-                                }
-                                if (METRIC == MVF_METRIC_L2) sc_ = qb_s[ql] * qb_s[ql] + xxf - 2.0f * sc_;  // GEMM-form s2
-                                key = key_from_score(sc_, METRIC);
-                            } else {
-                                const int32_t qq = __float_as_int(qa_s[ql]);
-                                const int32_t cqq = __float_as_int(qb_s[ql]);
-                                const int32_t dot = U8 ? acc[i][j][e] + bx + cqq : acc[i][j][e];  // dot in the space's own domain
-                                if (METRIC == MVF_METRIC_L2) {
-                                    key = key_from_raw(qq + xxi - 2 * acc[i][j][e], METRIC);  // shift invariant
-                                } else if (METRIC == MVF_METRIC_INNER_PRODUCT) {
-                                    key = key_from_raw(dot, METRIC);
-                                } else {
-                                    const int32_t qqn = U8 ? qq + 2 * cqq - 16384 * (int32_t)p.dim : qq;
-                                    const int32_t xxn = U8 ? xxu : xxi;
-                                    const float den = sqrtf((float)qqn) * sqrtf((float)xxn);
-                                    key = key_from_score(den > 0.0f ? (float)dot / den : 0.0f, METRIC);
-                                }
-                            }
-                            const uint32_t q = q0 + ql;
-                            if (q < p.nq && (DIRECT || key <= tau_s[ql])) {
-                                const uint32_t slot_i = DIRECT ? r - p.row_begin : atomicAdd(&p.cnt[q], 1u);
-                                if (slot_i < p.cap) p.cand[(size_t)q * p.cap + slot_i] = ((uint64_t)key << 32) | r;
-                            }
-                        }
-                    }
-                }
-            }
-        }
+        epilogue16<DT, METRIC, DIRECT, XS, BMQ, 32>(p, acc, nt, mt, wm, wn, lane, qa_s, qb_s, tau_s, thr_s);
     };
 
     // one flat k-tile g; rb holds B k-tile g+1 on entry and receives B k-tile g+3.  The LDS stores of k-tile g+1 and

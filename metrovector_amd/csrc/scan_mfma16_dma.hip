@@ -1,0 +1,268 @@
+// scan_mfma16_dma.hip — K2 for the narrow types with LDS-DMA staging.
+//
+// Same tile, MFMAs, persistent XCD-aware schedule and epilogue as scan_mfma16.hip (which stages through registers);
+// what differs is how the operands reach LDS.  The register-staged kernel spends ~830 of ~3600 cycles per 128-B
+// k-tile on the VGPR->LDS store path alone (ds_write_b128 moves ~79 B/clk/CU) plus the waits in front of it.  Here
+// every operand byte goes global -> LDS directly (global_load_lds_dwordx4, no VGPRs, no ds_write):
+//
+//   * k-tile = 64 bytes per row (64 int8 / 32 f16) = the k of one 16x16 MFMA; stage = 256 A rows + 256 B rows x 64 B = 32 KB;
+//     a RING of 4 stages (128 KB).  During k-tile g the block computes stage g & 3 and issues the DMA of k-tile g + 3
+//     into the stage freed by the barrier that ended k-tile g - 1; before the next barrier each wave waits for its
+//     own pieces of k-tile g + 1 with a COUNTED s_waitcnt vmcnt(8): two k-tiles (64 KB per CU) stay in flight
+//     across the barrier, which is what a streamed (HBM-latency) operand needs.
+//   * one DMA wave-instruction writes 1 KB contiguously (16 rows x 64 B, lane L -> row L>>2, slot L&3), so the LDS
+//     image cannot be padded; it is XOR-swizzled instead: slot = chunk ^ swz((row >> 2) & 3), applied on the per-lane
+//     SOURCE address here and on the fragment reads (conflict-free for ds_read_b128's lane groups).
+//   * k beyond a row's pitch must read zeros (0 x Inf would poison a Float16 dot): such chunks are fetched from a
+//     16-byte zero block instead (p.zeros); rows past row_end re-read the tile's first row (columns discarded).
+//   * UInt8's x ^ 0x80 happens on the B fragments after the LDS read.
+//
+// MFMA shape: v_mfma_f32_16x16x32_f16 / v_mfma_i32_16x16x64_i8 -- one MFMA consumes the whole 64-B k of a fragment
+// pair.  Same LDS bytes and matrix-pipe cycles per k-tile as the 32x32 shapes, but this loop is POWER-limited (the
+// matrix pipe is ~50 % busy at ~1.8 GHz whatever the staging: the clock falls as the MFMAs pack closer) and the chip
+// holds a higher clock on the 16x16 shape: +7 % wall.  Measured alternatives that did not pay are in DESIGN.md.
+//
+// Hazards: RAW — a wave's vmcnt wait covers only its own DMA pieces, the barrier after it publishes everyone's;
+// the data is first read in the NEXT k-tile.  WAR — a stage is re-filled only after the barrier that ends the k-tile
+// which read it.  No ordinary global load is in flight inside the k-loop (the epilogue's are consumed inside it).
+
+#include "scan_mfma.h"
+
+#include "mvf_common.h"
+
+#include <hip/hip_fp16.h>
+
+#include <cstdlib>
+#include <type_traits>
+
+namespace mvf {
+namespace {
+
+#include "scan_mfma16_common.inc"
+
+constexpr int DKB = 64;                       // k-tile bytes per row
+
+struct Cf {
+    static constexpr int NW = 8;                                // waves per block, as 2 (queries) x 4 (rows)
+    static constexpr int BMQ = 256;                             // queries (A rows) per block
+    static constexpr int NSTAGE = 4;
+    static constexpr int A_B = BMQ * DKB;                       // bytes of A per stage
+    static constexpr int STAGE_B = A_B + BROWS * DKB;           // A then B
+    static constexpr int APW = BMQ / 16 / NW;                   // 1-KB DMA pieces per wave per k-tile: A
+    static constexpr int BPW = BROWS / 16 / NW;                 //                                      B
+    static constexpr int PIECES = APW + BPW;
+    static constexpr int INFLIGHT = PIECES * (NSTAGE - 2);      // pieces left in flight across the barrier
+    static constexpr size_t LDS = (size_t)NSTAGE * STAGE_B + 4 * BMQ * 4;  // ring + qaux0 + tau + qaux1 + prefilter
+};
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* glb_ptr_t;
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int SH = 16;  // MFMA sub-tile: a wave's 128 x 64 outputs are 8 x 4 of them
+
+// XOR swizzle of the 16-B slot by x = (row >> 2) & 3.  A fragment read takes lane -> (row lane & 15, chunk lane >> 4);
+// ds_read_b128 is served in 16-lane groups {0-3,12-15,20-27}, {4-11,16-19,28-31}, ... and the permutation {0, 2, 3, 1}
+// makes each group touch 16 distinct (row & 3, slot) pairs (SQ_LDS_BANK_CONFLICT = 0).
+__device__ __forceinline__ uint32_t slot_swz(uint32_t x) { return (0x78u >> (2u * x)) & 3u; }
+
+template <int DT, int METRIC, bool DIRECT, bool XS>
+__global__ void __launch_bounds__(512, 2) scan_mfma16_dma_kernel(Batch16Params p) {
+    using AccT = typename std::conditional<DT == MVF_DTYPE_FLOAT16, f32x4, i32x4>::type;
+    constexpr int NW = Cf::NW, NI = 128 / SH, NJ = 64 / SH, NE = SH * SH / 64;
+    constexpr int BMQ = Cf::BMQ, NSTAGE = Cf::NSTAGE, STAGE_B = Cf::STAGE_B, OPER_B = Cf::A_B;  // OPER_B: B's offset in a stage
+    constexpr bool U8 = DT == MVF_DTYPE_UINT8;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* qa_s = reinterpret_cast<float*>(smem + NSTAGE * STAGE_B);  // [BMQ] f16: 2^-e / i8: qq (as int)
+    uint32_t* tau_s = reinterpret_cast<uint32_t*>(qa_s + BMQ);        // [BMQ]
+    float* qb_s = reinterpret_cast<float*>(tau_s + BMQ);              // [BMQ] f16: |q|
+    float* thr_s = qb_s + BMQ;                                        // [BMQ] pre-filter threshold
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+
+    // persistent blocks, XCD-aware tile order (scan_mfma16.hip)
+    const uint32_t xcd = blockIdx.x & 7u, ls = blockIdx.x >> 3, nls = gridDim.x >> 3;
+    auto slot_tile = [&](uint32_t n, uint32_t& nt, uint32_t& mt) {
+        const uint32_t slot = ls + n * nls;
+        nt = (slot / p.mtiles) * 8u + xcd;
+        mt = slot % p.mtiles;
+    };
+    uint32_t my_tiles = 0;
+    {
+        const uint32_t max_slot_excl = ((p.ntiles + 7u - xcd) / 8u) * p.mtiles;
+        if (ls < max_slot_excl) my_tiles = (max_slot_excl - ls + nls - 1) / nls;
+    }
+    if (my_tiles == 0) return;
+    const uint32_t G = my_tiles * p.KT;
+
+    // ---- DMA: 1-KB pieces (16 rows x 64 B); wave w fills A pieces [w APW, (w+1) APW) and B pieces [w BPW, (w+1) BPW) ----
+    const uint32_t rl = (uint32_t)lane >> 2;                              // row inside a piece
+    const uint32_t cl = ((uint32_t)lane & 3u) ^ slot_swz(((uint32_t)lane >> 4) & 3u);  // source chunk: slot ^ swz((row >> 2) & 3)
+    uint32_t d_n = 0, d_kt = 0;  // DMA cursor: (tile ordinal, k-tile) of the next stage to fill
+    const unsigned char* a_src[Cf::APW];  // per lane: its row of the cursor tile's queries, + chunk offset
+    const unsigned char* b_src[Cf::BPW];  // per lane: its corpus row (clamped), without the chunk offset
+    auto set_dma_tile = [&](uint32_t n) {
+        uint32_t nt, mt;
+        slot_tile(n, nt, mt);
+        const uint32_t r0 = p.row_begin + nt * BROWS;
+#pragma unroll
+        for (int j = 0; j < Cf::APW; j++)
+            a_src[j] = p.qprep + ((size_t)mt * BMQ + ((uint32_t)wave * Cf::APW + j) * 16u + rl) * p.KPB + cl * 16u;
+#pragma unroll
+        for (int j = 0; j < Cf::BPW; j++) {
+            const uint32_t r = r0 + ((uint32_t)wave * Cf::BPW + j) * 16u + rl;
+            b_src[j] = p.rows + (size_t)(r < p.row_end ? r : r0) * p.pitch;
+        }
+    };
+    // In the k-loop the pieces are issued after the groups of four MFMAs, so the address path works underneath the
+    // matrix pipe instead of in a lump after the barrier.
+    auto dma_piece = [&](uint32_t stage, int piece) __attribute__((always_inline)) {
+        unsigned char* st = smem + stage * STAGE_B;
+        if (piece < Cf::APW) {
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)(a_src[piece] + (size_t)d_kt * DKB),
+                                             (lds_ptr_t)(st + (wave * Cf::APW + piece) * (16 * DKB)), 16, 0, 0);
+        } else {
+            const int j = piece - Cf::APW;
+            const uint32_t v = d_kt * 4u + cl;  // 16-B vector of the row
+            const unsigned char* src = v < p.V ? b_src[j] + (size_t)v * 16u : p.zeros;
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)(st + OPER_B + (wave * Cf::BPW + j) * (16 * DKB)), 16, 0, 0);
+        }
+    };
+    auto dma_advance = [&]() __attribute__((always_inline)) {  // cursors clamp on the block's last tile
+        if (++d_kt == p.KT) {
+            d_kt = 0;
+            if (++d_n < my_tiles) set_dma_tile(d_n);
+        }
+    };
+    auto dma_ktile = [&](uint32_t stage) {
+#pragma unroll
+        for (int piece = 0; piece < Cf::PIECES; piece++) dma_piece(stage, piece);
+        dma_advance();
+    };
+
+    AccT acc[NI][NJ];
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int i = 0; i < NI; i++)
+#pragma unroll
+            for (int j = 0; j < NJ; j++)
+#pragma unroll
+                for (int e = 0; e < NE; e++) acc[i][j][e] = 0;
+    };
+    zero_acc();
+
+    uint32_t c_n = 0, c_kt = 0, c_nt, c_mt;  // compute cursor
+    slot_tile(0, c_nt, c_mt);
+    load_query_consts16<DT, METRIC, Cf::BMQ>(p, c_mt * BMQ, tid, qa_s, qb_s, tau_s, thr_s);
+
+    set_dma_tile(0);
+#pragma unroll
+    for (int st = 0; st < NSTAGE - 1; st++) dma_ktile(st);
+    __builtin_amdgcn_s_waitcnt(0x0F70 | Cf::INFLIGHT);  // vmcnt(INFLIGHT): k-tile 0 has landed (this wave's pieces)
+    __syncthreads();                                    // also publishes the query constants
+
+    static_assert(Cf::INFLIGHT < 16, "vmcnt low field");
+    // fragment addressing: lane reads row base + (lane & 15), chunk lane >> 4, at slot = chunk ^ swz((row >> 2) & 3)
+    const uint32_t frow = (uint32_t)lane & (SH - 1);
+    const uint32_t fchunk = (uint32_t)lane >> 4;
+    const uint32_t fslot = (fchunk ^ slot_swz((frow >> 2) & 3u)) & 3u;
+    const uint32_t a_off = ((uint32_t)wm * 128u + frow) * DKB + fslot * 16u;
+    const uint32_t b_off = OPER_B + ((uint32_t)wn * 64u + frow) * DKB + fslot * 16u;
+    auto read_a = [&](const unsigned char* st, int i) __attribute__((always_inline)) -> u32x4 {
+        return *reinterpret_cast<const u32x4*>(st + a_off + i * SH * DKB);
+    };
+    auto read_b = [&](const unsigned char* st, int j) __attribute__((always_inline)) -> u32x4 {
+        u32x4 x = *reinterpret_cast<const u32x4*>(st + b_off + j * SH * DKB);
+        if (U8) x ^= u32x4{0x80808080u, 0x80808080u, 0x80808080u, 0x80808080u};  // x_u -> x_s
+        return x;
+    };
+    auto mfma1 = [&](AccT& c, const u32x4& fa, const u32x4& fb) __attribute__((always_inline)) {
+        if constexpr (DT == MVF_DTYPE_FLOAT16)
+            c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, fa), __builtin_bit_cast(half8, fb), c, 0, 0, 0);
+        else
+            c = __builtin_amdgcn_mfma_i32_16x16x64_i8(__builtin_bit_cast(i32x4, fa), __builtin_bit_cast(i32x4, fb), c, 0, 0, 0);
+    };
+
+    uint32_t cs = 0, ds = NSTAGE - 1;  // compute stage (k-tile g), DMA target (k-tile g + NSTAGE - 1: the stage g - 1 read)
+    for (uint32_t g = 0; g < G; g++) {
+        const unsigned char* st = smem + cs * STAGE_B;
+        // eight groups of four MFMAs (one A fragment x four B fragments each, the whole 64-B k in one MFMA); the
+        // next group's A fragment is read while this group's MFMAs run; DMA pieces follow the even groups
+        u32x4 fb[4], fa[2];
+#pragma unroll
+        for (int j = 0; j < 4; j++) fb[j] = read_b(st, j);
+        fa[0] = read_a(st, 0);
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            if (i + 1 < 8) fa[(i + 1) & 1] = read_a(st, i + 1);
+#pragma unroll
+            for (int j = 0; j < 4; j++) mfma1(acc[i][j], fa[i & 1], fb[j]);
+            if ((i & 1) == 0) dma_piece(ds, i / 2);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        dma_advance();
+        cs = cs + 1 == NSTAGE ? 0 : cs + 1;
+        ds = ds + 1 == NSTAGE ? 0 : ds + 1;
+        if (++c_kt == p.KT) {  // tile finished: its successor's first k-tiles are already in the ring
+            epilogue16<DT, METRIC, DIRECT, XS, BMQ, SH>(p, acc, c_nt, c_mt, wm, wn, lane, qa_s, qb_s, tau_s, thr_s);
+            zero_acc();
+            c_kt = 0;
+            if (++c_n < my_tiles) {
+                uint32_t nmt;
+                slot_tile(c_n, c_nt, nmt);
+                if (nmt != c_mt) {  // block-uniform; rare
+                    __syncthreads();
+                    load_query_consts16<DT, METRIC, Cf::BMQ>(p, nmt * BMQ, tid, qa_s, qb_s, tau_s, thr_s);
+                    c_mt = nmt;
+                }
+            }
+        }
+        // k-tile g + 1 must have landed; the younger k-tile(s) stay in flight across the barrier
+        __builtin_amdgcn_s_waitcnt(0x0070 | Cf::INFLIGHT);  // vmcnt(INFLIGHT) lgkmcnt(0)
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    }
+    // the DMAs issued for k-tiles past the end target this block's own LDS: let them land before the wave exits
+    __builtin_amdgcn_s_waitcnt(0x0070 | 0x0F00);  // vmcnt(0)
+}
+
+template <int DT, int METRIC>
+hipError_t launch_dtm(const Batch16Params& p, dim3 grid, hipStream_t s) {
+    void (*fn)(Batch16Params) = p.direct ? &scan_mfma16_dma_kernel<DT, METRIC, true, false> : &scan_mfma16_dma_kernel<DT, METRIC, false, false>;
+    if constexpr (DT == MVF_DTYPE_FLOAT16)
+        if (p.xscale) fn = p.direct ? &scan_mfma16_dma_kernel<DT, METRIC, true, true> : &scan_mfma16_dma_kernel<DT, METRIC, false, true>;
+    // > 64 KiB of dynamic LDS needs the attribute; it is per device, and one process may drive several devices
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cf::LDS);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(fn, grid, dim3(Cf::NW * 64), Cf::LDS, s, p);
+    return hipGetLastError();
+}
+
+template <int DT>
+hipError_t launch_dt(const Batch16Params& p, int metric, dim3 grid, hipStream_t s) {
+    switch (metric) {
+    case MVF_METRIC_L2: return launch_dtm<DT, MVF_METRIC_L2>(p, grid, s);
+    case MVF_METRIC_INNER_PRODUCT: return launch_dtm<DT, MVF_METRIC_INNER_PRODUCT>(p, grid, s);
+    default: return launch_dtm<DT, MVF_METRIC_COSINE>(p, grid, s);
+    }
+}
+
+}  // namespace
+
+uint32_t scan_mfma16_dma_queries_per_block() { return Cf::BMQ; }
+
+// p.KPB / p.KT are in 64-byte k-tiles here; p.zeros points at >= 16 zero bytes; p.mtiles = nq_pad / 256.
+hipError_t launch_scan_mfma16_dma(const Batch16Params& p, int dtype, int metric, int num_cus, bool persistent, hipStream_t s) {
+    const uint32_t total = ((p.ntiles + 7) / 8) * p.mtiles * 8;
+    uint32_t nls = std::max(1u, (uint32_t)num_cus / 8u);
+    if (nls > p.mtiles) nls -= nls % p.mtiles;
+    const dim3 grid(persistent ? std::min(total, nls * 8u) : total);
+    if (dtype == MVF_DTYPE_FLOAT16) return launch_dt<MVF_DTYPE_FLOAT16>(p, metric, grid, s);
+    if (dtype == MVF_DTYPE_UINT8) return launch_dt<MVF_DTYPE_UINT8>(p, metric, grid, s);
+    return launch_dt<MVF_DTYPE_INT8>(p, metric, grid, s);
+}
+
+}  // namespace mvf
