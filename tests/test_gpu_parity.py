@@ -421,6 +421,25 @@ def test_batched_f32_shadow_dense_cluster_at_the_kth_rank(oracle, metric, cluste
         assert set(res.indices[i].tolist()) <= members
 
 
+@pytest.mark.parametrize("dtype,metric", [(1, 2), (1, 0), (2, 1), (3, 0), (0, 2)])
+def test_batched_register_staged_reference_kernel_agrees(oracle, dtype, metric, monkeypatch):
+    """MVF_K2_DMA=0 selects the register-staged f16/int8 MFMA kernel (the A/B reference of the default LDS-DMA
+    ring): both must return the same top-k -- bit-identical on integer spaces, identical after the exact
+    re-scoring on float spaces (dtype 0 runs the f16 kernel on the shadow of the f32 rows)."""
+    n, dim, nq, k = 30000, 200, 70, 40
+    rows = oracle.synth_rows(SEED, 0, n, dim, dtype)
+    q = oracle.synth_queries(SEED + 1, nq, dim, dtype)
+    with G.GpuCorpus.from_array(rows) as c:
+        c.set_scan_path(3)
+        monkeypatch.setenv("MVF_K2_DMA", "0")
+        ref = c.search(q, k, metric)
+        monkeypatch.delenv("MVF_K2_DMA")
+        res = c.search(q, k, metric)
+    assert (res.indices == ref.indices).all()
+    assert (res.scores.view(np.uint32) == ref.scores.view(np.uint32)).all()
+    assert (res.raw == ref.raw).all()
+
+
 def test_batched_path_single_query_forced(oracle):
     rows = oracle.synth_rows(SEED, 0, 3000, 96, 0)
     q = oracle.synth_queries(SEED + 1, 1, 96, 0)
