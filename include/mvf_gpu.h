@@ -167,9 +167,9 @@ int mvfgpu_search(const mvfgpu_corpus* corpus, uint8_t metric,
  * This is the timed region of bench.py and the producer of the per-shard
  * lists that RCCL all-gathers.  d_raw may be NULL.
  * Small batches run the streaming kernel and return without waiting (below
- * 32 queries on corpora under 1 GiB; on larger ones below 2 queries for
- * Float16 and shadowed Float32, 8 for Float32 without the shadow, 5 for
- * Int8/UInt8 — the measured crossovers; one query always streams).  Larger
+ * 32 queries on corpora under 1 GiB; on larger ones below 5 queries, or 9
+ * for Float32 without the f16 shadow — the measured crossovers: the
+ * streaming kernel takes up to 4 queries per pass over the rows).  Larger
  * batches run the MFMA path, whose
  * last step reads back per-query overflow flags (an adversarially ordered
  * corpus can overflow a candidate buffer; such queries are redone exactly by

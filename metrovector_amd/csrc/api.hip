@@ -560,17 +560,14 @@ bool use_batched_path(const mvfgpu_corpus* c, uint8_t metric, uint32_t nq) {
         supported = false;  // the re-scoring kernel keeps the query in LDS
     if (!supported) return false;
     if (c->scan_path >= 2) return true;
-    // K1 takes 2..4 queries per HBM pass (8.4 / 9.8 / 8.7 ms on 10M x 768 f32 / 12.5M x 1024 f16 / 50M x 768 int8);
-    // K2 costs a flat padded-tile time up to 128 / 256 queries (f32 kernel 16 ms, f16 kernel 6.4 ms on the f32
-    // corpus' shadow and 8.2 ms on the f16 corpus, int8 14 ms) plus ~0.2 ms of phase launches and the final flag
+    // K1 takes 2..4 queries per HBM pass (5.8 / 6.4 / 7.5 ms on 10M x 768 f32 / 12.5M x 1024 f16 / 50M x 768 int8);
+    // K2 costs a flat padded-tile time up to 128 / 256 queries (f32 kernel 15.3 ms, f16 kernel 6.4 ms on the f32
+    // corpus' shadow and 7.4 ms on the f16 corpus, int8 13.8 ms) plus ~0.2 ms of phase launches and the final flag
     // read-back: measured crossovers on >= 1 GiB of rows; small corpora keep K1 until the batch is MFMA-sized.
     const uint64_t bytes = c->n * (uint64_t)c->dim * elem_size(c->dtype);
     const bool shadowed = c->dtype == MVF_DTYPE_FLOAT32 && shadow_enabled() && c->shadow_state >= 0 &&  // runs as Float16
                           (size_t)((c->dim + 7u) & ~7u) * 4 + kBatchCap * 4 <= 64 * 1024;
-    const uint32_t threshold = bytes < (1ull << 30)                           ? 32u
-                               : c->dtype == MVF_DTYPE_FLOAT32 && !shadowed ? 8u
-                               : is_int_dtype(c->dtype)                     ? 5u
-                                                                            : 2u;
+    const uint32_t threshold = bytes < (1ull << 30) ? 32u : c->dtype == MVF_DTYPE_FLOAT32 && !shadowed ? 9u : 5u;
     return nq >= threshold;
 }
 
