@@ -440,6 +440,33 @@ def test_batched_register_staged_reference_kernel_agrees(oracle, dtype, metric, 
     assert (res.raw == ref.raw).all()
 
 
+@pytest.mark.parametrize("dtype", [0, 1, 2, 3])
+def test_batched_odd_shapes_sweep(oracle, dtype):
+    """The MFMA kernels pad everything (rows to 16 B, k to 64-B k-tiles, queries to the 256-query tile, rows to
+    256-row tiles): sweep dimensions that are not multiples of any of those -- down to one element -- with row
+    counts and batch sizes on both sides of the tile edges.  Float32 goes through the f16 shadow (path 3)."""
+    rng = np.random.default_rng(1234 + dtype)
+    dims = [1, 2, 7, 8, 15, 17, 31, 33, 63, 65, 100, 127, 129, 200, 257]
+    for dim in dims:
+        n = int(rng.choice([255, 256, 257, 1000, 4097, 5003]))
+        nq = int(rng.choice([32, 33, 255, 256, 257]))
+        k = int(rng.choice([1, 7, 64, 100]))
+        metric = int(rng.integers(0, 3))
+        rows = oracle.synth_rows(SEED + dim, 0, n, dim, dtype)
+        q = oracle.synth_queries(SEED + 1 + dim, nq, dim, dtype)
+        with G.GpuCorpus.from_array(rows) as c:
+            c.set_scan_path(3)
+            res = c.search(q, k, metric)
+        if dtype in (2, 3):
+            osc, oidx, oraw = oracle.search(rows, dtype, metric, q, k)
+            assert_exact(res, osc, oidx, oraw)
+        else:
+            rows32 = rows.astype(np.float32)
+            for i in range(0, nq, 7):
+                sc, _, _ = oracle.scores(rows, dtype, metric, q[i])
+                assert_float_topk(metric, res.scores[i], res.indices[i], sc, rows32, q[i], k)
+
+
 def test_batched_path_single_query_forced(oracle):
     rows = oracle.synth_rows(SEED, 0, 3000, 96, 0)
     q = oracle.synth_queries(SEED + 1, 1, 96, 0)
