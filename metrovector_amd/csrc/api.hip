@@ -283,7 +283,7 @@ bool k2_dma_persistent(uint8_t) {  // measured: int8 15 % and f16 5 % faster wit
 // ---- scaled-f16 shadow of a Float32 corpus (selection only) -----------------------------------------------------
 uint32_t shadow_pitch(uint32_t dim) { return (dim * 2u + 15u) & ~15u; }
 
-bool shadow_enabled() {  // MVF_F16_SHADOW=0 keeps Float32 corpora on the exact f32 MFMA kernel
+bool shadow_enabled() {  // MVF_F16_SHADOW=0 keeps Float32 corpora on the exact f32 MFMA kernel (scan path 3 overrides)
     const char* e = getenv("MVF_F16_SHADOW");
     return !e || atoi(e) != 0;
 }
@@ -324,7 +324,7 @@ int search_batched_path(const mvfgpu_corpus* c, uint8_t metric, const void* d_qu
     // f32 rows and the f32 query either way, so results do not depend on which one ran.
     bool use_shadow = false;
     const bool rescore_fits = (size_t)((c->dim + 7u) & ~7u) * 4 + kBatchCap * 4 <= 64 * 1024;  // query + candidates in LDS
-    if (c->dtype == MVF_DTYPE_FLOAT32 && c->scan_path != 2 && shadow_enabled() && rescore_fits) {
+    if (c->dtype == MVF_DTYPE_FLOAT32 && c->scan_path != 2 && (c->scan_path == 3 || shadow_enabled()) && rescore_fits) {
         HIP_TRY(ensure_shadow(c, s));
         use_shadow = c->shadow_state == 1;
     }
@@ -565,7 +565,7 @@ bool use_batched_path(const mvfgpu_corpus* c, uint8_t metric, uint32_t nq) {
     // corpus' shadow and 7.4 ms on the f16 corpus, int8 13.8 ms) plus ~0.2 ms of phase launches and the final flag
     // read-back: measured crossovers on >= 1 GiB of rows; small corpora keep K1 until the batch is MFMA-sized.
     const uint64_t bytes = c->n * (uint64_t)c->dim * elem_size(c->dtype);
-    const bool shadowed = c->dtype == MVF_DTYPE_FLOAT32 && shadow_enabled() && c->shadow_state >= 0 &&  // runs as Float16
+    const bool shadowed = c->dtype == MVF_DTYPE_FLOAT32 && (c->scan_path == 3 || shadow_enabled()) && c->shadow_state >= 0 &&  // runs as Float16
                           (size_t)((c->dim + 7u) & ~7u) * 4 + kBatchCap * 4 <= 64 * 1024;
     const uint32_t threshold = bytes < (1ull << 30) ? 32u : c->dtype == MVF_DTYPE_FLOAT32 && !shadowed ? 9u : 5u;
     return nq >= threshold;
