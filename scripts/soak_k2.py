@@ -1,0 +1,41 @@
+"""Determinism soak of the batched (K2) kernels at full size (development aid).
+
+An LDS-DMA stage read before its data landed passes any single comparison whenever the DMA happens to win the
+race; it shows up as rare run-to-run differences.  For each config: N searches must return bit-identical
+(scores, indices, raw), and the register-staged reference kernel (MVF_K2_DMA=0) must return the same."""
+import hashlib, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from oracle import mvf_oracle as O
+from metrovector_amd import gpu as G
+
+REPS = int(sys.argv[1]) if len(sys.argv) > 1 else 25
+CONFIGS = [  # rows, dim, dtype, metric, nq
+    (50_000_000, 768, 2, 1, 256),      # cfg4
+    (12_500_000, 1024, 1, 0, 1024),    # cfg5 shard
+    (10_000_000, 768, 0, 2, 1024),     # cfg3 (f16 shadow)
+    (3_000_000, 200, 3, 2, 300),       # uint8 cosine, odd dim
+    (2_000_001, 96, 1, 1, 777),        # f16 dot, ragged
+]
+def digest(r):
+    h = hashlib.sha256()
+    for a in (r.scores, r.indices, r.raw):
+        h.update(np.ascontiguousarray(a).tobytes())
+    return h.hexdigest()
+bad = 0
+for (n, dim, dt, metric, nq) in CONFIGS:
+    c = G.GpuCorpus.synthetic(n, dim, dt, 0x4D564631)
+    q = O.synth_queries(0x4D564632, nq, dim, dt)
+    t0 = time.time()
+    ds = set()
+    for i in range(REPS):
+        ds.add(digest(c.search(q, 100, metric)))
+    os.environ["MVF_K2_DMA"] = "0"
+    ref = digest(c.search(q, 100, metric))
+    del os.environ["MVF_K2_DMA"]
+    ok = len(ds) == 1 and ref in ds
+    bad += not ok
+    print(f"n={n} dim={dim} dt={dt} metric={metric} nq={nq}: {REPS} runs -> {len(ds)} distinct digest(s); "
+          f"register-staged kernel {'agrees' if ref in ds else 'DIFFERS'}  [{time.time()-t0:.1f} s]  {'OK' if ok else 'FAIL'}", flush=True)
+    c.close()
+sys.exit(1 if bad else 0)

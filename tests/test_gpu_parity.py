@@ -467,6 +467,23 @@ def test_batched_odd_shapes_sweep(oracle, dtype):
                 assert_float_topk(metric, res.scores[i], res.indices[i], sc, rows32, q[i], k)
 
 
+@pytest.mark.parametrize("dtype,metric", [(2, 1), (1, 2), (0, 0)])
+def test_batched_results_are_deterministic(oracle, dtype, metric):
+    """The LDS-DMA kernel reads a stage only after a counted wait and a barrier; a read that raced its DMA would
+    pass a single comparison whenever the DMA happened to win.  Repeated searches must be bit-identical
+    (scripts/soak_k2.py does the same at full size, hundreds of times)."""
+    n, dim, nq, k = 1_500_000, 256, 300, 50
+    with G.GpuCorpus.synthetic(n, dim, dtype, SEED) as c:
+        q = oracle.synth_queries(SEED + 1, nq, dim, dtype)
+        c.set_scan_path(3)
+        first = c.search(q, k, metric)
+        for _ in range(12):
+            r = c.search(q, k, metric)
+            assert (r.indices == first.indices).all()
+            assert (r.scores.view(np.uint32) == first.scores.view(np.uint32)).all()
+            assert (r.raw == first.raw).all()
+
+
 def test_batched_path_single_query_forced(oracle):
     rows = oracle.synth_rows(SEED, 0, 3000, 96, 0)
     q = oracle.synth_queries(SEED + 1, 1, 96, 0)
