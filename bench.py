@@ -281,9 +281,12 @@ def main():
                            "ms_per_step": eb / bsteps * 1e3}
                     if tmb.samples and tmb.scan_ms_avg > 0 and tmb.scan_kernel >= 2:
                         leg["roofline"] = mfma_roofline(tmb, args.dtype)
-                        tp = os.path.join(ROOT, "profiles", "r01_bench_n1_q1024_hbm_traffic.json")
-                        if tmb.scan_kernel == 2 and os.path.exists(tp):
+                        # HBM bytes per launch from the committed PMC passes of this exact workload and kernel
+                        tp = os.path.join(ROOT, "profiles", {2: "r01_bench_n1_q1024_hbm_traffic.json",
+                                                             4: "r01_bench_n1_q1024_shadow_hbm_traffic.json"}.get(tmb.scan_kernel, "-"))
+                        if os.path.exists(tp):
                             leg["roofline"]["traffic"] = json.load(open(tp))["roofline_traffic_bytes_per_launch"]
+                            leg["roofline"]["traffic_source"] = "profiles/" + os.path.basename(tp)
                     if oidx is not None:
                         gi = outb[1].cpu().numpy().view(np.uint64)[sel]
                         leg["recall_at_k"] = sum(len(set(a.tolist()) & set(b.tolist())) for a, b in zip(gi, oidx)) / oidx.size
