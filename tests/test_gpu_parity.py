@@ -484,6 +484,26 @@ def test_batched_results_are_deterministic(oracle, dtype, metric):
             assert (r.raw == first.raw).all()
 
 
+@pytest.mark.parametrize("dtype,metric", [(0, 2), (1, 0), (2, 1), (3, 2)])
+def test_batched_max_k(oracle, dtype, metric):
+    """k = MVFGPU_MAX_K = 1024: the per-query candidate budget (4096 slots per phase, 2048 carried) is at its
+    tightest and the phases grow only 2x at a time."""
+    n, dim, nq, k = 150_000, 64, 40, 1024
+    rows = oracle.synth_rows(SEED, 0, n, dim, dtype)
+    q = oracle.synth_queries(SEED + 1, nq, dim, dtype)
+    with G.GpuCorpus.from_array(rows) as c:
+        c.set_scan_path(3)
+        res = c.search(q, k, metric)
+    if dtype in (2, 3):
+        osc, oidx, oraw = oracle.search(rows, dtype, metric, q, k)
+        assert_exact(res, osc, oidx, oraw)
+    else:
+        rows32 = rows.astype(np.float32)
+        for i in range(0, nq, 5):
+            sc, _, _ = oracle.scores(rows, dtype, metric, q[i])
+            assert_float_topk(metric, res.scores[i], res.indices[i], sc, rows32, q[i], k)
+
+
 def test_batched_path_single_query_forced(oracle):
     rows = oracle.synth_rows(SEED, 0, 3000, 96, 0)
     q = oracle.synth_queries(SEED + 1, 1, 96, 0)
