@@ -1,4 +1,5 @@
-"""One batched int8 search for profiling (development aid)."""
+"""Two batched searches of cfg4 (50M x 768 int8 dot, 256 queries; argv[1] = 2, default) or of a cfg5 shard
+(12.5M x 1024 f16 L2, 1024 queries; argv[1] = 1), quiet, for rocprofv3 (the profiles/r01_cfg4_* / r01_cfg5_* files)."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle import mvf_oracle as O
