@@ -62,7 +62,8 @@ typedef struct mvfgpu_corpus_info {
     uint8_t data_type;    /* enum mvf_data_type */
     uint8_t reserved[3];
     int32_t device;
-    uint64_t device_bytes; /* HBM held by the handle (rows + norms + scratch) */
+    uint64_t device_bytes; /* HBM held by the handle: rows, norms, scratch and, once a batched search has built
+                              it, the f16 shadow of a Float32 corpus */
 } mvfgpu_corpus_info;
 
 typedef struct mvfgpu_timing {

@@ -142,6 +142,7 @@ int validate_shape(uint64_t n, uint32_t dim, uint8_t dtype) {
     if (dim == 0) return fail(MVF_ERR_INVALID_ARGUMENT, "dimension must be > 0");
     if (is_int_dtype(dtype) && dim > MVFGPU_MAX_INT_DIM)
         return fail(MVF_ERR_BUILD, "Int8/UInt8 dimension exceeds the exact-i32 bound (33025)");
+    if ((uint64_t)dim * elem_size(dtype) > (1ull << 30)) return fail(MVF_ERR_INVALID_ARGUMENT, "a row holds at most 1 GiB");
     if (n >= 0xFFFFFFFFull) return fail(MVF_ERR_INVALID_ARGUMENT, "a shard holds at most 2^32-2 rows");
     return MVF_OK;
 }
@@ -291,6 +292,7 @@ bool shadow_enabled() {  // MVF_F16_SHADOW=0 keeps Float32 corpora on the exact 
 // Built on the first batched search (like the row norms): +50 % of the corpus' HBM.  In automatic mode it is skipped
 // when that would leave less than 2 GiB free on the device; scan path 3 insists.
 hipError_t ensure_shadow(const mvfgpu_corpus* c, hipStream_t s) {
+    if (c->shadow_state == -1 && c->scan_path == 3) c->shadow_state = 0;  // skipped automatically earlier: try now
     if (c->shadow_state != 0) return hipSuccess;
     const size_t need = (size_t)std::max<uint64_t>(c->n, 1) * shadow_pitch(c->dim);
     if (c->scan_path != 3) {
@@ -766,8 +768,9 @@ int mvfgpu_corpus_get_info(const mvfgpu_corpus* c, mvfgpu_corpus_info* out) {
     out->data_type = c->dtype;
     out->device = c->device;
     std::lock_guard<std::mutex> lk(c->mu);
-    out->device_bytes = c->rows_bytes + c->cand.bytes + c->bq.bytes + c->bstate.bytes + c->bcand.bytes + c->xnorm.bytes + c->h_q.bytes +
-                        c->h_s.bytes + c->h_i.bytes + c->h_r.bytes;
+    out->device_bytes = c->rows_bytes + c->cand.bytes + c->bq.bytes + c->bstate.bytes + c->bcand.bytes + c->xnorm.bytes +
+                        c->repair.bytes + c->shadow.bytes + c->xscale.bytes + c->h_q.bytes + c->h_s.bytes + c->h_i.bytes +
+                        c->h_r.bytes;
     return MVF_OK;
 }
 

@@ -74,6 +74,8 @@ def test_argument_validation_precedes_device_use():
         G.GpuCorpus.from_pointer(rows.ctypes.data, 1, 40000, 2, 40000)
     with pytest.raises(E.CorruptedData):
         G.GpuCorpus.from_pointer(rows.ctypes.data, 4, 4, 0, 8)                # stride < row bytes
+    with pytest.raises(E.InvalidArgument, match="1 GiB"):
+        G.GpuCorpus.from_pointer(rows.ctypes.data, 1, 1 << 30, 0, 1 << 32)    # dim * 4 would overflow 32 bits
 
 
 @pytest.mark.parametrize("dtype,metric", [(0, 0), (0, 1), (0, 2), (2, 1), (3, 0), (2, 2)])

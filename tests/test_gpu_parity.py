@@ -504,6 +504,25 @@ def test_batched_max_k(oracle, dtype, metric):
             assert_float_topk(metric, res.scores[i], res.indices[i], sc, rows32, q[i], k)
 
 
+def test_device_bytes_accounts_for_the_f16_shadow(oracle):
+    """mvfgpu_corpus_get_info.device_bytes is what a caller budgets HBM with: the shadow a batched search builds for a
+    Float32 corpus (+50 %: dim*2 bytes per row rounded up to 16, plus 4 bytes of scale per row) must show up in it."""
+    n, dim = 40_000, 100
+    rows = oracle.synth_rows(SEED, 0, n, dim, 0)
+    q = oracle.synth_queries(SEED + 1, 64, dim, 0)
+    with G.GpuCorpus.from_array(rows) as c:
+        before = c.info().device_bytes
+        assert before >= n * 400
+        c.set_scan_path(2)
+        c.search(q, 10, G.COSINE)
+        exact_only = c.info().device_bytes
+        c.set_scan_path(3)
+        c.search(q, 10, G.COSINE)
+        with_shadow = c.info().device_bytes
+    assert with_shadow - exact_only >= n * (208 + 4)      # pitch16 = 208 B for 100 halves
+    assert exact_only > before                            # norms + K2 scratch
+
+
 def test_batched_path_single_query_forced(oracle):
     rows = oracle.synth_rows(SEED, 0, 3000, 96, 0)
     q = oracle.synth_queries(SEED + 1, 1, 96, 0)
