@@ -77,9 +77,9 @@ typedef struct mvfgpu_timing {
     float scan_ms_avg;   /* mean over the (up to 64) newest profiled searches */
     float select_ms_avg;
     uint32_t samples;    /* searches averaged */
-    uint32_t scan_kernel; /* 1 = streaming (K1); MFMA batched (K2): 2 = f32 kernel on Float32 rows,
-                             3 = f16/int8 kernel on the stored rows, 4 = f16 kernel on the f16 shadow of a
-                             Float32 corpus */
+    uint32_t scan_kernel; /* 1 = streaming (K1) on the stored rows, 5 = K1 on the f16 shadow of a Float32
+                             corpus (scan path 4); MFMA batched (K2): 2 = f32 kernel on Float32 rows,
+                             3 = f16/int8 kernel on the stored rows, 4 = f16 kernel on the f16 shadow */
     uint32_t scan_launches; /* scan launches of one search (timing covers the first) */
     uint64_t scan_bytes; /* algorithmic bytes one scan launch reads */
     uint64_t scan_flops; /* algorithmic flops of one scan launch (2*nq*rows*dim) */
@@ -230,7 +230,12 @@ int mvfgpu_last_timing(const mvfgpu_corpus* corpus, mvfgpu_timing* out);
 /* Force a scan path for A/B measurements and tests: 0 = automatic,
  * 1 = streaming kernel (K1) for every nq, 2 = MFMA batched kernel (K2) on the
  * stored rows, 3 = K2 with the f16 shadow on Float32 corpora (same as 2 on
- * the other types).
+ * the other types), 4 = as 0, but one or two queries on a Float32 corpus
+ * STREAM THE F16 SHADOW instead of the stored rows (half the bytes, so about
+ * half the time; same proven-margin selection and exact re-scoring as the
+ * batched path, hence the same results; synchronous; also enabled by
+ * MVF_STREAM_SHADOW=1 in the environment).  Off by default: the default
+ * single-query path reads the stored f32 rows and returns asynchronously.
  *
  * The f16 shadow: batched searches on a Float32 corpus select candidates with
  * the f16 MFMA kernel on a scaled-f16 copy of the rows (built on the first

@@ -175,16 +175,31 @@ const void* scan_kernel(uint8_t dtype, int metric, int G, int nqv) {
     }
 }
 
+// Streaming over the scaled-f16 shadow of a Float32 corpus (scan path 4): K1 reads the shadow rows instead of the stored
+// ones and hands the k best COMPOSITES per query to the margin compaction instead of formatting results.
+struct ShadowStream {
+    const unsigned char* rows;
+    const float* xscale;
+    uint32_t pitch, V, J;
+    int G;
+    uint64_t* cand;   // [nq][cand_cap]
+    uint32_t* cnt;    // [nq]
+    uint32_t cand_cap;
+};
+
 int search_stream_path(const mvfgpu_corpus* c, uint8_t metric, const void* d_queries, uint32_t nq, uint32_t k,
-                       float* d_scores, uint64_t* d_indices, int32_t* d_raw, hipStream_t s, bool profile = true) {
+                       float* d_scores, uint64_t* d_indices, int32_t* d_raw, hipStream_t s, bool profile = true,
+                       const ShadowStream* alt = nullptr) {
     const uint32_t kcap = next_pow2(k);
-    const int G = c->G;
+    const int G = alt ? alt->G : c->G;
+    const uint32_t J = alt ? alt->J : c->J;
+    const uint8_t kdtype = alt ? (uint8_t)MVF_DTYPE_FLOAT16 : c->dtype;
     const uint32_t chunk_rows = scan_chunk_rows(G);
     const uint32_t nchunks = (uint32_t)((c->n + chunk_rows - 1) / chunk_rows);
     const uint32_t pmax = next_pow2(k + chunk_rows);
 
     mvfgpu_timing tm{};
-    tm.scan_kernel = 1;
+    tm.scan_kernel = alt ? 5u : 1u;
     bool first = true;
     mvfgpu_corpus::ProfSlot* ps = nullptr;
     if (c->profiling && profile) {
@@ -195,18 +210,18 @@ int search_stream_path(const mvfgpu_corpus* c, uint8_t metric, const void* d_que
     }
 
     for (uint32_t q0 = 0; q0 < nq;) {
-        int nqv = (nq - q0) >= 2 ? 4 : 1;
-        size_t lds = scan_lds_bytes(c->dtype, G, c->J, nqv, pmax);
+        int nqv = (nq - q0) >= 2 && !alt ? 4 : 1;
+        size_t lds = scan_lds_bytes(kdtype, G, J, nqv, pmax);
         if (nqv == 4 && lds > 150 * 1024) {
             nqv = 1;
-            lds = scan_lds_bytes(c->dtype, G, c->J, nqv, pmax);
+            lds = scan_lds_bytes(kdtype, G, J, nqv, pmax);
         }
         if (lds > 160 * 1024) return fail(MVF_ERR_BUILD, "dimension too large for the streaming kernel's LDS query tile");
         const uint32_t nq_here = std::min<uint32_t>(nqv, nq - q0);
 
         uint32_t nblocks = 0;
         if (nchunks > 0) {
-            const void* kfn = scan_kernel(c->dtype, metric, G, nqv);
+            const void* kfn = alt ? scan_stream_kernel_ptr_dt1x(metric, G, nqv) : scan_kernel(c->dtype, metric, G, nqv);
             if (lds > 48 * 1024)
                 HIP_TRY(hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             int occ = 0;
@@ -216,14 +231,15 @@ int search_stream_path(const mvfgpu_corpus* c, uint8_t metric, const void* d_que
             HIP_TRY(c->cand.reserve((size_t)nq_here * nblocks * kcap * 8));
 
             ScanParams sp{};
-            sp.rows = c->d_rows;
+            sp.rows = alt ? alt->rows : c->d_rows;
+            sp.xscale = alt ? alt->xscale : nullptr;
             sp.queries = d_queries;
             sp.cand = static_cast<uint64_t*>(c->cand.p);
             sp.n = (uint32_t)c->n;
-            sp.pitch = c->pitch;
+            sp.pitch = alt ? alt->pitch : c->pitch;
             sp.dim = c->dim;
-            sp.V = c->V;
-            sp.J = c->J;
+            sp.V = alt ? alt->V : c->V;
+            sp.J = J;
             sp.q0 = q0;
             sp.nq_total = nq;
             sp.k = k;
@@ -232,11 +248,12 @@ int search_stream_path(const mvfgpu_corpus* c, uint8_t metric, const void* d_que
             sp.chunk_rows = chunk_rows;
             sp.nchunks = nchunks;
             if (ps && first) HIP_TRY(hipEventRecord(ps->e[0], s));
-            HIP_TRY(scan_launch(c->dtype, sp, metric, G, nqv, dim3(nblocks), lds, s));
+            if (alt) HIP_TRY(scan_stream_launch_dt1x(sp, metric, G, nqv, dim3(nblocks), lds, s));
+            else HIP_TRY(scan_launch(c->dtype, sp, metric, G, nqv, dim3(nblocks), lds, s));
             if (ps && first) {
                 HIP_TRY(hipEventRecord(ps->e[1], s));
                 ps->scanned = true;
-                tm.scan_bytes = (uint64_t)c->n * c->dim * elem_size(c->dtype);
+                tm.scan_bytes = (uint64_t)c->n * c->dim * elem_size(kdtype);
                 tm.scan_flops = 2ull * nq_here * c->n * c->dim;
             }
             tm.scan_launches++;
@@ -252,9 +269,15 @@ int search_stream_path(const mvfgpu_corpus* c, uint8_t metric, const void* d_que
             fp.metric = metric;
             fp.dtype = c->dtype;
             fp.index_base = c->index_base;
-            fp.out_scores = d_scores + (size_t)q0 * k;
-            fp.out_indices = d_indices + (size_t)q0 * k;
-            fp.out_raw = d_raw ? d_raw + (size_t)q0 * k : nullptr;
+            if (alt) {
+                fp.out_cand = alt->cand + (size_t)q0 * alt->cand_cap;
+                fp.out_cnt = alt->cnt + q0;
+                fp.cand_cap = alt->cand_cap;
+            } else {
+                fp.out_scores = d_scores + (size_t)q0 * k;
+                fp.out_indices = d_indices + (size_t)q0 * k;
+                fp.out_raw = d_raw ? d_raw + (size_t)q0 * k : nullptr;
+            }
             HIP_TRY(launch_select_final(fp, nq_here, s));
         }
         if (ps && first) HIP_TRY(hipEventRecord(ps->e[2], s));
@@ -289,13 +312,13 @@ bool shadow_enabled() {  // MVF_F16_SHADOW=0 keeps Float32 corpora on the exact 
     return !e || atoi(e) != 0;
 }
 
-// Built on the first batched search (like the row norms): +50 % of the corpus' HBM.  In automatic mode it is skipped
-// when that would leave less than 2 GiB free on the device; scan path 3 insists.
-hipError_t ensure_shadow(const mvfgpu_corpus* c, hipStream_t s) {
-    if (c->shadow_state == -1 && c->scan_path == 3) c->shadow_state = 0;  // skipped automatically earlier: try now
+// Built on the first search that wants it (like the row norms): +50 % of the corpus' HBM.  Unless the caller insists
+// (scan paths 3 and 4) it is skipped when that would leave less than 2 GiB free on the device.
+hipError_t ensure_shadow(const mvfgpu_corpus* c, hipStream_t s, bool insist) {
+    if (c->shadow_state == -1 && insist) c->shadow_state = 0;  // skipped automatically earlier: try now
     if (c->shadow_state != 0) return hipSuccess;
     const size_t need = (size_t)std::max<uint64_t>(c->n, 1) * shadow_pitch(c->dim);
-    if (c->scan_path != 3) {
+    if (!insist) {
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < need + ((size_t)2 << 30)) {
             c->shadow_state = -1;
@@ -315,6 +338,70 @@ hipError_t ensure_shadow(const mvfgpu_corpus* c, hipStream_t s) {
     return e;
 }
 
+// K2 per-query state (threshold key, candidate count, overflow flag), armed once and re-armed by the kernels that end
+// a search.
+int ensure_bstate(const mvfgpu_corpus* c, uint32_t nq_pad, hipStream_t s) {
+    if (c->bstate_slots >= nq_pad) return MVF_OK;
+    HIP_TRY(c->bstate.reserve((size_t)nq_pad * 12));
+    HIP_TRY(hipMemsetAsync(c->bstate.p, 0xFF, (size_t)nq_pad * 4, s));                                                    // tau
+    HIP_TRY(hipMemsetAsync(static_cast<unsigned char*>(c->bstate.p) + (size_t)nq_pad * 4, 0, (size_t)nq_pad * 8, s));  // cnt, overflow
+    c->bstate_slots = nq_pad;
+    return MVF_OK;
+}
+
+// K4: per-row norms of the STORED rows, once per resident corpus (a shadow only feeds the dot products).
+// float rows: |x| [n], sum x^2 [n], max sum x^2 [1]; Int8 rows: sum x^2 (i32) [n]; UInt8 rows: sum (x-128)^2 [n],
+// 128 * sum (x-128) [n]
+int ensure_norms(const mvfgpu_corpus* c, hipStream_t s) {
+    if (c->xnorm_ready) return MVF_OK;
+    const uint32_t n = (uint32_t)c->n;
+    const size_t nn = std::max<uint32_t>(n, 1);
+    HIP_TRY(c->xnorm.reserve((2 * nn + 1) * 4));
+    float* xn = static_cast<float*>(c->xnorm.p);
+    if (!is_int_dtype(c->dtype)) HIP_TRY(hipMemsetAsync(xn + 2 * nn, 0, 4, s));
+    if (c->dtype == MVF_DTYPE_FLOAT32) HIP_TRY(launch_row_norms_f32(c->d_rows, n, c->pitch, xn, xn + nn, xn + 2 * nn, s));
+    else HIP_TRY(launch_row_norms16(c->d_rows, c->dtype, n, c->pitch, c->dim, c->xnorm.p, xn + nn, xn + 2 * nn, s));
+    c->xnorm_ready = true;
+    return MVF_OK;
+}
+
+// Queries whose candidate budget overflowed (or whose margin reached past a truncated list) are redone exactly by K1 on
+// the stored rows: the flags are read back (host sync), the flagged queries gathered so that K1 takes them four per pass.
+int repair_flagged_queries(const mvfgpu_corpus* c, uint8_t metric, const void* d_queries, uint32_t nq, uint32_t nq_pad,
+                           uint32_t k, uint32_t* overflow, float* d_scores, uint64_t* d_indices, int32_t* d_raw,
+                           hipStream_t s) {
+    std::vector<uint32_t> flags(nq);
+    HIP_TRY(hipMemcpyAsync(flags.data(), overflow, (size_t)nq * 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    std::vector<uint32_t> redo;
+    for (uint32_t q = 0; q < nq; q++)
+        if (flags[q]) redo.push_back(q);
+    if (redo.empty()) return MVF_OK;
+    HIP_TRY(hipMemsetAsync(overflow, 0, (size_t)nq_pad * 4, s));
+    const size_t nf = redo.size();
+    if (getenv("MVF_DEBUG_REPAIR")) fprintf(stderr, "[mvfgpu] overflow repair: %zu of %u queries redone by K1\n", nf, nq);
+    const size_t qbytes = (size_t)c->dim * (is_int_dtype(c->dtype) ? 1u : 4u);
+    const size_t qarea = (nf * qbytes + 15u) & ~(size_t)15u, nres = nf * k;
+    HIP_TRY(c->repair.reserve(qarea + nres * 16));
+    unsigned char* gq = static_cast<unsigned char*>(c->repair.p);
+    uint64_t* ti = reinterpret_cast<uint64_t*>(gq + qarea);
+    float* ts = reinterpret_cast<float*>(ti + nres);
+    int32_t* tr = reinterpret_cast<int32_t*>(ts + nres);
+    for (size_t i = 0; i < nf; i++)
+        HIP_TRY(hipMemcpyAsync(gq + i * qbytes, static_cast<const unsigned char*>(d_queries) + redo[i] * qbytes, qbytes,
+                               hipMemcpyDeviceToDevice, s));
+    int rc = search_stream_path(c, metric, gq, (uint32_t)nf, k, ts, ti, tr, s, /*profile=*/false);
+    if (rc != MVF_OK) return rc;
+    for (size_t i = 0; i < nf; i++) {
+        const size_t o = (size_t)redo[i] * k;
+        HIP_TRY(hipMemcpyAsync(d_scores + o, ts + i * k, (size_t)k * 4, hipMemcpyDeviceToDevice, s));
+        HIP_TRY(hipMemcpyAsync(d_indices + o, ti + i * k, (size_t)k * 8, hipMemcpyDeviceToDevice, s));
+        if (d_raw) HIP_TRY(hipMemcpyAsync(d_raw + o, tr + i * k, (size_t)k * 4, hipMemcpyDeviceToDevice, s));
+    }
+    HIP_TRY(hipStreamSynchronize(s));
+    return MVF_OK;
+}
+
 // K2 path: MFMA batched scan in geometric phases with per-query candidate
 // compaction between them (scan_mfma.hip for Float32 rows, scan_mfma16.hip for
 // Float16 / Int8 rows).  Blocking at the end: the overflow flags are read back
@@ -327,7 +414,7 @@ int search_batched_path(const mvfgpu_corpus* c, uint8_t metric, const void* d_qu
     bool use_shadow = false;
     const bool rescore_fits = (size_t)((c->dim + 7u) & ~7u) * 4 + kBatchCap * 4 <= 64 * 1024;  // query + candidates in LDS
     if (c->dtype == MVF_DTYPE_FLOAT32 && c->scan_path != 2 && (c->scan_path == 3 || shadow_enabled()) && rescore_fits) {
-        HIP_TRY(ensure_shadow(c, s));
+        HIP_TRY(ensure_shadow(c, s, c->scan_path == 3));
         use_shadow = c->shadow_state == 1;
     }
     const bool wide = c->dtype == MVF_DTYPE_FLOAT32 && !use_shadow;  // f32 rows: 128x128x32-float tiles
@@ -351,11 +438,9 @@ int search_batched_path(const mvfgpu_corpus* c, uint8_t metric, const void* d_qu
     float* qaux1 = qaux0 + nq_pad;
     unsigned char* zeros = reinterpret_cast<unsigned char*>(qaux1 + nq_pad);  // 64 zero bytes
     HIP_TRY(hipMemsetAsync(zeros, 0, 64, s));
-    if (c->bstate_slots < nq_pad) {
-        HIP_TRY(c->bstate.reserve((size_t)nq_pad * 12));
-        HIP_TRY(hipMemsetAsync(c->bstate.p, 0xFF, (size_t)nq_pad * 4, s));                                  // tau
-        HIP_TRY(hipMemsetAsync(static_cast<unsigned char*>(c->bstate.p) + (size_t)nq_pad * 4, 0, (size_t)nq_pad * 8, s));  // cnt, overflow
-        c->bstate_slots = nq_pad;
+    {
+        int rc = ensure_bstate(c, nq_pad, s);
+        if (rc != MVF_OK) return rc;
     }
     uint32_t* tau = static_cast<uint32_t*>(c->bstate.p);
     uint32_t* cnt = tau + c->bstate_slots;
@@ -366,17 +451,10 @@ int search_batched_path(const mvfgpu_corpus* c, uint8_t metric, const void* d_qu
     // (single f16 query plane); the other combinations carry final keys through the phases
     const bool approx = is_float && (metric == MVF_METRIC_L2 || kdtype == MVF_DTYPE_FLOAT16);
     const bool need_norms = approx || metric != MVF_METRIC_INNER_PRODUCT || c->dtype == MVF_DTYPE_UINT8;
-    // K4 buffer: float rows: |x| [n], sum x^2 [n], max sum x^2 [1]; Int8 rows: sum x^2 (i32) [n];
-    // UInt8 rows: sum (x-128)^2 [n], 128 * sum (x-128) [n]
     const size_t nn = std::max<uint32_t>(n, 1);
-    if (need_norms && !c->xnorm_ready) {  // once per resident corpus
-        HIP_TRY(c->xnorm.reserve((2 * nn + 1) * 4));
-        float* xn = static_cast<float*>(c->xnorm.p);
-        if (is_float) HIP_TRY(hipMemsetAsync(xn + 2 * nn, 0, 4, s));
-        // norms always come from the STORED rows (a shadow only feeds the dot products)
-        if (c->dtype == MVF_DTYPE_FLOAT32) HIP_TRY(launch_row_norms_f32(c->d_rows, n, c->pitch, xn, xn + nn, xn + 2 * nn, s));
-        else HIP_TRY(launch_row_norms16(c->d_rows, c->dtype, n, c->pitch, c->dim, c->xnorm.p, xn + nn, xn + 2 * nn, s));
-        c->xnorm_ready = true;
+    if (need_norms) {
+        int rc = ensure_norms(c, s);
+        if (rc != MVF_OK) return rc;
     }
     const float* xx2 = is_float && c->xnorm.p ? static_cast<const float*>(c->xnorm.p) + nn : nullptr;
     const float* xxmax = is_float && c->xnorm.p ? static_cast<const float*>(c->xnorm.p) + 2 * nn : nullptr;
@@ -515,41 +593,97 @@ int search_batched_path(const mvfgpu_corpus* c, uint8_t metric, const void* d_qu
         c->prof_next++;
     }
 
-    // overflow check (rare: needs > cap survivors for one query within one phase)
-    std::vector<uint32_t> flags(nq);
-    HIP_TRY(hipMemcpyAsync(flags.data(), overflow, (size_t)nq * 4, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
-    bool any = false;
-    for (uint32_t q = 0; q < nq; q++) any |= flags[q] != 0;
-    if (any) {
-        // Repair: the flagged queries are gathered so that K1 takes them four per pass over the corpus.
-        HIP_TRY(hipMemsetAsync(overflow, 0, (size_t)nq_pad * 4, s));
-        std::vector<uint32_t> redo;
-        for (uint32_t q = 0; q < nq; q++)
-            if (flags[q]) redo.push_back(q);
-        const size_t nf = redo.size();
-        if (getenv("MVF_DEBUG_REPAIR")) fprintf(stderr, "[mvfgpu] K2 overflow repair: %zu of %u queries redone by K1\n", nf, nq);
-        const size_t qbytes = (size_t)c->dim * (is_int_dtype(c->dtype) ? 1u : 4u);
-        const size_t qarea = (nf * qbytes + 15u) & ~(size_t)15u, nres = nf * k;
-        HIP_TRY(c->repair.reserve(qarea + nres * 16));
-        unsigned char* gq = static_cast<unsigned char*>(c->repair.p);
-        uint64_t* ti = reinterpret_cast<uint64_t*>(gq + qarea);
-        float* ts = reinterpret_cast<float*>(ti + nres);
-        int32_t* tr = reinterpret_cast<int32_t*>(ts + nres);
-        for (size_t i = 0; i < nf; i++)
-            HIP_TRY(hipMemcpyAsync(gq + i * qbytes, static_cast<const unsigned char*>(d_queries) + redo[i] * qbytes, qbytes,
-                                   hipMemcpyDeviceToDevice, s));
-        int rc = search_stream_path(c, metric, gq, (uint32_t)nf, k, ts, ti, tr, s, /*profile=*/false);
-        if (rc != MVF_OK) return rc;
-        for (size_t i = 0; i < nf; i++) {
-            const size_t o = (size_t)redo[i] * k;
-            HIP_TRY(hipMemcpyAsync(d_scores + o, ts + i * k, (size_t)k * 4, hipMemcpyDeviceToDevice, s));
-            HIP_TRY(hipMemcpyAsync(d_indices + o, ti + i * k, (size_t)k * 8, hipMemcpyDeviceToDevice, s));
-            if (d_raw) HIP_TRY(hipMemcpyAsync(d_raw + o, tr + i * k, (size_t)k * 4, hipMemcpyDeviceToDevice, s));
-        }
-        HIP_TRY(hipStreamSynchronize(s));
-    }
-    return MVF_OK;
+    return repair_flagged_queries(c, metric, d_queries, nq, nq_pad, k, overflow, d_scores, d_indices, d_raw, s);
+}
+
+// Scan path 4 (opt-in): one or two queries on a Float32 corpus STREAM ITS SCALED-F16 SHADOW -- half the bytes of the
+// stored rows, so half the time of the HBM-bound K1 -- with the batched path's select-with-a-margin / re-score-exactly
+// scheme: K1 (dt1x unit: f16 rows times xscale[r]) keeps the k' > k best approximate scores; every candidate within
+// twice the error bound of the k-th is re-scored from the stored f32 rows and the f32 query; if ALL k' are inside the
+// margin (rows beyond the cut may be too) the query is flagged and redone by the exact K1.  Ends with the flag
+// read-back, i.e. it is synchronous like the batched path.
+//   x~ = x (1 + e), |e| <= 2^-11 per element:  |q.x~ - q.x| <= 2^-11 |q||x|;  | |q - x~| - |q - x| | <= 2^-11 |x|;
+//   cosine (numerator and denominator both from x~) <= 2 * 2^-11; plus the f32 accumulation, (dim + 16) 2^-23.
+int search_stream_shadow_path(const mvfgpu_corpus* c, uint8_t metric, const void* d_queries, uint32_t nq, uint32_t k,
+                              float* d_scores, uint64_t* d_indices, int32_t* d_raw, hipStream_t s) {
+    const uint32_t cap = kBatchCap;
+    const uint32_t nq_pad = (nq + 255u) & ~255u;
+    const uint32_t n = (uint32_t)c->n;
+    const size_t nn = std::max<uint32_t>(n, 1);
+    int rc = ensure_bstate(c, nq_pad, s);
+    if (rc == MVF_OK) rc = ensure_norms(c, s);
+    if (rc != MVF_OK) return rc;
+    uint32_t* tau = static_cast<uint32_t*>(c->bstate.p);
+    uint32_t* cnt = tau + c->bstate_slots;
+    uint32_t* overflow = cnt + c->bstate_slots;
+    HIP_TRY(c->bcand.reserve((size_t)nq_pad * cap * 8));
+    // |q| per query for the margins: the f16 query preparation computes it (its planes are not used here)
+    const uint32_t KPB = ((c->dim * 2u + 63u) / 64u) * 64u;
+    HIP_TRY(c->bq.reserve((size_t)nq_pad * KPB + (size_t)nq_pad * 8 + 64));
+    unsigned char* qprep = static_cast<unsigned char*>(c->bq.p);
+    float* qaux0 = reinterpret_cast<float*>(qprep + (size_t)nq_pad * KPB);
+    float* qaux1 = qaux0 + nq_pad;
+    HIP_TRY(launch_prep_queries16(d_queries, MVF_DTYPE_FLOAT16, nq, nq_pad, c->dim, KPB, qprep, qaux0, qaux1, s));
+
+    const uint32_t ksel = std::min<uint32_t>(MVFGPU_MAX_K, std::max(2u * k, k + 64u));  // k' candidates per query
+    ShadowStream alt{};
+    alt.rows = static_cast<const unsigned char*>(c->shadow.p);
+    alt.xscale = static_cast<const float*>(c->xscale.p);
+    alt.pitch = shadow_pitch(c->dim);
+    alt.V = alt.pitch / 16;
+    choose_group(alt.V, &alt.G, &alt.J);
+    alt.cand = static_cast<uint64_t*>(c->bcand.p);
+    alt.cnt = cnt;
+    alt.cand_cap = cap;
+    rc = search_stream_path(c, metric, d_queries, nq, ksel, nullptr, nullptr, nullptr, s, /*profile=*/true, &alt);
+    if (rc != MVF_OK) return rc;
+
+    CompactParams cp{};
+    cp.cand = alt.cand;
+    cp.cnt = cnt;
+    cp.tau = tau;
+    cp.overflow = overflow;
+    cp.cap = cap;
+    cp.k = k;
+    cp.metric = metric;
+    cp.dtype = c->dtype;
+    cp.index_base = c->index_base;
+    cp.qnorm = qaux1;
+    cp.xxmax = static_cast<const float*>(c->xnorm.p) + 2 * nn;
+    // per-element relative rounding of the shadow rows (2^-11) and f32 accumulation of `dim` terms ((dim + 16) 2^-23
+    // of the sum; half of that, relative, on a square root)
+    const float e11 = 4.8828125e-4f * 1.001f, eacc = (float)(std::max<uint32_t>(c->dim, 64) + 16) * 1.1920929e-7f;
+    cp.eps = metric == MVF_METRIC_COSINE ? 2.0f * e11 + eacc : metric == MVF_METRIC_INNER_PRODUCT ? e11 + eacc : e11;
+    cp.eps_acc = 0.5f * eacc;
+    cp.l2_is_distance = 1;
+    cp.truncated_at = n > ksel ? ksel : 0u;
+    HIP_TRY(launch_compact_margin(cp, nq, s));
+
+    RescoreParams rp{};
+    rp.cand = alt.cand;
+    rp.cnt = cnt;
+    rp.tau = tau;
+    rp.cap = cap;
+    rp.k = k;
+    rp.queries = static_cast<const float*>(d_queries);
+    rp.rows = c->d_rows;
+    rp.pitch = c->pitch;
+    rp.dim = c->dim;
+    rp.dtype = c->dtype;
+    rp.index_base = c->index_base;
+    rp.out_scores = d_scores;
+    rp.out_indices = d_indices;
+    rp.out_raw = d_raw;
+    HIP_TRY(launch_rescore(rp, metric, nq, s));
+    return repair_flagged_queries(c, metric, d_queries, nq, nq_pad, k, overflow, d_scores, d_indices, d_raw, s);
+}
+
+// Scan path 4 applies to one or two queries on a Float32 corpus whose shadow exists (or can be built now).
+bool stream_shadow_wanted(const mvfgpu_corpus* c, uint32_t nq) {
+    if (c->dtype != MVF_DTYPE_FLOAT32 || nq > 2 || c->n == 0) return false;
+    const char* e = getenv("MVF_STREAM_SHADOW");
+    if (c->scan_path != 4 && !(c->scan_path == 0 && e && atoi(e) != 0)) return false;
+    return (size_t)((c->dim + 7u) & ~7u) * 4 + kBatchCap * 4 <= 64 * 1024;  // the re-scoring kernel keeps the query in LDS
 }
 
 bool use_batched_path(const mvfgpu_corpus* c, uint8_t metric, uint32_t nq) {
@@ -561,7 +695,7 @@ bool use_batched_path(const mvfgpu_corpus* c, uint8_t metric, uint32_t nq) {
         (size_t)((c->dim + 7u) & ~7u) * 4 + kBatchCap * 4 > 64 * 1024)
         supported = false;  // the re-scoring kernel keeps the query in LDS
     if (!supported) return false;
-    if (c->scan_path >= 2) return true;
+    if (c->scan_path == 2 || c->scan_path == 3) return true;
     // K1 takes 2..4 queries per HBM pass (5.8 / 6.4 / 7.5 ms on 10M x 768 f32 / 12.5M x 1024 f16 / 50M x 768 int8);
     // K2 costs a flat padded-tile time up to 128 / 256 queries (f32 kernel 15.3 ms, f16 kernel 6.4 ms on the f32
     // corpus' shadow and 7.4 ms on the f16 corpus, int8 13.8 ms) plus ~0.2 ms of phase launches and the final flag
@@ -829,8 +963,15 @@ int mvfgpu_search_device(const mvfgpu_corpus* c, uint8_t metric, const void* d_q
     std::lock_guard<std::mutex> lk(c->mu);
     // the scratch buffers are stream-ordered: a call on another stream waits for the previous one
     if (c->has_done && c->last_stream != s) HIP_TRY(hipStreamWaitEvent(s, c->ev_done, 0));
-    rc = use_batched_path(c, metric, nq) ? search_batched_path(c, metric, d_queries, nq, k, d_scores, d_indices, d_raw, s)
-                                         : search_stream_path(c, metric, d_queries, nq, k, d_scores, d_indices, d_raw, s);
+    bool shadow_stream = false;
+    if (stream_shadow_wanted(c, nq)) {
+        hipError_t e = ensure_shadow(c, s, c->scan_path == 4);
+        if (e != hipSuccess) return fail(MVF_ERR_DEVICE, std::string("shadow build: ") + hipGetErrorString(e));
+        shadow_stream = c->shadow_state == 1;
+    }
+    rc = shadow_stream                       ? search_stream_shadow_path(c, metric, d_queries, nq, k, d_scores, d_indices, d_raw, s)
+         : use_batched_path(c, metric, nq) ? search_batched_path(c, metric, d_queries, nq, k, d_scores, d_indices, d_raw, s)
+                                           : search_stream_path(c, metric, d_queries, nq, k, d_scores, d_indices, d_raw, s);
     if (rc != MVF_OK) return rc;
     HIP_TRY(hipEventRecord(c->ev_done, s));
     c->has_done = true;
@@ -1028,7 +1169,7 @@ int mvfgpu_last_timing(const mvfgpu_corpus* c, mvfgpu_timing* out) {
 
 int mvfgpu_set_scan_path(mvfgpu_corpus* c, int path) {
     if (!c) return fail(MVF_ERR_INVALID_ARGUMENT, "corpus is NULL");
-    if (path < 0 || path > 3) return fail(MVF_ERR_INVALID_ARGUMENT, "path must be 0, 1, 2 or 3");
+    if (path < 0 || path > 4) return fail(MVF_ERR_INVALID_ARGUMENT, "path must be 0..4");
     std::lock_guard<std::mutex> lk(c->mu);
     c->scan_path = path;
     return MVF_OK;

@@ -18,6 +18,11 @@ struct SelectParams {
     float* out_scores;      // [nq][k]
     uint64_t* out_indices;
     int32_t* out_raw;       // nullable
+    // alternative output (streaming over the f16 shadow): the k best COMPOSITES, unformatted, as the candidate list
+    // of the margin compaction / re-scoring kernels: out_cand[q * cand_cap + i], out_cnt[q] = how many
+    uint64_t* out_cand;     // nullable
+    uint32_t* out_cnt;
+    uint32_t cand_cap;
 };
 
 struct ShardMergeParams {

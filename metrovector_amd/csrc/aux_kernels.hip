@@ -102,6 +102,12 @@ __global__ void __launch_bounds__(1024) select_final_kernel(SelectParams p) {
         }
         m = kcur;
     }
+    if (p.out_cand) {
+        const uint32_t keep = m < p.k ? m : p.k;
+        for (uint32_t i = tid; i < keep; i += 1024) p.out_cand[(size_t)q * p.cand_cap + i] = buf[i];
+        if (tid == 0) p.out_cnt[q] = keep;
+        return;
+    }
     for (uint32_t i = tid; i < p.k; i += 1024) write_result(i < m ? buf[i] : kPadComposite, q * p.k + i, p);
 }
 

@@ -66,6 +66,13 @@ struct CompactParams {
     const float* qnorm;   // [nq] |q|
     const float* xxmax;   // [1] max over rows of sum x^2
     float eps;
+    // streaming over the f16 shadow (K1 keys): L2 keys are DISTANCES, | |q - x~| - |q - x| | <= |x~ - x| <= eps max|x|,
+    // plus the accumulation, eps_acc (|q| + max|x|); and the list was
+    // cut at `truncated_at` candidates by the selection before -- if every one of them is inside the margin, rows
+    // beyond the cut may be too: the query is flagged and redone exactly
+    uint8_t l2_is_distance;
+    float eps_acc;
+    uint32_t truncated_at;
     // final stage only
     uint8_t metric, dtype;
     uint64_t index_base;

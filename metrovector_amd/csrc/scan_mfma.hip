@@ -447,7 +447,9 @@ __global__ void __launch_bounds__(1024) compact_margin_kernel(CompactParams p) {
         const float vk = score_from_key((uint32_t)(buf[p.k - 1] >> 32), p.metric);
         const float qn = p.qnorm[q];
         float thr;
-        if (p.metric == MVF_METRIC_L2) thr = vk + 2.0f * p.eps * (qn * qn + p.xxmax[0]);
+        if (p.metric == MVF_METRIC_L2 && p.l2_is_distance)
+            thr = vk + 2.0f * (p.eps * sqrtf(p.xxmax[0]) + p.eps_acc * (qn + sqrtf(p.xxmax[0])));
+        else if (p.metric == MVF_METRIC_L2) thr = vk + 2.0f * p.eps * (qn * qn + p.xxmax[0]);
         else if (p.metric == MVF_METRIC_COSINE) thr = vk - 2.0f * p.eps;
         else thr = vk - 2.0f * p.eps * qn * sqrtf(p.xxmax[0]);
         tkey = key_from_score(thr, p.metric);
@@ -463,6 +465,7 @@ __global__ void __launch_bounds__(1024) compact_margin_kernel(CompactParams p) {
         keep = keep_cap;
         over = true;
     }
+    if (p.truncated_at && m >= p.truncated_at && keep_s >= m) over = true;  // the margin reaches past the cut
     for (uint32_t i = tid; i < keep; i += 1024) c[i] = buf[i];
     if (tid == 0) {
         if (over) p.overflow[q] = 1u;

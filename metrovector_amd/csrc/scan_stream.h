@@ -9,6 +9,7 @@ namespace mvf {
 struct ScanParams {
     const unsigned char* rows;  // device rows, `pitch` bytes apart, 16-B aligned
     const void* queries;        // device [nq_total][dim]: f32, or the space's int type
+    const float* xscale;        // dt1x only: the rows are the scaled-f16 shadow of a Float32 corpus, row r times xscale[r]
     uint64_t* cand;             // out: [launch queries][gridDim.x][kcap] sorted composites, ~0-padded
     uint32_t n;                 // rows in the shard
     uint32_t pitch;             // bytes per device row (multiple of 16)
@@ -33,6 +34,7 @@ MVF_DECL_SCAN(0)
 MVF_DECL_SCAN(1)
 MVF_DECL_SCAN(2)
 MVF_DECL_SCAN(3)
+MVF_DECL_SCAN(1x)  // Float16 rows of an f32 corpus' shadow, scaled back by ScanParams::xscale; nqv = 1 only
 #undef MVF_DECL_SCAN
 
 // rows per chunk for a lane-group width G (multiple of the 16*64/G rows a block covers per step)

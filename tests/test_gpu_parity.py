@@ -523,6 +523,71 @@ def test_device_bytes_accounts_for_the_f16_shadow(oracle):
     assert exact_only > before                            # norms + K2 scratch
 
 
+# ---------------------------------------------------------------------------
+# Scan path 4: one or two queries on a Float32 corpus stream its f16 shadow (K1, dt1x unit), margin + exact re-score
+# ---------------------------------------------------------------------------
+
+@pytest.mark.parametrize("metric", [0, 1, 2])
+@pytest.mark.parametrize("shape", [(60000, 768, 1, 100), (20000, 100, 2, 10), (300, 64, 1, 500), (9000, 36, 2, 1),
+                                   (5003, 7, 1, 64)])
+def test_stream_shadow_path(oracle, metric, shape):
+    n, dim, nq, k = shape
+    rows = oracle.synth_rows(SEED, 0, n, dim, 0)
+    q = oracle.synth_queries(SEED + 1, nq, dim, 0)
+    with G.GpuCorpus.from_array(rows, index_base=77) as c:
+        c.set_scan_path(4)
+        c.set_profiling(True)
+        res = c.search(q, k, metric)
+        assert c.last_timing().scan_kernel == 5       # K1 really streamed the shadow
+        c.set_profiling(False)
+        c.set_scan_path(1)
+        exact = c.search(q, k, metric)                # K1 on the stored f32 rows
+    for i in range(nq):
+        sc, _, _ = oracle.scores(rows, 0, metric, q[i])
+        assert_float_topk(metric, res.scores[i], res.indices[i], sc, rows, q[i], k, 77)
+    assert recall_at_k(res.indices, exact.indices) >= 0.999
+
+
+@pytest.mark.parametrize("metric", [0, 1, 2])
+@pytest.mark.parametrize("cluster", [40, 3000])
+def test_stream_shadow_dense_cluster_at_the_kth_rank(oracle, metric, cluster):
+    """Score gaps inside the cluster are far below the shadow's error bound.  40 near-identical rows around the
+    k-th rank fit inside the k' = 2k candidates and are re-scored; with 3000 of them every one of the k' candidates
+    is inside the margin, rows beyond the cut may be too, and the query is redone by the exact kernel."""
+    n, dim, k = 20000, 192, 50
+    rows = oracle.synth_rows(SEED, 0, n, dim, 0)
+    rng = np.random.default_rng(12)
+    base = rng.standard_normal(dim).astype(np.float32)
+    where = rng.choice(n, cluster, replace=False)
+    rows[where] = base * 0.5 + rng.standard_normal((cluster, dim)).astype(np.float32) * 1.5e-3
+    q = (base[None, :] + rng.standard_normal((2, dim)).astype(np.float32) * 1e-2).astype(np.float32)
+    with G.GpuCorpus.from_array(rows) as c:
+        c.set_scan_path(4)
+        res = c.search(q, k, metric)
+    for i in range(2):
+        sc, _, _ = oracle.scores(rows, 0, metric, q[i])
+        assert_float_topk(metric, res.scores[i], res.indices[i], sc, rows, q[i], k)
+
+
+def test_stream_shadow_row_dynamic_range(oracle):
+    n, dim, k = 12000, 96, 25
+    rng = np.random.default_rng(21)
+    rows = oracle.synth_rows(SEED, 0, n, dim, 0)
+    rows *= (10.0 ** rng.uniform(-30, 30, n)).astype(np.float32)[:, None]
+    rows[::11, ::3] *= 1e-7
+    rows[5] = 0.0
+    rows[17, 3] = np.inf
+    rows[23, 0] = np.nan
+    q = oracle.synth_queries(SEED + 1, 2, dim, 0)
+    for metric in (2, 1, 0):
+        with G.GpuCorpus.from_array(rows) as c:
+            c.set_scan_path(4)
+            res = c.search(q, k, metric)
+        for i in range(2):
+            sc, _, _ = oracle.scores(rows, 0, metric, q[i])
+            assert_float_topk(metric, res.scores[i], res.indices[i], sc, rows, q[i], k)
+
+
 def test_batched_path_single_query_forced(oracle):
     rows = oracle.synth_rows(SEED, 0, 3000, 96, 0)
     q = oracle.synth_queries(SEED + 1, 1, 96, 0)
