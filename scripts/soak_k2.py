@@ -16,7 +16,14 @@ CONFIGS = [  # rows, dim, dtype, metric, nq
     (10_000_000, 768, 0, 2, 1024),     # cfg3 (f16 shadow)
     (3_000_000, 200, 3, 2, 300),       # uint8 cosine, odd dim
     (2_000_001, 96, 1, 1, 777),        # f16 dot, ragged
+    (6_000_000, 384, 1, 2, 257),       # f16 cosine, one query past a tile
+    (8_000_000, 512, 2, 0, 1000),      # int8 L2
+    (5_000_000, 768, 3, 1, 129),       # uint8 dot
+    (4_000_000, 1000, 0, 0, 513),      # f32 L2 through the shadow, dim not a multiple of 32
+    (3_000_000, 768, 0, 1, 5),         # f32 dot, smallest batched size
 ]
+if len(sys.argv) > 2 and sys.argv[2] == "extra":
+    CONFIGS = CONFIGS[5:]
 def digest(r):
     h = hashlib.sha256()
     for a in (r.scores, r.indices, r.raw):
