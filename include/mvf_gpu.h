@@ -168,9 +168,10 @@ int mvfgpu_search(const mvfgpu_corpus* corpus, uint8_t metric,
  * This is the timed region of bench.py and the producer of the per-shard
  * lists that RCCL all-gathers.  d_raw may be NULL.
  * Small batches run the streaming kernel and return without waiting (below
- * 32 queries on corpora under 1 GiB; on larger ones below 5 queries, or 9
- * for Float32 without the f16 shadow — the measured crossovers: the
- * streaming kernel takes up to 4 queries per pass over the rows).  Larger
+ * 32 queries on corpora under 1 GiB; on larger ones a single query, below 5
+ * for Int8/UInt8 and below 9 for Float32 without the f16 shadow — the
+ * measured crossovers: the streaming kernel takes up to 4 queries per pass
+ * over the rows, the MFMA path uses a 64-query tile up to 128 queries).  Larger
  * batches run the MFMA path, whose
  * last step reads back per-query overflow flags (an adversarially ordered
  * corpus can overflow a candidate buffer; such queries are redone exactly by

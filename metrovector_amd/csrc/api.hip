@@ -423,7 +423,7 @@ int search_batched_path(const mvfgpu_corpus* c, uint8_t metric, const void* d_qu
     const uint32_t kpitch = use_shadow ? shadow_pitch(c->dim) : c->pitch;
     const uint32_t tile_rows = wide ? 128u : 256u;
     const bool dma = !wide && k2_dma_enabled();            // LDS-DMA kernel (default) or the register-staged one
-    const uint32_t qpb = wide ? 128u : dma ? scan_mfma16_dma_queries_per_block() : scan_mfma16_queries_per_block(kdtype);
+    const uint32_t qpb = wide ? 128u : dma ? scan_mfma16_dma_queries_per_block(nq) : scan_mfma16_queries_per_block(kdtype);
     const uint32_t nq_pad = (nq + qpb - 1u) / qpb * qpb;
     const uint32_t ktb = dma ? 64u : 128u;                  // k-tile bytes of the f16/int8 kernel in use
     const uint32_t KT = wide ? (c->dim + 31u) / 32u : (c->dim * elem_size(kdtype) + ktb - 1u) / ktb;
@@ -552,7 +552,7 @@ int search_batched_path(const mvfgpu_corpus* c, uint8_t metric, const void* d_qu
             bp.direct = hp.direct = (begin == 0 && end - begin <= cap) ? 1u : 0u;
             if (ps && last) HIP_TRY(hipEventRecord(ps->e[0], s));
             if (wide) HIP_TRY(launch_scan_mfma_f32(bp, metric, c->num_cus, s));
-            else if (dma) HIP_TRY(launch_scan_mfma16_dma(hp, kdtype, metric, c->num_cus, k2_dma_persistent(kdtype), s));
+            else if (dma) HIP_TRY(launch_scan_mfma16_dma(hp, kdtype, metric, c->num_cus, qpb, k2_dma_persistent(kdtype), s));
             else HIP_TRY(launch_scan_mfma16(hp, kdtype, metric, c->num_cus, s));
             if (ps && last) {
                 HIP_TRY(hipEventRecord(ps->e[1], s));
@@ -696,14 +696,18 @@ bool use_batched_path(const mvfgpu_corpus* c, uint8_t metric, uint32_t nq) {
         supported = false;  // the re-scoring kernel keeps the query in LDS
     if (!supported) return false;
     if (c->scan_path == 2 || c->scan_path == 3) return true;
-    // K1 takes 2..4 queries per HBM pass (5.8 / 6.4 / 7.5 ms on 10M x 768 f32 / 12.5M x 1024 f16 / 50M x 768 int8);
-    // K2 costs a flat padded-tile time up to 128 / 256 queries (f32 kernel 15.3 ms, f16 kernel 6.4 ms on the f32
-    // corpus' shadow and 7.4 ms on the f16 corpus, int8 13.8 ms) plus ~0.2 ms of phase launches and the final flag
-    // read-back: measured crossovers on >= 1 GiB of rows; small corpora keep K1 until the batch is MFMA-sized.
+    // K1 takes 2..4 queries per HBM pass (5.7 / 6.3 / 7.4 ms on 10M x 768 f32 / 12.5M x 1024 f16 / 50M x 768 int8);
+    // K2 costs a flat padded-tile time: with the 64-query tile 3.65 ms (f16 kernel on the f32 corpus' shadow), 4.9 ms
+    // (f16 corpus), 7.6 ms (int8) up to 64 queries; the exact f32 kernel 15.3 ms up to 128 -- plus ~0.2 ms of phase
+    // launches and the final flag read-back.  Measured crossovers on >= 1 GiB of rows; small corpora keep K1 until the
+    // batch is MFMA-sized.
     const uint64_t bytes = c->n * (uint64_t)c->dim * elem_size(c->dtype);
     const bool shadowed = c->dtype == MVF_DTYPE_FLOAT32 && (c->scan_path == 3 || shadow_enabled()) && c->shadow_state >= 0 &&  // runs as Float16
                           (size_t)((c->dim + 7u) & ~7u) * 4 + kBatchCap * 4 <= 64 * 1024;
-    const uint32_t threshold = bytes < (1ull << 30) ? 32u : c->dtype == MVF_DTYPE_FLOAT32 && !shadowed ? 9u : 5u;
+    const uint32_t threshold = bytes < (1ull << 30)                           ? 32u
+                               : c->dtype == MVF_DTYPE_FLOAT32 && !shadowed ? 9u
+                               : is_int_dtype(c->dtype)                     ? 5u
+                                                                            : 2u;
     return nq >= threshold;
 }
 

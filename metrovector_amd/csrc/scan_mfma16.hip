@@ -225,7 +225,7 @@ __global__ void __launch_bounds__(512, 2) scan_mfma16_kernel(Batch16Params p) {
     };
 
     auto epilogue = [&](uint32_t nt, uint32_t mt) __attribute__((always_inline)) {
-        epilogue16<DT, METRIC, DIRECT, XS, BMQ, 32>(p, acc, nt, mt, wm, wn, lane, qa_s, qb_s, tau_s, thr_s);
+        epilogue16<DT, METRIC, DIRECT, XS, BMQ, 32, 128, 64>(p, acc, nt, mt, wm, wn, lane, qa_s, qb_s, tau_s, thr_s);
     };
 
     // one flat k-tile g; rb holds B k-tile g+1 on entry and receives B k-tile g+3.  The LDS stores of k-tile g+1 and

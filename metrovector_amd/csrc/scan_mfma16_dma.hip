@@ -42,13 +42,22 @@ namespace {
 
 constexpr int DKB = 64;                       // k-tile bytes per row
 
-struct Cf {
-    static constexpr int NW = 8;                                // waves per block, as 2 (queries) x 4 (rows)
-    static constexpr int BMQ = 256;                             // queries (A rows) per block
-    static constexpr int NSTAGE = 4;
+// Two block shapes, both 8 waves and 256 corpus rows per tile:
+//   BMQ = 256 queries: waves 2 (queries) x 4 (rows), each 128 x 64 outputs; ring of 4 stages x 32 KB.  MFMA-bound.
+//   BMQ = 64 queries (batches <= 128): waves 1 x 8, each 64 x 32 outputs; a quarter of the MFMA work per corpus byte,
+//     so the kernel is HBM-bound and the ring is deeper instead: 6 stages x 20 KB, four of them in flight.
+template <int BMQ_> struct CfT {
+    static constexpr int NW = 8;
+    static constexpr int BMQ = BMQ_;                            // queries (A rows) per block
+    static constexpr int WQ = BMQ == 256 ? 128 : 64;            // a wave's share of the tile: queries ...
+    static constexpr int WR = BMQ == 256 ? 64 : 32;             // ... x corpus rows
+    static constexpr int WN = BROWS / WR;                       // waves along the rows (4 or 8); NW / WN along the queries
+    static constexpr int NSTAGE = BMQ == 256 ? 4 : 6;
     static constexpr int A_B = BMQ * DKB;                       // bytes of A per stage
     static constexpr int STAGE_B = A_B + BROWS * DKB;           // A then B
-    static constexpr int APW = BMQ / 16 / NW;                   // 1-KB DMA pieces per wave per k-tile: A
+    static constexpr int APIECES = BMQ / 16;                    // 1-KB DMA pieces of A per k-tile (16 or 4)
+    static constexpr int APW = APIECES >= NW ? APIECES / NW : 1;  // per wave (with 4 pieces, waves 4..7 re-issue 0..3:
+                                                                //  every wave then carries the same vmcnt count)
     static constexpr int BPW = BROWS / 16 / NW;                 //                                      B
     static constexpr int PIECES = APW + BPW;
     static constexpr int INFLIGHT = PIECES * (NSTAGE - 2);      // pieces left in flight across the barrier
@@ -59,17 +68,18 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* glb_ptr_t;
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-constexpr int SH = 16;  // MFMA sub-tile: a wave's 128 x 64 outputs are 8 x 4 of them
+constexpr int SH = 16;  // MFMA sub-tile: a wave's WQ x WR outputs are (WQ/16) x (WR/16) of them
 
 // XOR swizzle of the 16-B slot by x = (row >> 2) & 3.  A fragment read takes lane -> (row lane & 15, chunk lane >> 4);
 // ds_read_b128 is served in 16-lane groups {0-3,12-15,20-27}, {4-11,16-19,28-31}, ... and the permutation {0, 2, 3, 1}
 // makes each group touch 16 distinct (row & 3, slot) pairs (SQ_LDS_BANK_CONFLICT = 0).
 __device__ __forceinline__ uint32_t slot_swz(uint32_t x) { return (0x78u >> (2u * x)) & 3u; }
 
-template <int DT, int METRIC, bool DIRECT, bool XS>
+template <int DT, int METRIC, bool DIRECT, bool XS, int BMQ_>
 __global__ void __launch_bounds__(512, 2) scan_mfma16_dma_kernel(Batch16Params p) {
     using AccT = typename std::conditional<DT == MVF_DTYPE_FLOAT16, f32x4, i32x4>::type;
-    constexpr int NW = Cf::NW, NI = 128 / SH, NJ = 64 / SH, NE = SH * SH / 64;
+    using Cf = CfT<BMQ_>;
+    constexpr int NW = Cf::NW, WQ = Cf::WQ, WR = Cf::WR, NI = WQ / SH, NJ = WR / SH, NE = SH * SH / 64;
     constexpr int BMQ = Cf::BMQ, NSTAGE = Cf::NSTAGE, STAGE_B = Cf::STAGE_B, OPER_B = Cf::A_B;  // OPER_B: B's offset in a stage
     constexpr bool U8 = DT == MVF_DTYPE_UINT8;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -80,7 +90,7 @@ __global__ void __launch_bounds__(512, 2) scan_mfma16_dma_kernel(Batch16Params p
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 2, wn = wave & 3;
+    const int wm = wave / Cf::WN, wn = wave % Cf::WN;
 
     // persistent blocks, XCD-aware tile order (scan_mfma16.hip)
     const uint32_t xcd = blockIdx.x & 7u, ls = blockIdx.x >> 3, nls = gridDim.x >> 3;
@@ -109,7 +119,7 @@ __global__ void __launch_bounds__(512, 2) scan_mfma16_dma_kernel(Batch16Params p
         const uint32_t r0 = p.row_begin + nt * BROWS;
 #pragma unroll
         for (int j = 0; j < Cf::APW; j++)
-            a_src[j] = p.qprep + ((size_t)mt * BMQ + ((uint32_t)wave * Cf::APW + j) * 16u + rl) * p.KPB + cl * 16u;
+            a_src[j] = p.qprep + ((size_t)mt * BMQ + (((uint32_t)wave * Cf::APW + j) % Cf::APIECES) * 16u + rl) * p.KPB + cl * 16u;
 #pragma unroll
         for (int j = 0; j < Cf::BPW; j++) {
             const uint32_t r = r0 + ((uint32_t)wave * Cf::BPW + j) * 16u + rl;
@@ -122,7 +132,7 @@ __global__ void __launch_bounds__(512, 2) scan_mfma16_dma_kernel(Batch16Params p
         unsigned char* st = smem + stage * STAGE_B;
         if (piece < Cf::APW) {
             __builtin_amdgcn_global_load_lds((glb_ptr_t)(a_src[piece] + (size_t)d_kt * DKB),
-                                             (lds_ptr_t)(st + (wave * Cf::APW + piece) * (16 * DKB)), 16, 0, 0);
+                                             (lds_ptr_t)(st + ((wave * Cf::APW + piece) % Cf::APIECES) * (16 * DKB)), 16, 0, 0);
         } else {
             const int j = piece - Cf::APW;
             const uint32_t v = d_kt * 4u + cl;  // 16-B vector of the row
@@ -155,7 +165,7 @@ __global__ void __launch_bounds__(512, 2) scan_mfma16_dma_kernel(Batch16Params p
 
     uint32_t c_n = 0, c_kt = 0, c_nt, c_mt;  // compute cursor
     slot_tile(0, c_nt, c_mt);
-    load_query_consts16<DT, METRIC, Cf::BMQ>(p, c_mt * BMQ, tid, qa_s, qb_s, tau_s, thr_s);
+    load_query_consts16<DT, METRIC, BMQ>(p, c_mt * BMQ, tid, qa_s, qb_s, tau_s, thr_s);
 
     set_dma_tile(0);
 #pragma unroll
@@ -168,8 +178,8 @@ __global__ void __launch_bounds__(512, 2) scan_mfma16_dma_kernel(Batch16Params p
     const uint32_t frow = (uint32_t)lane & (SH - 1);
     const uint32_t fchunk = (uint32_t)lane >> 4;
     const uint32_t fslot = (fchunk ^ slot_swz((frow >> 2) & 3u)) & 3u;
-    const uint32_t a_off = ((uint32_t)wm * 128u + frow) * DKB + fslot * 16u;
-    const uint32_t b_off = OPER_B + ((uint32_t)wn * 64u + frow) * DKB + fslot * 16u;
+    const uint32_t a_off = ((uint32_t)wm * WQ + frow) * DKB + fslot * 16u;
+    const uint32_t b_off = OPER_B + ((uint32_t)wn * WR + frow) * DKB + fslot * 16u;
     auto read_a = [&](const unsigned char* st, int i) __attribute__((always_inline)) -> u32x4 {
         return *reinterpret_cast<const u32x4*>(st + a_off + i * SH * DKB);
     };
@@ -188,25 +198,25 @@ __global__ void __launch_bounds__(512, 2) scan_mfma16_dma_kernel(Batch16Params p
     uint32_t cs = 0, ds = NSTAGE - 1;  // compute stage (k-tile g), DMA target (k-tile g + NSTAGE - 1: the stage g - 1 read)
     for (uint32_t g = 0; g < G; g++) {
         const unsigned char* st = smem + cs * STAGE_B;
-        // eight groups of four MFMAs (one A fragment x four B fragments each, the whole 64-B k in one MFMA); the
-        // next group's A fragment is read while this group's MFMAs run; DMA pieces follow the even groups
-        u32x4 fb[4], fa[2];
+        // NI groups of NJ MFMAs (one A fragment x NJ B fragments each, the whole 64-B k in one MFMA); the next group's
+        // A fragment is read while this group's MFMAs run; the DMA pieces follow the groups
+        u32x4 fb[NJ], fa[2];
 #pragma unroll
-        for (int j = 0; j < 4; j++) fb[j] = read_b(st, j);
+        for (int j = 0; j < NJ; j++) fb[j] = read_b(st, j);
         fa[0] = read_a(st, 0);
 #pragma unroll
-        for (int i = 0; i < 8; i++) {
-            if (i + 1 < 8) fa[(i + 1) & 1] = read_a(st, i + 1);
+        for (int i = 0; i < NI; i++) {
+            if (i + 1 < NI) fa[(i + 1) & 1] = read_a(st, i + 1);
 #pragma unroll
-            for (int j = 0; j < 4; j++) mfma1(acc[i][j], fa[i & 1], fb[j]);
-            if ((i & 1) == 0) dma_piece(ds, i / 2);
+            for (int j = 0; j < NJ; j++) mfma1(acc[i][j], fa[i & 1], fb[j]);
+            if (NI == 8 ? (i & 1) == 0 : i < Cf::PIECES) dma_piece(ds, NI == 8 ? i / 2 : i);
             __builtin_amdgcn_sched_barrier(0);
         }
         dma_advance();
         cs = cs + 1 == NSTAGE ? 0 : cs + 1;
         ds = ds + 1 == NSTAGE ? 0 : ds + 1;
         if (++c_kt == p.KT) {  // tile finished: its successor's first k-tiles are already in the ring
-            epilogue16<DT, METRIC, DIRECT, XS, BMQ, SH>(p, acc, c_nt, c_mt, wm, wn, lane, qa_s, qb_s, tau_s, thr_s);
+            epilogue16<DT, METRIC, DIRECT, XS, BMQ, SH, WQ, WR>(p, acc, c_nt, c_mt, wm, wn, lane, qa_s, qb_s, tau_s, thr_s);
             zero_acc();
             c_kt = 0;
             if (++c_n < my_tiles) {
@@ -214,7 +224,7 @@ __global__ void __launch_bounds__(512, 2) scan_mfma16_dma_kernel(Batch16Params p
                 slot_tile(c_n, c_nt, nmt);
                 if (nmt != c_mt) {  // block-uniform; rare
                     __syncthreads();
-                    load_query_consts16<DT, METRIC, Cf::BMQ>(p, nmt * BMQ, tid, qa_s, qb_s, tau_s, thr_s);
+                    load_query_consts16<DT, METRIC, BMQ>(p, nmt * BMQ, tid, qa_s, qb_s, tau_s, thr_s);
                     c_mt = nmt;
                 }
             }
@@ -229,40 +239,53 @@ __global__ void __launch_bounds__(512, 2) scan_mfma16_dma_kernel(Batch16Params p
     __builtin_amdgcn_s_waitcnt(0x0070 | 0x0F00);  // vmcnt(0)
 }
 
-template <int DT, int METRIC>
+template <int DT, int METRIC, int BMQ>
 hipError_t launch_dtm(const Batch16Params& p, dim3 grid, hipStream_t s) {
-    void (*fn)(Batch16Params) = p.direct ? &scan_mfma16_dma_kernel<DT, METRIC, true, false> : &scan_mfma16_dma_kernel<DT, METRIC, false, false>;
+    void (*fn)(Batch16Params) =
+        p.direct ? &scan_mfma16_dma_kernel<DT, METRIC, true, false, BMQ> : &scan_mfma16_dma_kernel<DT, METRIC, false, false, BMQ>;
     if constexpr (DT == MVF_DTYPE_FLOAT16)
-        if (p.xscale) fn = p.direct ? &scan_mfma16_dma_kernel<DT, METRIC, true, true> : &scan_mfma16_dma_kernel<DT, METRIC, false, true>;
+        if (p.xscale)
+            fn = p.direct ? &scan_mfma16_dma_kernel<DT, METRIC, true, true, BMQ> : &scan_mfma16_dma_kernel<DT, METRIC, false, true, BMQ>;
     // > 64 KiB of dynamic LDS needs the attribute; it is per device, and one process may drive several devices
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cf::LDS);
+    const size_t lds = CfT<BMQ>::LDS;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(fn, grid, dim3(Cf::NW * 64), Cf::LDS, s, p);
+    hipLaunchKernelGGL(fn, grid, dim3(512), lds, s, p);
     return hipGetLastError();
 }
 
-template <int DT>
+template <int DT, int BMQ>
 hipError_t launch_dt(const Batch16Params& p, int metric, dim3 grid, hipStream_t s) {
     switch (metric) {
-    case MVF_METRIC_L2: return launch_dtm<DT, MVF_METRIC_L2>(p, grid, s);
-    case MVF_METRIC_INNER_PRODUCT: return launch_dtm<DT, MVF_METRIC_INNER_PRODUCT>(p, grid, s);
-    default: return launch_dtm<DT, MVF_METRIC_COSINE>(p, grid, s);
+    case MVF_METRIC_L2: return launch_dtm<DT, MVF_METRIC_L2, BMQ>(p, grid, s);
+    case MVF_METRIC_INNER_PRODUCT: return launch_dtm<DT, MVF_METRIC_INNER_PRODUCT, BMQ>(p, grid, s);
+    default: return launch_dtm<DT, MVF_METRIC_COSINE, BMQ>(p, grid, s);
     }
+}
+
+template <int BMQ>
+hipError_t launch_bmq(const Batch16Params& p, int dtype, int metric, dim3 grid, hipStream_t s) {
+    if (dtype == MVF_DTYPE_FLOAT16) return launch_dt<MVF_DTYPE_FLOAT16, BMQ>(p, metric, grid, s);
+    if (dtype == MVF_DTYPE_UINT8) return launch_dt<MVF_DTYPE_UINT8, BMQ>(p, metric, grid, s);
+    return launch_dt<MVF_DTYPE_INT8, BMQ>(p, metric, grid, s);
 }
 
 }  // namespace
 
-uint32_t scan_mfma16_dma_queries_per_block() { return Cf::BMQ; }
+// queries per block tile for a batch of nq: the 64-query tile (HBM-bound) up to 128 queries, else the 256-query tile
+uint32_t scan_mfma16_dma_queries_per_block(uint32_t nq) {
+    if (const char* e = getenv("MVF_K2_TILE")) return atoi(e) == 64 ? 64u : 256u;
+    return nq <= 128 ? 64u : 256u;
+}
 
-// p.KPB / p.KT are in 64-byte k-tiles here; p.zeros points at >= 16 zero bytes; p.mtiles = nq_pad / 256.
-hipError_t launch_scan_mfma16_dma(const Batch16Params& p, int dtype, int metric, int num_cus, bool persistent, hipStream_t s) {
+// p.KPB / p.KT are in 64-byte k-tiles here; p.zeros points at >= 16 zero bytes; p.mtiles = nq_pad / bmq.
+hipError_t launch_scan_mfma16_dma(const Batch16Params& p, int dtype, int metric, int num_cus, uint32_t bmq, bool persistent,
+                                  hipStream_t s) {
     const uint32_t total = ((p.ntiles + 7) / 8) * p.mtiles * 8;
     uint32_t nls = std::max(1u, (uint32_t)num_cus / 8u);
     if (nls > p.mtiles) nls -= nls % p.mtiles;
     const dim3 grid(persistent ? std::min(total, nls * 8u) : total);
-    if (dtype == MVF_DTYPE_FLOAT16) return launch_dt<MVF_DTYPE_FLOAT16>(p, metric, grid, s);
-    if (dtype == MVF_DTYPE_UINT8) return launch_dt<MVF_DTYPE_UINT8>(p, metric, grid, s);
-    return launch_dt<MVF_DTYPE_INT8>(p, metric, grid, s);
+    return bmq == 64 ? launch_bmq<64>(p, dtype, metric, grid, s) : launch_bmq<256>(p, dtype, metric, grid, s);
 }
 
 }  // namespace mvf

@@ -6,10 +6,10 @@ from oracle import mvf_oracle as O
 from metrovector_amd import gpu as G
 for (n, dim, dt, metric) in ((10_000_000, 768, 0, 2), (12_500_000, 1024, 1, 0), (50_000_000, 768, 2, 1)):
     c = G.GpuCorpus.synthetic(n, dim, dt, 0x4D564631)
-    for nq in (4, 8, 12, 16, 24, 32, 64, 128):
+    for nq in (2, 3, 4, 5, 8, 16, 64, 65, 128, 129):
         q = O.synth_queries(0x4D564632, nq, dim, dt)
         out = []
-        for path in (1, 2):
+        for path in (1, 3):
             c.set_scan_path(path)
             c.search(q, 100, metric)
             t0 = time.time()

@@ -21,9 +21,15 @@ CONFIGS = [  # rows, dim, dtype, metric, nq
     (5_000_000, 768, 3, 1, 129),       # uint8 dot
     (4_000_000, 1000, 0, 0, 513),      # f32 L2 through the shadow, dim not a multiple of 32
     (3_000_000, 768, 0, 1, 5),         # f32 dot, smallest batched size
+    (6_000_000, 384, 1, 2, 64),        # the 64-query tile (HBM-bound block shape): f16 cosine, a full tile
+    (8_000_000, 512, 2, 0, 100),       # int8 L2, two 64-query tiles
+    (5_000_000, 768, 3, 1, 33),        # uint8 dot
+    (10_000_000, 768, 0, 2, 16),       # f32 cosine through the shadow
 ]
 if len(sys.argv) > 2 and sys.argv[2] == "extra":
     CONFIGS = CONFIGS[5:]
+if len(sys.argv) > 2 and sys.argv[2] == "tile64":
+    CONFIGS = CONFIGS[10:]
 def digest(r):
     h = hashlib.sha256()
     for a in (r.scores, r.indices, r.raw):
