@@ -1,15 +1,17 @@
 // scan_mfma16_dma.hip — K2 for the narrow types with LDS-DMA staging.
 //
-// Same tile, MFMAs, persistent XCD-aware schedule and epilogue as scan_mfma16.hip (which stages through registers);
-// what differs is how the operands reach LDS.  The register-staged kernel spends ~830 of ~3600 cycles per 128-B
+// Same role, persistent XCD-aware schedule and epilogue as scan_mfma16.hip (which stages through registers and is kept
+// as the A/B reference); what differs is how the operands reach LDS, the MFMA shape and a second, HBM-bound block shape
+// for small batches.  The register-staged kernel spends ~830 of ~3600 cycles per 128-B
 // k-tile on the VGPR->LDS store path alone (ds_write_b128 moves ~79 B/clk/CU) plus the waits in front of it.  Here
 // every operand byte goes global -> LDS directly (global_load_lds_dwordx4, no VGPRs, no ds_write):
 //
-//   * k-tile = 64 bytes per row (64 int8 / 32 f16) = the k of one 16x16 MFMA; stage = 256 A rows + 256 B rows x 64 B = 32 KB;
-//     a RING of 4 stages (128 KB).  During k-tile g the block computes stage g & 3 and issues the DMA of k-tile g + 3
-//     into the stage freed by the barrier that ended k-tile g - 1; before the next barrier each wave waits for its
-//     own pieces of k-tile g + 1 with a COUNTED s_waitcnt vmcnt(8): two k-tiles (64 KB per CU) stay in flight
-//     across the barrier, which is what a streamed (HBM-latency) operand needs.
+//   * k-tile = 64 bytes per row (64 int8 / 32 f16) = the k of one 16x16 MFMA; stage = BMQ query rows + 256 corpus rows x
+//     64 B; a RING of S stages (256-query shape: 4 x 32 KB; 64-query shape: 6 x 20 KB, see CfT).  During k-tile g the
+//     block computes stage g mod S and issues the DMA of k-tile g + S - 1 into the stage freed by the barrier that
+//     ended k-tile g - 1; before the next barrier each wave waits for its own pieces of k-tile g + 1 with a COUNTED
+//     s_waitcnt vmcnt(pieces x (S - 2)): S - 2 k-tiles (64 KB of corpus bytes per CU) stay in flight across the
+//     barrier, which is what a streamed (HBM-latency) operand needs.
 //   * one DMA wave-instruction writes 1 KB contiguously (16 rows x 64 B, lane L -> row L>>2, slot L&3), so the LDS
 //     image cannot be padded; it is XOR-swizzled instead: slot = chunk ^ swz((row >> 2) & 3), applied on the per-lane
 //     SOURCE address here and on the fragment reads (conflict-free for ds_read_b128's lane groups).
