@@ -27,6 +27,12 @@ extern "C" {
                      query_dim: u32, nq: u32, k: u32, out_scores: *mut f32, out_indices: *mut u64,
                      out_raw: *mut i32) -> c_int;
     fn mvfgpu_last_error_message() -> *const c_char;
+    /// Rows by GLOBAL index from HBM: the `ScoredVector.vector` payload (similarity_search.rs:18).
+    fn mvfgpu_corpus_gather_rows(corpus: *const MvfGpuCorpus, indices: *const u64, count: u64,
+                                 out_rows: *mut c_void) -> c_int;
+    /// 0 automatic, 1 streaming kernel, 2 exact MFMA on the stored rows, 3 MFMA with the f16 shadow (the automatic
+    /// choice for Float32 spaces), 4 additionally streams the f16 shadow for 1-2 queries (include/mvf_gpu.h).
+    fn mvfgpu_set_scan_path(corpus: *mut MvfGpuCorpus, path: c_int) -> c_int;
 }
 
 fn status_to_error(status: c_int) -> MvfError {
@@ -92,6 +98,45 @@ impl GpuCorpus {
         }
         let _ = self.dimension;
         Ok(indices.into_iter().zip(scores).take_while(|(i, _)| *i != u64::MAX).collect())
+    }
+
+    /// Batched search: `queries` holds `nq` rows of `dimension` f32 values; returns `nq` lists of up to `k` hits.
+    /// Two or more queries on a large space take the MFMA path (include/mvf_gpu.h).
+    pub fn search_batch(&self, metric: DistanceMetric, queries: &[f32], nq: usize, k: usize) -> Result<Vec<Vec<(u64, f32)>>> {
+        let mut scores = vec![0f32; nq * k];
+        let mut indices = vec![0u64; nq * k];
+        let rc = unsafe {
+            mvfgpu_search(self.handle, metric.0, queries.as_ptr() as *const c_void, DataType::Float32.0,
+                          self.dimension, nq as u32, k as u32, scores.as_mut_ptr(), indices.as_mut_ptr(),
+                          std::ptr::null_mut())
+        };
+        if rc != 0 {
+            return Err(status_to_error(rc));
+        }
+        Ok((0..nq)
+            .map(|q| (0..k).map(|j| (indices[q * k + j], scores[q * k + j])).take_while(|(i, _)| *i != u64::MAX).collect())
+            .collect())
+    }
+
+    /// The rows behind a result list, fetched from HBM (f32 spaces): `ScoredVector.vector`.
+    pub fn gather_rows_f32(&self, indices: &[u64]) -> Result<Vec<f32>> {
+        let mut out = vec![0f32; indices.len() * self.dimension as usize];
+        let rc = unsafe {
+            mvfgpu_corpus_gather_rows(self.handle, indices.as_ptr(), indices.len() as u64, out.as_mut_ptr() as *mut c_void)
+        };
+        if rc != 0 {
+            return Err(status_to_error(rc));
+        }
+        Ok(out)
+    }
+
+    /// See `mvfgpu_set_scan_path` in include/mvf_gpu.h.
+    pub fn set_scan_path(&mut self, path: i32) -> Result<()> {
+        let rc = unsafe { mvfgpu_set_scan_path(self.handle, path) };
+        if rc != 0 {
+            return Err(status_to_error(rc));
+        }
+        Ok(())
     }
 }
 
