@@ -588,6 +588,26 @@ def test_stream_shadow_row_dynamic_range(oracle):
             assert_float_topk(metric, res.scores[i], res.indices[i], sc, rows, q[i], k)
 
 
+@pytest.mark.parametrize("dtype,metric,nq,k", [(0, 2, 20000, 10), (1, 0, 6000, 100), (2, 1, 9000, 7), (0, 1, 2000, 1024)])
+def test_batched_very_large_batches(oracle, dtype, metric, nq, k):
+    """Thousands of queries in one call (tens of query tiles, hundreds of MB of per-query candidate buffers): a sample
+    of the queries is checked against the oracle."""
+    n, dim = 120_000, 64
+    rows = oracle.synth_rows(SEED, 0, n, dim, dtype)
+    q = oracle.synth_queries(SEED + 1, nq, dim, dtype)
+    with G.GpuCorpus.from_array(rows) as c:
+        res = c.search(q, k, metric)          # automatic path: MFMA (shadowed for Float32)
+    sample = list(range(0, nq, max(1, nq // 25))) + [nq - 1]
+    if dtype in (2, 3):
+        osc, oidx, oraw = oracle.search(rows, dtype, metric, q[sample], k)
+        assert (res.indices[sample] == oidx).all() and (res.raw[sample] == oraw).all()
+    else:
+        rows32 = rows.astype(np.float32)
+        for i in sample:
+            sc, _, _ = oracle.scores(rows, dtype, metric, q[i])
+            assert_float_topk(metric, res.scores[i], res.indices[i], sc, rows32, q[i], k)
+
+
 def test_batched_path_single_query_forced(oracle):
     rows = oracle.synth_rows(SEED, 0, 3000, 96, 0)
     q = oracle.synth_queries(SEED + 1, 1, 96, 0)
