@@ -299,6 +299,11 @@ bool k2_dma_enabled() {
     return !e || atoi(e) != 0;
 }
 
+uint32_t k2_growth_cap() {  // largest phase-to-phase growth of the K2 scan (MVF_K2_GROWTH overrides, for A/B runs)
+    if (const char* e = getenv("MVF_K2_GROWTH")) return (uint32_t)std::max(2, atoi(e));
+    return 8u;
+}
+
 bool k2_dma_persistent(uint8_t) {  // measured: int8 15 % and f16 5 % faster with one persistent block per CU
     if (const char* e = getenv("MVF_K2_PERSISTENT16")) return atoi(e) != 0;
     return true;
@@ -541,7 +546,7 @@ int search_batched_path(const mvfgpu_corpus* c, uint8_t metric, const void* d_qu
 
     // phase p scans rows [R_p, R_{p+1}); phase 0 passes everything (R_1 = cap rows), later phases grow by g:
     // expected survivors per query k*(g-1) + k carried <= cap/2
-    const uint32_t g = std::min(8u, std::max(2u, cap / (2u * k)));
+    const uint32_t g = std::min(k2_growth_cap(), std::max(2u, cap / (2u * k)));
     uint64_t begin = 0, end = std::min<uint64_t>(n, cap);
     for (;;) {
         const bool last = end >= n;
