@@ -426,9 +426,9 @@ int search_batched_path(const mvfgpu_corpus* c, uint8_t metric, const void* d_qu
     const uint8_t kdtype = use_shadow ? (uint8_t)MVF_DTYPE_FLOAT16 : c->dtype;  // element type the scan kernel reads
     const unsigned char* krows = use_shadow ? static_cast<const unsigned char*>(c->shadow.p) : c->d_rows;
     const uint32_t kpitch = use_shadow ? shadow_pitch(c->dim) : c->pitch;
-    const uint32_t tile_rows = wide ? 128u : 256u;
     const bool dma = !wide && k2_dma_enabled();            // LDS-DMA kernel (default) or the register-staged one
     const uint32_t qpb = wide ? 128u : dma ? scan_mfma16_dma_queries_per_block(nq) : scan_mfma16_queries_per_block(kdtype);
+    const uint32_t tile_rows = wide ? 128u : dma ? scan_mfma16_dma_tile_rows(qpb) : 256u;
     const uint32_t nq_pad = (nq + qpb - 1u) / qpb * qpb;
     const uint32_t ktb = dma ? 64u : 128u;                  // k-tile bytes of the f16/int8 kernel in use
     const uint32_t KT = wide ? (c->dim + 31u) / 32u : (c->dim * elem_size(kdtype) + ktb - 1u) / ktb;

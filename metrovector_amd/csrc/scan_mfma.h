@@ -112,6 +112,7 @@ hipError_t launch_rescore(const RescoreParams& p, int metric, uint32_t nq, hipSt
 uint32_t scan_mfma16_queries_per_block(int dtype);
 hipError_t launch_scan_mfma16(const Batch16Params& p, int dtype, int metric, int num_cus, hipStream_t s);
 uint32_t scan_mfma16_dma_queries_per_block(uint32_t nq);
+uint32_t scan_mfma16_dma_tile_rows(uint32_t bmq);
 hipError_t launch_scan_mfma16_dma(const Batch16Params& p, int dtype, int metric, int num_cus, uint32_t bmq, bool persistent,
                                   hipStream_t s);
 hipError_t launch_prep_queries16(const void* q, int dtype, uint32_t nq, uint32_t nq_pad, uint32_t dim, uint32_t KPB,

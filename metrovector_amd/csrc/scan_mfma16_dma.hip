@@ -44,23 +44,27 @@ namespace {
 
 constexpr int DKB = 64;                       // k-tile bytes per row
 
-// Two block shapes, both 8 waves and 256 corpus rows per tile:
-//   BMQ = 256 queries: waves 2 (queries) x 4 (rows), each 128 x 64 outputs; ring of 4 stages x 32 KB.  MFMA-bound.
-//   BMQ = 64 queries (batches <= 128): waves 1 x 8, each 64 x 32 outputs; a quarter of the MFMA work per corpus byte,
-//     so the kernel is HBM-bound and the ring is deeper instead: 6 stages x 20 KB, four of them in flight.
+// Two block shapes, both 8 waves:
+//   BMQ = 256 queries x 256 corpus rows: waves 2 (queries) x 4 (rows), each 128 x 64 outputs; ring of 4 stages x 32 KB.
+//     MFMA-bound (power-limited).
+//   BMQ = 64 queries x 512 corpus rows (batches <= 128): waves 1 x 8, each 64 x 64 outputs; a quarter of the MFMA work
+//     per corpus byte, so the kernel is HBM-bound: ring of 4 stages x 36 KB, two of them (64 KB of corpus bytes) in
+//     flight, and twice the rows per barrier of the other shape (with 256 rows and 8 MFMAs per wave between barriers
+//     the k-tile iteration was latency-bound at 4.9 TB/s, whatever the ring depth).
 template <int BMQ_> struct CfT {
     static constexpr int NW = 8;
     static constexpr int BMQ = BMQ_;                            // queries (A rows) per block
+    static constexpr int BR = BMQ == 256 ? 256 : 512;           // corpus rows per block tile
     static constexpr int WQ = BMQ == 256 ? 128 : 64;            // a wave's share of the tile: queries ...
-    static constexpr int WR = BMQ == 256 ? 64 : 32;             // ... x corpus rows
-    static constexpr int WN = BROWS / WR;                       // waves along the rows (4 or 8); NW / WN along the queries
-    static constexpr int NSTAGE = BMQ == 256 ? 4 : 6;
+    static constexpr int WR = 64;                               // ... x corpus rows
+    static constexpr int WN = BR / WR;                          // waves along the rows (4 or 8); NW / WN along the queries
+    static constexpr int NSTAGE = 4;
     static constexpr int A_B = BMQ * DKB;                       // bytes of A per stage
-    static constexpr int STAGE_B = A_B + BROWS * DKB;           // A then B
+    static constexpr int STAGE_B = A_B + BR * DKB;              // A then B
     static constexpr int APIECES = BMQ / 16;                    // 1-KB DMA pieces of A per k-tile (16 or 4)
     static constexpr int APW = APIECES >= NW ? APIECES / NW : 1;  // per wave (with 4 pieces, waves 4..7 re-issue 0..3:
                                                                 //  every wave then carries the same vmcnt count)
-    static constexpr int BPW = BROWS / 16 / NW;                 //                                      B
+    static constexpr int BPW = BR / 16 / NW;                    //                                      B
     static constexpr int PIECES = APW + BPW;
     static constexpr int INFLIGHT = PIECES * (NSTAGE - 2);      // pieces left in flight across the barrier
     static constexpr size_t LDS = (size_t)NSTAGE * STAGE_B + 4 * BMQ * 4;  // ring + qaux0 + tau + qaux1 + prefilter
@@ -118,7 +122,7 @@ __global__ void __launch_bounds__(512, 2) scan_mfma16_dma_kernel(Batch16Params p
     auto set_dma_tile = [&](uint32_t n) {
         uint32_t nt, mt;
         slot_tile(n, nt, mt);
-        const uint32_t r0 = p.row_begin + nt * BROWS;
+        const uint32_t r0 = p.row_begin + nt * Cf::BR;
 #pragma unroll
         for (int j = 0; j < Cf::APW; j++)
             a_src[j] = p.qprep + ((size_t)mt * BMQ + (((uint32_t)wave * Cf::APW + j) % Cf::APIECES) * 16u + rl) * p.KPB + cl * 16u;
@@ -211,14 +215,15 @@ __global__ void __launch_bounds__(512, 2) scan_mfma16_dma_kernel(Batch16Params p
             if (i + 1 < NI) fa[(i + 1) & 1] = read_a(st, i + 1);
 #pragma unroll
             for (int j = 0; j < NJ; j++) mfma1(acc[i][j], fa[i & 1], fb[j]);
-            if (NI == 8 ? (i & 1) == 0 : i < Cf::PIECES) dma_piece(ds, NI == 8 ? i / 2 : i);
+            if (NI == 8 ? (i & 1) == 0 : true) dma_piece(ds, NI == 8 ? i / 2 : i);          // 4 pieces over 8 groups, or
+            if (NI == 4 && i == NI - 1 && Cf::PIECES > NI) dma_piece(ds, NI);                    // 5 pieces over 4 groups
             __builtin_amdgcn_sched_barrier(0);
         }
         dma_advance();
         cs = cs + 1 == NSTAGE ? 0 : cs + 1;
         ds = ds + 1 == NSTAGE ? 0 : ds + 1;
         if (++c_kt == p.KT) {  // tile finished: its successor's first k-tiles are already in the ring
-            epilogue16<DT, METRIC, DIRECT, XS, BMQ, SH, WQ, WR>(p, acc, c_nt, c_mt, wm, wn, lane, qa_s, qb_s, tau_s, thr_s);
+            epilogue16<DT, METRIC, DIRECT, XS, BMQ, SH, WQ, WR, Cf::BR>(p, acc, c_nt, c_mt, wm, wn, lane, qa_s, qb_s, tau_s, thr_s);
             zero_acc();
             c_kt = 0;
             if (++c_n < my_tiles) {
@@ -280,7 +285,10 @@ uint32_t scan_mfma16_dma_queries_per_block(uint32_t nq) {
     return nq <= 128 ? 64u : 256u;
 }
 
-// p.KPB / p.KT are in 64-byte k-tiles here; p.zeros points at >= 16 zero bytes; p.mtiles = nq_pad / bmq.
+uint32_t scan_mfma16_dma_tile_rows(uint32_t bmq) { return bmq == 64 ? CfT<64>::BR : CfT<256>::BR; }
+
+// p.KPB / p.KT are in 64-byte k-tiles here; p.zeros points at >= 16 zero bytes; p.mtiles = nq_pad / bmq;
+// p.ntiles = ceil(rows / scan_mfma16_dma_tile_rows(bmq)).
 hipError_t launch_scan_mfma16_dma(const Batch16Params& p, int dtype, int metric, int num_cus, uint32_t bmq, bool persistent,
                                   hipStream_t s) {
     const uint32_t total = ((p.ntiles + 7) / 8) * p.mtiles * 8;
