@@ -11,7 +11,7 @@ from .errors import (BuildError, CorruptedData, DeviceError, DimensionMismatch, 
 from .reader import MvfReader, Vector, VectorSlice, VectorSpace  # noqa: F401,E402  (reference: src/reader.rs, src/vectors/*)
 from .builder import BuiltMvf, MvfBuilder  # noqa: F401,E402                      (reference: src/builder.rs)
 from .gpu import GpuCorpus, SearchResult  # noqa: F401,E402
-from .search import ScoredVector, find_top_k_similar, upload_space  # noqa: F401,E402  (examples/similarity_search.rs:140-176)
+from .search import ScoredVector, find_top_k_similar, find_top_k_similar_batch, upload_space  # noqa: F401,E402  (examples/similarity_search.rs:140-176)
 
 __all__ = ["MvfError", "MvfReader", "VectorSpace", "Vector", "VectorSlice", "MvfBuilder", "BuiltMvf", "GpuCorpus",
-           "SearchResult", "ScoredVector", "find_top_k_similar", "upload_space"]
+           "SearchResult", "ScoredVector", "find_top_k_similar", "find_top_k_similar_batch", "upload_space"]

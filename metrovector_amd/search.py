@@ -72,3 +72,40 @@ def find_top_k_similar(space: VectorSpace, query, k: int, metric: int | None = N
         payload = row.astype(np.float32) if dt in (0, 1) else row.copy()  # as Vector::as_f32 for float spaces
         out.append(ScoredVector(int(idx), float(score), payload))
     return out
+
+
+def find_top_k_similar_batch(space: VectorSpace, queries, k: int, metric: int | None = None,
+                             corpus: GpuCorpus | None = None, device: int = 0,
+                             with_vectors: bool = False) -> list[list[ScoredVector]]:
+    """The batched form: one call for many queries ([nq, dimension]) -- on large spaces two or more queries take the
+    MFMA path (include/mvf_gpu.h).  Same semantics per query as `find_top_k_similar`; the row payloads are fetched only
+    when `with_vectors` is set (nq * k rows)."""
+    if metric is None:
+        metric = int(space.distance_metric())
+    if metric not in (L2, INNER_PRODUCT, COSINE):
+        raise BuildError(f"Unsupported distance metric {metric}")
+    dt = int(space.data_type())
+    q = np.asarray(queries, dtype=_NP_OF[query_dtype_code(dt)])
+    if q.ndim != 2:
+        raise BuildError("queries must be a 2-D array [nq, dimension]")
+    own = corpus is None
+    if own:
+        corpus = upload_space(space, device)
+    try:
+        res = corpus.search(q, k, metric)
+        valid = res.indices != np.uint64(0xFFFFFFFFFFFFFFFF)
+        rows = corpus.gather_rows(res.indices[valid]) if with_vectors else None
+    finally:
+        if own:
+            corpus.close()
+    out, r = [], 0
+    for i in range(q.shape[0]):
+        hits = []
+        for idx, score in zip(res.indices[i][valid[i]], res.scores[i][valid[i]]):
+            payload = None
+            if rows is not None:
+                payload = rows[r].astype(np.float32) if dt in (0, 1) else rows[r].copy()
+                r += 1
+            hits.append(ScoredVector(int(idx), float(score), payload))
+        out.append(hits)
+    return out

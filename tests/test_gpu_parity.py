@@ -70,6 +70,23 @@ def test_find_top_k_similar_on_mvf_file(golden, golden_dir):
         find_top_k_similar(space, [1, 2, 3], 5)
 
 
+def test_find_top_k_similar_batch_agrees_with_the_single_query_drop_in(golden, golden_dir):
+    from metrovector_amd import MvfReader, find_top_k_similar, find_top_k_similar_batch, upload_space
+    r = MvfReader.open(os.path.join(golden_dir, "clusters_60x4_f32.mvf"))
+    space = r.vector_space(r.vector_space_names()[0])
+    cases = golden["similarity_search_60x4"]["cases"]
+    qs = [c["query"] for c in cases] * 20            # 60+ queries: the batched (MFMA) path even on a tiny space
+    with upload_space(space) as corpus:
+        batch = find_top_k_similar_batch(space, qs, 5, corpus=corpus, with_vectors=True)
+        for q, hits in zip(qs, batch):
+            single = find_top_k_similar(space, q, 5, corpus=corpus)
+            assert [h.index for h in hits] == [s.index for s in single]
+            np.testing.assert_allclose([h.score for h in hits], [s.score for s in single], rtol=1e-5, atol=1e-7)
+            assert all((h.vector == s.vector).all() for h, s in zip(hits, single))
+    with pytest.raises(E.BuildError):
+        find_top_k_similar_batch(space, [1, 2, 3, 4], 5)      # 1-D: not a batch
+
+
 def test_multi_space_file_all_dtypes(oracle, golden_dir):
     from metrovector_amd.reader import MvfReader
     from metrovector_amd.search import find_top_k_similar, upload_space
