@@ -57,6 +57,9 @@ typedef struct mvf_vector_space {
     uint32_t vector_ids_block_index;
     uint8_t has_sparse_metadata;
     uint8_t has_tombstones;
+    uint8_t tombstone_format;         /* TombstoneInfo (schema/core.fbs:35-39): 0 None, 1 Bitmap, 2 SortedList */
+    uint32_t tombstone_block_index;   /* "0 if no deletions" */
+    uint64_t tombstone_deleted_count;
 } mvf_vector_space;
 
 /* VectorSlice (src/vectors/mem.rs:24-30): what the GPU boundary consumes. */
@@ -96,6 +99,21 @@ int mvf_reader_validate_with_checksum(const mvf_reader* r);
 int mvf_space_get_vector(const mvf_vector_space* s, uint64_t index, const void** data, uint64_t* len);
 /* map_vector_range, vector_space.rs:155-188. */
 int mvf_space_map_vector_range(const mvf_vector_space* s, uint64_t start, uint64_t count, mvf_vector_slice* out);
+/*
+ * Vector ids and deletions (schema/core.fbs:54, :56, :35-39).  The reference neither writes nor reads them
+ * (src/builder.rs:483-485: always 0 / None), so the block layouts are defined here in the schema's words:
+ *   vector_ids block : one u64 LE per row; vector_ids_block_index 0 = "use positions as IDs";
+ *   Bitmap           : bit (r & 7) of byte (r >> 3) set = the row at POSITION r is deleted;
+ *   SortedList       : ascending u64 LE deleted ids -- vector ids when the space has an id block, else positions.
+ * mvf_space_vector_ids returns a borrowed, possibly UNALIGNED pointer into the mapping (NULL when positions are
+ * the ids); mvf_space_tombstone_bitmap expands either tombstone format into a position bitmap of
+ * (total_vectors + 7) / 8 bytes (all zero without deletions) -- the form mvfgpu_corpus_set_tombstones consumes.
+ * Compressed blocks (schema/types.fbs:28-32) are refused everywhere with MVF_ERR_BUILD: the reference has no codec.
+ */
+int mvf_space_vector_ids(const mvf_vector_space* s, const void** ids_le, uint64_t* count);
+int mvf_space_tombstones(const mvf_vector_space* s, uint8_t* format, const void** data, uint64_t* size,
+                         uint64_t* deleted_count);
+int mvf_space_tombstone_bitmap(const mvf_vector_space* s, uint8_t* bitmap, uint64_t nbytes, uint64_t* deleted);
 /* Vector::as_f32, vector.rs:71-92: decodes len/elem_size values into out
  * (capacity `cap` floats); Int8/UInt8/others -> MVF_ERR_BUILD "Cannot convert to f32". */
 int mvf_vector_as_f32(const void* data, uint64_t len, uint8_t data_type, float* out, uint64_t cap, uint64_t* n_out);
@@ -114,6 +132,10 @@ int mvf_builder_add_vectors_f32(mvf_builder* b, const char* space_name, const fl
  * the space's storage type — the only way to write Int8/UInt8 spaces. */
 int mvf_builder_add_vectors_raw(mvf_builder* b, const char* space_name, const void* rows, uint64_t n_vectors,
                                 uint32_t dimension);
+/* EXTENSION: the reference's builder has the fields (builder.rs:61-63) but no setter. */
+int mvf_builder_set_vector_ids(mvf_builder* b, const char* space_name, const uint64_t* ids, uint64_t n);
+int mvf_builder_set_tombstones(mvf_builder* b, const char* space_name, uint8_t format, const void* data, uint64_t len,
+                               uint64_t deleted_count);
 int mvf_builder_add_metadata_column(mvf_builder* b, const char* name, uint8_t data_type, const void* bytes,
                                     uint64_t len);                      /* :211-236 */
 /*

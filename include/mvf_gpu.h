@@ -60,10 +60,11 @@ typedef struct mvfgpu_corpus_info {
     uint32_t dimension;
     uint32_t pitch_bytes; /* device row pitch: dimension*elem_size rounded up to 16 */
     uint8_t data_type;    /* enum mvf_data_type */
-    uint8_t reserved[3];
+    uint8_t reserved[3];  /* [0]: 1 when vector ids are attached (searches then report ids, not positions) */
     int32_t device;
     uint64_t device_bytes; /* HBM held by the handle: rows, norms, scratch and, once a batched search has built
                               it, the f16 shadow of a Float32 corpus */
+    uint64_t deleted_rows; /* rows masked by the tombstone bitmap */
 } mvfgpu_corpus_info;
 
 typedef struct mvfgpu_timing {
@@ -115,6 +116,30 @@ int mvfgpu_corpus_create(const void* rows, uint64_t n, uint32_t dimension,
                          uint64_t index_base, mvfgpu_corpus** out);
 
 /*
+ * The same upload with options (NULL = the defaults of mvfgpu_corpus_create).  The upload is a two-stream pipeline
+ * (DESIGN.md §6): chunks of `chunk_mib` MiB (0 = 256) cross PCIe on one stream while the other re-pitches the chunk
+ * before (rows whose size is not a multiple of 16 bytes, or that lie further apart than their size) and, on request,
+ * computes what the first BATCHED search would otherwise build -- the row norms, and for Float32 spaces the scaled-f16
+ * shadow used for candidate selection (+50 % device memory; skipped silently when that would leave < 2 GiB free).
+ * Checksum validation of the block (the reference leaves it `todo!()`, src/reader.rs:220) lives in libmvf_host
+ * (mvf_reader_validate_with_checksum): run it on another thread beside this call.
+ */
+typedef struct mvfgpu_upload_options {
+    uint32_t struct_size; /* sizeof(mvfgpu_upload_options): lets the struct grow */
+    uint32_t flags;       /* MVFGPU_UPLOAD_* */
+    uint32_t chunk_mib;   /* chunk size in MiB, 0 = 256 */
+    uint32_t reserved;
+} mvfgpu_upload_options;
+#define MVFGPU_UPLOAD_EAGER_NORMS 1u    /* row norms (K4) per chunk, beside the copy of the next */
+#define MVFGPU_UPLOAD_EAGER_SHADOW 2u   /* Float32 spaces: norms + the f16 shadow per chunk */
+#define MVFGPU_UPLOAD_PINNED_STAGING 4u /* double-buffer through pinned host chunks filled by memcpy threads instead of
+                                           handing the pageable source to the runtime (A/B: scripts/probe_upload.py) */
+int mvfgpu_corpus_create_ex(const void* rows, uint64_t n, uint32_t dimension,
+                            uint8_t data_type, uint64_t stride_bytes, int device,
+                            uint64_t index_base, const mvfgpu_upload_options* options,
+                            mvfgpu_corpus** out);
+
+/*
  * Generate rows [row0, row0+n) of the synthetic corpus on the device
  * (counter-based: element (r,c) = f(seed, r*dimension + c), DESIGN.md §6 —
  * the CPU oracle regenerates any row).  index_base = row0.
@@ -139,6 +164,23 @@ int mvfgpu_corpus_read_rows(const mvfgpu_corpus* corpus, uint64_t first,
  * [index_base, index_base + rows) -> MVF_ERR_INDEX_OUT_OF_BOUNDS. */
 int mvfgpu_corpus_gather_rows(const mvfgpu_corpus* corpus, const uint64_t* indices,
                               uint64_t count, void* out_rows);
+
+/*
+ * Deletions and vector ids (schema/core.fbs:35-39 TombstoneInfo, :54 vector_ids_block_index, :56 tombstones).  The
+ * reference neither writes nor honours them (src/builder.rs:483-485), so the semantics are this library's:
+ *   - tombstones: bit (first_bit + r) of `bitmap` (bit b of a byte array = byte b >> 3, bit b & 7) set = the shard's
+ *     LOCAL row r is deleted; `nbits` = bits the array holds, >= first_bit + rows.  A deleted row is never returned: the
+ *     streaming kernel tests the bit where a row would enter a candidate list, the MFMA kernels where a candidate is
+ *     appended.  libmvf_host's mvf_space_tombstone_bitmap produces the bitmap from either on-disk format; pass the
+ *     whole space's bitmap with first_bit = the shard's first row.  NULL / 0 removes the mask.
+ *   - vector ids: one u64 (little endian, any alignment) per LOCAL row; searches then report ids[row] instead of
+ *     index_base + row (ties still break by row position, then -- across shards -- by shard order), and
+ *     mvfgpu_corpus_gather_rows accepts the reported ids.  NULL / 0 removes them.
+ * Both calls wait for the device to go idle; like create / destroy they must not race with searches on the handle.
+ */
+int mvfgpu_corpus_set_tombstones(mvfgpu_corpus* corpus, const uint8_t* bitmap,
+                                 uint64_t first_bit, uint64_t nbits);
+int mvfgpu_corpus_set_vector_ids(mvfgpu_corpus* corpus, const void* ids_le, uint64_t n);
 
 /* ---- search -------------------------------------------------------------- */
 
@@ -186,7 +228,11 @@ int mvfgpu_search_device(const mvfgpu_corpus* corpus, uint8_t metric,
 /*
  * Merge `nlists` per-shard results, each [nq][k] sorted best-first with
  * UINT64_MAX padding, laid out [nlists][nq][k], into the global [nq][k]
- * ordered by (score order, global index).  data_type tells whether `raw`
+ * ordered by (score order, list order, rank inside the list).  The lists must
+ * come in ASCENDING ROW-RANGE ORDER (the rank order of an all-gather): each is
+ * sorted by (score order, row position), so ties come out in ascending global
+ * row position -- also when the shards report vector ids instead of positions
+ * (mvfgpu_corpus_set_vector_ids).  nlists * k <= 8192.  data_type tells whether `raw`
  * carries the exact integer score (Int8/UInt8 with L2/InnerProduct).
  * _host: plain host buffers, no GPU needed.  _device: device buffers on
  * `device` (e.g. the output of an RCCL all-gather), async on hip_stream.

@@ -13,7 +13,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-GPU_LIB_PATH = os.path.join(_HERE, "libmvf_gpu.so")
+GPU_LIB_PATH = os.environ.get("MVF_GPU_LIB_PATH") or os.path.join(_HERE, "libmvf_gpu.so")  # override: diagnostic builds
 HOST_LIB_PATH = os.path.join(_HERE, "libmvf_host.so")
 
 _gpu = None
@@ -23,7 +23,14 @@ _host = None
 class CorpusInfo(C.Structure):
     _fields_ = [("rows", C.c_uint64), ("index_base", C.c_uint64), ("dimension", C.c_uint32),
                 ("pitch_bytes", C.c_uint32), ("data_type", C.c_uint8), ("reserved", C.c_uint8 * 3),
-                ("device", C.c_int32), ("device_bytes", C.c_uint64)]
+                ("device", C.c_int32), ("device_bytes", C.c_uint64), ("deleted_rows", C.c_uint64)]
+
+
+class UploadOptions(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("flags", C.c_uint32), ("chunk_mib", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+UPLOAD_EAGER_NORMS, UPLOAD_EAGER_SHADOW, UPLOAD_PINNED_STAGING = 1, 2, 4
 
 
 class Timing(C.Structure):
@@ -63,6 +70,9 @@ def gpu() -> C.CDLL:
     lib.mvfgpu_last_error_message.restype = C.c_char_p
     lib.mvfgpu_last_error_message.argtypes = []
     lib.mvfgpu_corpus_create.argtypes = [vp, u64, u32, u8, u64, i32, u64, pp]
+    lib.mvfgpu_corpus_create_ex.argtypes = [vp, u64, u32, u8, u64, i32, u64, C.POINTER(UploadOptions), pp]
+    lib.mvfgpu_corpus_set_tombstones.argtypes = [vp, vp, u64, u64]
+    lib.mvfgpu_corpus_set_vector_ids.argtypes = [vp, vp, u64]
     lib.mvfgpu_corpus_create_synthetic.argtypes = [u64, u32, u8, u64, u64, i32, pp]
     lib.mvfgpu_corpus_destroy.restype = None
     lib.mvfgpu_corpus_destroy.argtypes = [vp]
@@ -78,7 +88,8 @@ def gpu() -> C.CDLL:
     lib.mvfgpu_set_profiling.argtypes = [vp, i32]
     lib.mvfgpu_last_timing.argtypes = [vp, C.POINTER(Timing)]
     lib.mvfgpu_set_scan_path.argtypes = [vp, i32]
-    for name in ("mvfgpu_device_count", "mvfgpu_corpus_create", "mvfgpu_corpus_create_synthetic",
+    for name in ("mvfgpu_device_count", "mvfgpu_corpus_create", "mvfgpu_corpus_create_ex", "mvfgpu_corpus_create_synthetic",
+                 "mvfgpu_corpus_set_tombstones", "mvfgpu_corpus_set_vector_ids",
                  "mvfgpu_corpus_get_info", "mvfgpu_corpus_read_rows", "mvfgpu_corpus_gather_rows", "mvfgpu_search", "mvfgpu_search_device",
                  "mvfgpu_merge_topk_host", "mvfgpu_merge_topk_device", "mvfgpu_merge_topk_packed_device",
                  "mvfgpu_synth_queries_device",
@@ -98,7 +109,8 @@ class CVectorSpace(C.Structure):
                 ("dimension", C.c_uint32), ("total_vectors", C.c_uint64), ("vector_type", C.c_uint8),
                 ("distance_metric", C.c_uint8), ("data_type", C.c_uint8), ("index_type", C.c_uint8),
                 ("vectors_block_index", C.c_uint32), ("vector_ids_block_index", C.c_uint32),
-                ("has_sparse_metadata", C.c_uint8), ("has_tombstones", C.c_uint8)]
+                ("has_sparse_metadata", C.c_uint8), ("has_tombstones", C.c_uint8), ("tombstone_format", C.c_uint8),
+                ("tombstone_block_index", C.c_uint32), ("tombstone_deleted_count", C.c_uint64)]
 
 
 class CVectorSlice(C.Structure):
@@ -138,6 +150,11 @@ def host() -> C.CDLL:
     lib.mvf_space_get_vector.argtypes = [C.POINTER(CVectorSpace), u64, pp, C.POINTER(u64)]
     lib.mvf_space_map_vector_range.argtypes = [C.POINTER(CVectorSpace), u64, u64, C.POINTER(CVectorSlice)]
     lib.mvf_vector_as_f32.argtypes = [vp, u64, u8, vp, u64, C.POINTER(u64)]
+    lib.mvf_space_vector_ids.argtypes = [C.POINTER(CVectorSpace), pp, C.POINTER(u64)]
+    lib.mvf_space_tombstones.argtypes = [C.POINTER(CVectorSpace), C.POINTER(u8), pp, C.POINTER(u64), C.POINTER(u64)]
+    lib.mvf_space_tombstone_bitmap.argtypes = [C.POINTER(CVectorSpace), vp, u64, C.POINTER(u64)]
+    lib.mvf_builder_set_vector_ids.argtypes = [vp, C.c_char_p, vp, u64]
+    lib.mvf_builder_set_tombstones.argtypes = [vp, C.c_char_p, u8, vp, u64, u64]
     lib.mvf_builder_new.argtypes = [pp]
     lib.mvf_builder_free.restype = None
     lib.mvf_builder_free.argtypes = [vp]

@@ -78,6 +78,18 @@ class MvfBuilder:
         _lib.host_check(_lib.host().mvf_builder_add_vectors_raw(self._h, space_name.encode(), a.ctypes.data_as(C.c_void_p),
                                                                 a.shape[0], a.shape[1]))
 
+    def set_vector_ids(self, space_name: str, ids) -> None:
+        """EXTENSION: one u64 id per row (the reference's builder has the field, builder.rs:61, but no setter)."""
+        a = np.ascontiguousarray(ids, dtype=np.uint64)
+        _lib.host_check(_lib.host().mvf_builder_set_vector_ids(self._h, space_name.encode(), a.ctypes.data_as(C.c_void_p), a.size))
+
+    def set_tombstones(self, space_name: str, fmt: int, payload: bytes, deleted_count: int) -> None:
+        """EXTENSION: a deletion block -- fmt 1 Bitmap (bit per row position, LSB first), 2 SortedList (ascending
+        u64 LE ids); TombstoneFormat, schema/types.fbs:35-39."""
+        buf = (C.c_uint8 * len(payload)).from_buffer_copy(payload) if payload else None
+        _lib.host_check(_lib.host().mvf_builder_set_tombstones(self._h, space_name.encode(), int(fmt), buf, len(payload),
+                                                               int(deleted_count)))
+
     def add_metadata_column(self, name: str, data_type: int, values: bytes) -> None:  # builder.rs:211-236
         buf = (C.c_uint8 * len(values)).from_buffer_copy(values) if values else None
         _lib.host_check(_lib.host().mvf_builder_add_metadata_column(self._h, name.encode(), int(data_type), buf, len(values)))

@@ -17,6 +17,7 @@
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 using namespace mvf;
@@ -86,11 +87,16 @@ struct mvfgpu_corpus {
     mutable DevBuf bq, bstate, bcand, xnorm;  // K2: padded queries + norms; tau/cnt/overflow; candidates; row norms
     mutable DevBuf repair;                // K2 overflow repair: gathered queries + their results
     mutable DevBuf shadow, xscale;        // Float32 corpora: scaled-f16 shadow rows (selection only) + 2^-s_r per row
+    DevBuf tomb, ids;                     // deletion bitmap (u32 words over local rows) / vector ids (u64 per local row)
+    uint64_t deleted = 0;                 // bits set in the bitmap
+    std::vector<uint64_t> h_ids;          // host copy of the ids ...
+    mutable std::vector<std::pair<uint64_t, uint32_t>> id_index;  // ... and, built by the first gather, (id, row) sorted by id
     mutable int shadow_state = 0;         // 0 not built yet, 1 ready, -1 unavailable (no memory)
     mutable bool xnorm_ready = false;
     mutable uint32_t bstate_slots = 0;    // queries the K2 state arrays are armed for
     mutable DevBuf h_q, h_s, h_i, h_r;    // device mirrors for the host-buffer API
     mutable hipStream_t own_stream = nullptr;
+    hipStream_t up_stream = nullptr;      // upload pipeline: re-pitch / norms / shadow of chunk i beside the copy of chunk i+1
     mutable hipEvent_t ev_done = nullptr;
     mutable hipStream_t last_stream = nullptr;
     mutable bool has_done = false;
@@ -234,6 +240,7 @@ int search_stream_path(const mvfgpu_corpus* c, uint8_t metric, const void* d_que
             sp.rows = alt ? alt->rows : c->d_rows;
             sp.xscale = alt ? alt->xscale : nullptr;
             sp.queries = d_queries;
+            sp.tomb = static_cast<const uint32_t*>(c->tomb.p);
             sp.cand = static_cast<uint64_t*>(c->cand.p);
             sp.n = (uint32_t)c->n;
             sp.pitch = alt ? alt->pitch : c->pitch;
@@ -269,6 +276,7 @@ int search_stream_path(const mvfgpu_corpus* c, uint8_t metric, const void* d_que
             fp.metric = metric;
             fp.dtype = c->dtype;
             fp.index_base = c->index_base;
+            fp.ids = static_cast<const uint64_t*>(c->ids.p);
             if (alt) {
                 fp.out_cand = alt->cand + (size_t)q0 * alt->cand_cap;
                 fp.out_cnt = alt->cnt + q0;
@@ -296,6 +304,12 @@ int search_stream_path(const mvfgpu_corpus* c, uint8_t metric, const void* d_que
 // register-staged scan_mfma16.hip (kept as the A/B reference: same results, ~7 % slower).
 bool k2_dma_enabled() {
     const char* e = getenv("MVF_K2_DMA");
+    return !e || atoi(e) != 0;
+}
+
+// 256-query tile: the ping-pong schedule (scan_mfma16_pp.hip) or, with MVF_K2_PP=0, the lockstep LDS-DMA kernel
+bool k2_pp_enabled() {
+    const char* e = getenv("MVF_K2_PP");
     return !e || atoi(e) != 0;
 }
 
@@ -330,7 +344,7 @@ hipError_t ensure_shadow(const mvfgpu_corpus* c, hipStream_t s, bool insist) {
             return hipSuccess;
         }
     }
-    if (c->shadow.reserve(need) != hipSuccess || c->xscale.reserve((size_t)std::max<uint64_t>(c->n, 1) * 4) != hipSuccess) {
+    if (c->shadow.reserve(need) != hipSuccess || c->xscale.reserve(((size_t)std::max<uint64_t>(c->n, 1) + 256) * 4) != hipSuccess) {
         (void)hipGetLastError();
         c->shadow.release();
         c->xscale.release();
@@ -357,15 +371,22 @@ int ensure_bstate(const mvfgpu_corpus* c, uint32_t nq_pad, hipStream_t s) {
 // K4: per-row norms of the STORED rows, once per resident corpus (a shadow only feeds the dot products).
 // float rows: |x| [n], sum x^2 [n], max sum x^2 [1]; Int8 rows: sum x^2 (i32) [n]; UInt8 rows: sum (x-128)^2 [n],
 // 128 * sum (x-128) [n]
+// Layout: two arrays of norm_stride(n) entries (a multiple of 256, so both are 1-KB aligned), 256 entries of padding
+// (the ping-pong K2 kernel DMAs the 256 entries of a row tile at once, also for the corpus' last, partial tile), then
+// the one-element maximum.
+size_t norm_stride(uint64_t n) { return ((size_t)std::max<uint64_t>(n, 1) + 255u) & ~(size_t)255u; }
+size_t norm_max_at(uint64_t n) { return 2 * norm_stride(n) + 256; }
+
 int ensure_norms(const mvfgpu_corpus* c, hipStream_t s) {
     if (c->xnorm_ready) return MVF_OK;
     const uint32_t n = (uint32_t)c->n;
-    const size_t nn = std::max<uint32_t>(n, 1);
-    HIP_TRY(c->xnorm.reserve((2 * nn + 1) * 4));
+    const size_t nn = norm_stride(n);
+    HIP_TRY(c->xnorm.reserve((norm_max_at(n) + 1) * 4));
     float* xn = static_cast<float*>(c->xnorm.p);
-    if (!is_int_dtype(c->dtype)) HIP_TRY(hipMemsetAsync(xn + 2 * nn, 0, 4, s));
-    if (c->dtype == MVF_DTYPE_FLOAT32) HIP_TRY(launch_row_norms_f32(c->d_rows, n, c->pitch, xn, xn + nn, xn + 2 * nn, s));
-    else HIP_TRY(launch_row_norms16(c->d_rows, c->dtype, n, c->pitch, c->dim, c->xnorm.p, xn + nn, xn + 2 * nn, s));
+    float* xmax = xn + norm_max_at(n);
+    if (!is_int_dtype(c->dtype)) HIP_TRY(hipMemsetAsync(xmax, 0, 4, s));
+    if (c->dtype == MVF_DTYPE_FLOAT32) HIP_TRY(launch_row_norms_f32(c->d_rows, n, c->pitch, xn, xn + nn, xmax, s));
+    else HIP_TRY(launch_row_norms16(c->d_rows, c->dtype, n, c->pitch, c->dim, c->xnorm.p, xn + nn, xmax, s));
     c->xnorm_ready = true;
     return MVF_OK;
 }
@@ -456,13 +477,13 @@ int search_batched_path(const mvfgpu_corpus* c, uint8_t metric, const void* d_qu
     // (single f16 query plane); the other combinations carry final keys through the phases
     const bool approx = is_float && (metric == MVF_METRIC_L2 || kdtype == MVF_DTYPE_FLOAT16);
     const bool need_norms = approx || metric != MVF_METRIC_INNER_PRODUCT || c->dtype == MVF_DTYPE_UINT8;
-    const size_t nn = std::max<uint32_t>(n, 1);
+    const size_t nn = norm_stride(n);
     if (need_norms) {
         int rc = ensure_norms(c, s);
         if (rc != MVF_OK) return rc;
     }
     const float* xx2 = is_float && c->xnorm.p ? static_cast<const float*>(c->xnorm.p) + nn : nullptr;
-    const float* xxmax = is_float && c->xnorm.p ? static_cast<const float*>(c->xnorm.p) + 2 * nn : nullptr;
+    const float* xxmax = is_float && c->xnorm.p ? static_cast<const float*>(c->xnorm.p) + norm_max_at(n) : nullptr;
     if (wide)
         HIP_TRY(launch_prep_queries(static_cast<const float*>(d_queries), nq, nq_pad, c->dim, KPB / 4,
                                     reinterpret_cast<float*>(qprep), qaux0, s));
@@ -476,6 +497,7 @@ int search_batched_path(const mvfgpu_corpus* c, uint8_t metric, const void* d_qu
     bp.xnorm = static_cast<const float*>(c->xnorm.p);
     bp.xx2 = xx2;
     bp.xxmax = xxmax;
+    bp.tomb = static_cast<const uint32_t*>(c->tomb.p);
     bp.tau = tau;
     bp.cand = static_cast<uint64_t*>(c->bcand.p);
     bp.cnt = cnt;
@@ -500,6 +522,7 @@ int search_batched_path(const mvfgpu_corpus* c, uint8_t metric, const void* d_qu
     hp.dim = c->dim;
     hp.xx2 = xx2;
     hp.xxmax = xxmax;
+    hp.tomb = bp.tomb;
     hp.tau = tau;
     hp.cand = bp.cand;
     hp.cnt = cnt;
@@ -522,6 +545,7 @@ int search_batched_path(const mvfgpu_corpus* c, uint8_t metric, const void* d_qu
     cp.metric = metric;
     cp.dtype = c->dtype;
     cp.index_base = c->index_base;
+    cp.ids = static_cast<const uint64_t*>(c->ids.p);
     cp.out_scores = d_scores;
     cp.out_indices = d_indices;
     cp.out_raw = d_raw;
@@ -557,6 +581,8 @@ int search_batched_path(const mvfgpu_corpus* c, uint8_t metric, const void* d_qu
             bp.direct = hp.direct = (begin == 0 && end - begin <= cap) ? 1u : 0u;
             if (ps && last) HIP_TRY(hipEventRecord(ps->e[0], s));
             if (wide) HIP_TRY(launch_scan_mfma_f32(bp, metric, c->num_cus, s));
+            else if (dma && qpb == 256u && k2_pp_enabled() && scan_mfma16_pp_usable(hp.mtiles, c->num_cus, KT))
+                HIP_TRY(launch_scan_mfma16_pp(hp, kdtype, metric, c->num_cus, s));
             else if (dma) HIP_TRY(launch_scan_mfma16_dma(hp, kdtype, metric, c->num_cus, qpb, k2_dma_persistent(kdtype), s));
             else HIP_TRY(launch_scan_mfma16(hp, kdtype, metric, c->num_cus, s));
             if (ps && last) {
@@ -587,6 +613,7 @@ int search_batched_path(const mvfgpu_corpus* c, uint8_t metric, const void* d_qu
         rp.dim = c->dim;
         rp.dtype = c->dtype;
         rp.index_base = c->index_base;
+        rp.ids = static_cast<const uint64_t*>(c->ids.p);
         rp.out_scores = d_scores;
         rp.out_indices = d_indices;
         rp.out_raw = d_raw;
@@ -614,7 +641,6 @@ int search_stream_shadow_path(const mvfgpu_corpus* c, uint8_t metric, const void
     const uint32_t cap = kBatchCap;
     const uint32_t nq_pad = (nq + 255u) & ~255u;
     const uint32_t n = (uint32_t)c->n;
-    const size_t nn = std::max<uint32_t>(n, 1);
     int rc = ensure_bstate(c, nq_pad, s);
     if (rc == MVF_OK) rc = ensure_norms(c, s);
     if (rc != MVF_OK) return rc;
@@ -653,8 +679,9 @@ int search_stream_shadow_path(const mvfgpu_corpus* c, uint8_t metric, const void
     cp.metric = metric;
     cp.dtype = c->dtype;
     cp.index_base = c->index_base;
+    cp.ids = static_cast<const uint64_t*>(c->ids.p);
     cp.qnorm = qaux1;
-    cp.xxmax = static_cast<const float*>(c->xnorm.p) + 2 * nn;
+    cp.xxmax = static_cast<const float*>(c->xnorm.p) + norm_max_at(n);
     // per-element relative rounding of the shadow rows (2^-11) and f32 accumulation of `dim` terms ((dim + 16) 2^-23
     // of the sum; half of that, relative, on a square root)
     const float e11 = 4.8828125e-4f * 1.001f, eacc = (float)(std::max<uint32_t>(c->dim, 64) + 16) * 1.1920929e-7f;
@@ -676,6 +703,7 @@ int search_stream_shadow_path(const mvfgpu_corpus* c, uint8_t metric, const void
     rp.dim = c->dim;
     rp.dtype = c->dtype;
     rp.index_base = c->index_base;
+    rp.ids = static_cast<const uint64_t*>(c->ids.p);
     rp.out_scores = d_scores;
     rp.out_indices = d_indices;
     rp.out_raw = d_raw;
@@ -714,6 +742,147 @@ bool use_batched_path(const mvfgpu_corpus* c, uint8_t metric, uint32_t nq) {
                                : is_int_dtype(c->dtype)                     ? 5u
                                                                             : 2u;
     return nq >= threshold;
+}
+
+// ---- upload pipeline: the step in front of the path ------------------------------------------------
+// The host rows (an mmap'd MVF block: any alignment, stride >= row bytes) reach HBM in chunks on the copy stream while
+// a second stream re-pitches, and -- on request -- computes the row norms (K4) and the f16 shadow of the chunk before:
+//   copy stream   : H2D chunk i           | H2D chunk i+1            | ...
+//   compute stream:   (wait ev_copy[i])  re-pitch i, norms i, shadow i |  ...
+// so a corpus that will serve batched searches is ready for the first of them when the last chunk lands.
+//   * rows tightly packed and a multiple of 16 B: chunks go straight to their place (no staging, no re-pitch);
+//   * otherwise a chunk is copied AS IT LIES (gaps included) into one of two device staging buffers and the re-pitch
+//     kernel reads it with the host stride -- only row_bytes of each row are read from the stage, the 16-B padding
+//     is written as zeros (K1, the norms and the shadow all consume whole 16-B vectors).  Rows further apart than
+//     twice their size go through hipMemcpy2DAsync instead (no point in moving the gaps over PCIe).
+//   * source memory: pageable by default -- the runtime's own pinned bounce buffers already move a 1-D copy from
+//     pageable / mmap'd memory at ~56 of the 63 GB/s PCIe Gen5 x16 offers; MVFGPU_UPLOAD_PINNED_STAGING instead
+//     double-buffers through two pinned host chunks filled by a pool of memcpy threads (A/B: scripts/probe_upload.py).
+struct PinnedPair {
+    void* p[2] = {nullptr, nullptr};
+    ~PinnedPair() {
+        for (auto q : p)
+            if (q) (void)hipHostFree(q);
+    }
+};
+struct StagePair {
+    unsigned char* p[2] = {nullptr, nullptr};
+    ~StagePair() {
+        for (auto q : p)
+            if (q) (void)hipFree(q);
+    }
+};
+struct EventSet {
+    hipEvent_t e[6] = {};
+    ~EventSet() {
+        for (auto q : e)
+            if (q) (void)hipEventDestroy(q);
+    }
+};
+
+void parallel_memcpy(void* dst, const void* src, size_t bytes, unsigned threads) {
+    if (threads <= 1 || bytes < ((size_t)8 << 20)) {
+        std::memcpy(dst, src, bytes);
+        return;
+    }
+    std::vector<std::thread> pool;
+    const size_t part = ((bytes / threads) + 4095) & ~(size_t)4095;
+    for (unsigned t = 0; t < threads; t++) {
+        const size_t o = (size_t)t * part;
+        if (o >= bytes) break;
+        const size_t len = std::min(part, bytes - o);
+        pool.emplace_back([=] { std::memcpy(static_cast<char*>(dst) + o, static_cast<const char*>(src) + o, len); });
+    }
+    for (auto& t : pool) t.join();
+}
+
+int upload_rows(mvfgpu_corpus* c, const void* rows, uint64_t stride, const mvfgpu_upload_options& o) {
+    const uint64_t n = c->n, row_bytes = (uint64_t)c->dim * elem_size(c->dtype);
+    const bool direct = stride == row_bytes && row_bytes == c->pitch;
+    const bool sparse = !direct && stride > 2 * row_bytes;  // 2-D copies: do not move the gaps
+    const bool pinned = (o.flags & MVFGPU_UPLOAD_PINNED_STAGING) != 0 && !sparse;
+    const uint64_t chunk_bytes = (uint64_t)(o.chunk_mib ? o.chunk_mib : 256u) << 20;
+    const uint64_t chunk_rows = std::max<uint64_t>(1, chunk_bytes / stride);
+    const unsigned char* src = static_cast<const unsigned char*>(rows);
+    HIP_TRY(hipStreamCreateWithFlags(&c->up_stream, hipStreamNonBlocking));
+    hipStream_t s_copy = c->own_stream, s_comp = c->up_stream;
+
+    // what the compute stream prepares per chunk
+    bool want_norms = (o.flags & (MVFGPU_UPLOAD_EAGER_NORMS | MVFGPU_UPLOAD_EAGER_SHADOW)) != 0;
+    bool want_shadow = (o.flags & MVFGPU_UPLOAD_EAGER_SHADOW) != 0 && c->dtype == MVF_DTYPE_FLOAT32 && shadow_enabled();
+    float* xn = nullptr;
+    const size_t nn = norm_stride(n);
+    if (want_norms) {
+        HIP_TRY(c->xnorm.reserve((norm_max_at(n) + 1) * 4));
+        xn = static_cast<float*>(c->xnorm.p);
+        if (!is_int_dtype(c->dtype)) HIP_TRY(hipMemsetAsync(xn + norm_max_at(n), 0, 4, s_comp));
+    }
+    if (want_shadow) {
+        const size_t need = (size_t)n * shadow_pitch(c->dim);
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < need + ((size_t)2 << 30) ||
+            c->shadow.reserve(need) != hipSuccess || c->xscale.reserve(((size_t)n + 256) * 4) != hipSuccess) {
+            (void)hipGetLastError();
+            c->shadow.release();
+            c->xscale.release();
+            want_shadow = false;  // as ensure_shadow: the searches then use the exact f32 kernel
+        }
+    }
+
+    StagePair stage;
+    PinnedPair pin;
+    EventSet ev;  // [0,1] copy of buffer b landed, [2,3] compute on buffer b done, [4,5] H2D out of pinned buffer b done
+    for (auto& e : ev.e) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    const uint64_t span_max = (std::min(chunk_rows, n) - 1) * stride + row_bytes;  // bytes of one chunk as it lies
+    if (!direct && !sparse)
+        for (auto& q : stage.p) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&q), span_max));
+    if (pinned)
+        for (auto& q : pin.p) HIP_TRY(hipHostMalloc(&q, span_max, hipHostMallocDefault));
+    if (sparse && c->pitch != row_bytes) HIP_TRY(hipMemsetAsync(c->d_rows, 0, c->rows_bytes, s_copy));  // the 16-B padding
+    const unsigned threads = std::min(8u, std::max(1u, std::thread::hardware_concurrency()));
+
+    uint64_t i = 0;
+    for (uint64_t r0 = 0; r0 < n; r0 += chunk_rows, i++) {
+        const int b = (int)(i & 1);
+        const uint64_t h = std::min(chunk_rows, n - r0);
+        const uint64_t span = (h - 1) * stride + row_bytes;
+        unsigned char* place = c->d_rows + r0 * c->pitch;
+        if (!direct && !sparse && i >= 2) HIP_TRY(hipEventSynchronize(ev.e[2 + b]));  // stage b: its re-pitch is done
+        if (sparse) {
+            HIP_TRY(hipMemcpy2DAsync(place, c->pitch, src + r0 * stride, stride, row_bytes, h, hipMemcpyHostToDevice, s_copy));
+        } else {
+            unsigned char* dst = direct ? place : stage.p[b];
+            if (pinned) {
+                if (i >= 2) HIP_TRY(hipEventSynchronize(ev.e[4 + b]));  // pinned buffer b: its H2D is done
+                parallel_memcpy(pin.p[b], src + r0 * stride, span, threads);
+                HIP_TRY(hipMemcpyAsync(dst, pin.p[b], span, hipMemcpyHostToDevice, s_copy));
+                HIP_TRY(hipEventRecord(ev.e[4 + b], s_copy));
+            } else {
+                HIP_TRY(hipMemcpyAsync(dst, src + r0 * stride, span, hipMemcpyHostToDevice, s_copy));
+            }
+        }
+        HIP_TRY(hipEventRecord(ev.e[b], s_copy));
+        HIP_TRY(hipStreamWaitEvent(s_comp, ev.e[b], 0));
+        if (!direct && !sparse)
+            HIP_TRY(launch_repack_rows(stage.p[b], place, h, (uint32_t)row_bytes, stride, c->pitch, s_comp));
+        if (want_norms) {
+            if (c->dtype == MVF_DTYPE_FLOAT32)
+                HIP_TRY(launch_row_norms_f32(place, (uint32_t)h, c->pitch, xn + r0, xn + nn + r0, xn + norm_max_at(n), s_comp));
+            else
+                HIP_TRY(launch_row_norms16(place, c->dtype, (uint32_t)h, c->pitch, c->dim, xn + r0, xn + nn + r0,
+                                           xn + norm_max_at(n), s_comp));
+        }
+        if (want_shadow)
+            HIP_TRY(launch_shadow_f16(place, (uint32_t)h, c->pitch, c->dim,
+                                      static_cast<unsigned char*>(c->shadow.p) + r0 * shadow_pitch(c->dim), shadow_pitch(c->dim),
+                                      static_cast<float*>(c->xscale.p) + r0, s_comp));
+        HIP_TRY(hipEventRecord(ev.e[2 + b], s_comp));
+    }
+    HIP_TRY(hipStreamSynchronize(s_copy));
+    HIP_TRY(hipStreamSynchronize(s_comp));
+    if (want_norms) c->xnorm_ready = true;
+    c->shadow_state = want_shadow ? 1 : c->shadow_state;
+    return MVF_OK;
 }
 
 int check_query_args(const mvfgpu_corpus* c, uint8_t metric, const void* queries, uint8_t query_dtype,
@@ -771,10 +940,15 @@ const char* mvfgpu_strerror(int status) {
 
 const char* mvfgpu_last_error_message(void) { return g_last_error.c_str(); }
 
-int mvfgpu_corpus_create(const void* rows, uint64_t n, uint32_t dimension, uint8_t data_type,
-                         uint64_t stride_bytes, int device, uint64_t index_base, mvfgpu_corpus** out) {
+int mvfgpu_corpus_create_ex(const void* rows, uint64_t n, uint32_t dimension, uint8_t data_type, uint64_t stride_bytes,
+                            int device, uint64_t index_base, const mvfgpu_upload_options* opts, mvfgpu_corpus** out) {
     if (!out) return fail(MVF_ERR_INVALID_ARGUMENT, "out is NULL");
     *out = nullptr;
+    mvfgpu_upload_options o{};
+    if (opts) {
+        if (opts->struct_size < 8 || opts->struct_size > 4096) return fail(MVF_ERR_INVALID_ARGUMENT, "upload options: bad struct_size");
+        std::memcpy(&o, opts, std::min<size_t>(opts->struct_size, sizeof(o)));
+    }
     int rc = validate_shape(n, dimension, data_type);
     if (rc != MVF_OK) return rc;
     const uint64_t row_bytes = (uint64_t)dimension * elem_size(data_type);
@@ -798,45 +972,18 @@ int mvfgpu_corpus_create(const void* rows, uint64_t n, uint32_t dimension, uint8
     c->index_base = index_base;
     rc = init_common(c);
     if (rc == MVF_OK) rc = alloc_rows(c);
-    if (rc == MVF_OK && n > 0) {
-        hipError_t e = hipSuccess;
-        if (stride_bytes == c->pitch) {
-            // one 1-D copy: the runtime pins the pageable source (mmap included) on the fly — measured 56 GB/s
-            // of the 63 GB/s PCIe Gen5 x16 link
-            e = hipMemcpy(c->d_rows, rows, c->rows_bytes, hipMemcpyHostToDevice);
-        } else if (stride_bytes == row_bytes) {
-            // tightly packed rows whose size is not a multiple of 16: 1-D copies of <= 1 GiB into a staging buffer
-            // + a device-side re-pitch (hipMemcpy2D manages only ~17 GB/s)
-            const uint64_t chunk_rows = std::max<uint64_t>(1, (1ull << 30) / row_bytes);
-            unsigned char* stage = nullptr;
-            e = hipMalloc(reinterpret_cast<void**>(&stage), (size_t)std::min(chunk_rows, n) * row_bytes);
-            for (uint64_t r0 = 0; r0 < n && e == hipSuccess; r0 += chunk_rows) {
-                const uint64_t h = std::min(chunk_rows, n - r0);
-                e = hipMemcpy(stage, static_cast<const unsigned char*>(rows) + r0 * row_bytes, (size_t)h * row_bytes,
-                              hipMemcpyHostToDevice);
-                if (e == hipSuccess)
-                    e = launch_repack_rows(stage, c->d_rows + r0 * c->pitch, h, (uint32_t)row_bytes, c->pitch, c->own_stream);
-                if (e == hipSuccess) e = hipStreamSynchronize(c->own_stream);
-            }
-            if (stage) (void)hipFree(stage);
-        } else {
-            if (c->pitch != row_bytes) e = hipMemset(c->d_rows, 0, c->rows_bytes);  // zero the 16-B padding
-            const uint64_t step = 1u << 20;  // rows per 2-D copy
-            for (uint64_t r0 = 0; r0 < n && e == hipSuccess; r0 += step) {
-                const uint64_t h = std::min(step, n - r0);
-                e = hipMemcpy2D(c->d_rows + r0 * c->pitch, c->pitch,
-                                static_cast<const unsigned char*>(rows) + r0 * stride_bytes, stride_bytes, row_bytes, h,
-                                hipMemcpyHostToDevice);
-            }
-        }
-        if (e != hipSuccess) rc = fail(MVF_ERR_DEVICE, std::string("row upload: ") + hipGetErrorString(e));
-    }
+    if (rc == MVF_OK && n > 0) rc = upload_rows(c, rows, stride_bytes, o);
     if (rc != MVF_OK) {
         mvfgpu_corpus_destroy(c);
         return rc;
     }
     *out = c;
     return MVF_OK;
+}
+
+int mvfgpu_corpus_create(const void* rows, uint64_t n, uint32_t dimension, uint8_t data_type,
+                         uint64_t stride_bytes, int device, uint64_t index_base, mvfgpu_corpus** out) {
+    return mvfgpu_corpus_create_ex(rows, n, dimension, data_type, stride_bytes, device, index_base, nullptr, out);
 }
 
 int mvfgpu_corpus_create_synthetic(uint64_t n, uint32_t dimension, uint8_t data_type, uint64_t seed, uint64_t row0,
@@ -888,11 +1035,14 @@ void mvfgpu_corpus_destroy(mvfgpu_corpus* c) {
         c->repair.release();
         c->shadow.release();
         c->xscale.release();
+        c->tomb.release();
+        c->ids.release();
         c->h_q.release();
         c->h_s.release();
         c->h_i.release();
         c->h_r.release();
         if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+        if (c->up_stream) (void)hipStreamDestroy(c->up_stream);
         if (c->ev_done) (void)hipEventDestroy(c->ev_done);
         for (auto& ps : c->prof)
             for (auto& e : ps.e)
@@ -910,8 +1060,10 @@ int mvfgpu_corpus_get_info(const mvfgpu_corpus* c, mvfgpu_corpus_info* out) {
     out->pitch_bytes = c->pitch;
     out->data_type = c->dtype;
     out->device = c->device;
+    out->reserved[0] = c->ids.p ? 1 : 0;  // has_vector_ids
+    out->deleted_rows = c->deleted;
     std::lock_guard<std::mutex> lk(c->mu);
-    out->device_bytes = c->rows_bytes + c->cand.bytes + c->bq.bytes + c->bstate.bytes + c->bcand.bytes + c->xnorm.bytes +
+    out->device_bytes = c->tomb.bytes + c->ids.bytes + c->rows_bytes + c->cand.bytes + c->bq.bytes + c->bstate.bytes + c->bcand.bytes + c->xnorm.bytes +
                         c->repair.bytes + c->shadow.bytes + c->xscale.bytes + c->h_q.bytes + c->h_s.bytes + c->h_i.bytes +
                         c->h_r.bytes;
     return MVF_OK;
@@ -935,6 +1087,29 @@ int mvfgpu_corpus_gather_rows(const mvfgpu_corpus* c, const uint64_t* indices, u
     if (!c || (count && (!indices || !out_rows))) return fail(MVF_ERR_INVALID_ARGUMENT, "NULL argument");
     if (count == 0) return MVF_OK;
     if (count > 0xFFFFFFFFull) return fail(MVF_ERR_INVALID_ARGUMENT, "too many rows in one gather");
+    std::vector<uint64_t> mapped;  // with vector ids a search reports ids: translate them back to positions
+    if (!c->h_ids.empty()) {
+        std::lock_guard<std::mutex> lk(c->mu);
+        if (c->id_index.empty()) {
+            c->id_index.reserve(c->h_ids.size());
+            for (size_t r = 0; r < c->h_ids.size(); r++) c->id_index.emplace_back(c->h_ids[r], (uint32_t)r);
+            std::sort(c->id_index.begin(), c->id_index.end());
+        }
+        mapped.resize(count);
+        for (uint64_t i = 0; i < count; i++) {
+            if (indices[i] == ~0ull) {
+                mapped[i] = ~0ull;
+                continue;
+            }
+            auto it = std::lower_bound(c->id_index.begin(), c->id_index.end(), std::make_pair(indices[i], 0u));
+            if (it == c->id_index.end() || it->first != indices[i]) {
+                g_last_error = "Index out of bounds: vector id " + std::to_string(indices[i]) + " is not in this shard";
+                return MVF_ERR_INDEX_OUT_OF_BOUNDS;
+            }
+            mapped[i] = c->index_base + it->second;  // duplicates: the first position holding the id
+        }
+        indices = mapped.data();
+    }
     for (uint64_t i = 0; i < count; i++) {
         const uint64_t g = indices[i];
         if (g == ~0ull) continue;  // padding of a short result list: a zero row
@@ -958,6 +1133,60 @@ int mvfgpu_corpus_gather_rows(const mvfgpu_corpus* c, const uint64_t* indices, u
                                (uint32_t)count, static_cast<unsigned char*>(c->h_q.p), c->own_stream));
     HIP_TRY(hipMemcpyAsync(out_rows, c->h_q.p, (size_t)count * row_bytes, hipMemcpyDeviceToHost, c->own_stream));
     HIP_TRY(hipStreamSynchronize(c->own_stream));
+    return MVF_OK;
+}
+
+int mvfgpu_corpus_set_tombstones(mvfgpu_corpus* c, const uint8_t* bitmap, uint64_t first_bit, uint64_t nbits) {
+    if (!c) return fail(MVF_ERR_INVALID_ARGUMENT, "corpus is NULL");
+    DeviceGuard guard(c->device);
+    if (!guard.ok) return fail(MVF_ERR_DEVICE, "hipSetDevice failed");
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIP_TRY(hipDeviceSynchronize());  // searches in flight still read the old bitmap
+    if (!bitmap || nbits == 0) {
+        c->tomb.release();
+        c->deleted = 0;
+        return MVF_OK;
+    }
+    if (first_bit + c->n > nbits || first_bit + c->n < first_bit)
+        return fail(MVF_ERR_INVALID_ARGUMENT, "tombstone bitmap covers fewer rows than the shard holds");
+    const size_t words = ((size_t)c->n + 31) / 32;
+    std::vector<uint32_t> w(words + 1, 0u);
+    uint64_t dead = 0;
+    for (uint64_t r = 0; r < c->n; r++) {  // re-base to local rows (first_bit need not be a multiple of 8)
+        const uint64_t b = first_bit + r;
+        if ((bitmap[b >> 3] >> (b & 7)) & 1u) {
+            w[r >> 5] |= 1u << (r & 31);
+            dead++;
+        }
+    }
+    if (dead == 0) {
+        c->tomb.release();
+        c->deleted = 0;
+        return MVF_OK;
+    }
+    HIP_TRY(c->tomb.reserve((words + 1) * 4));
+    HIP_TRY(hipMemcpy(c->tomb.p, w.data(), (words + 1) * 4, hipMemcpyHostToDevice));
+    c->deleted = dead;
+    return MVF_OK;
+}
+
+int mvfgpu_corpus_set_vector_ids(mvfgpu_corpus* c, const void* ids_le, uint64_t n) {
+    if (!c) return fail(MVF_ERR_INVALID_ARGUMENT, "corpus is NULL");
+    DeviceGuard guard(c->device);
+    if (!guard.ok) return fail(MVF_ERR_DEVICE, "hipSetDevice failed");
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIP_TRY(hipDeviceSynchronize());
+    c->id_index.clear();
+    if (!ids_le || n == 0) {
+        c->ids.release();
+        c->h_ids.clear();
+        return MVF_OK;
+    }
+    if (n != c->n) return fail(MVF_ERR_INVALID_ARGUMENT, "vector id count differs from the shard's row count");
+    c->h_ids.resize(n);
+    std::memcpy(c->h_ids.data(), ids_le, (size_t)n * 8);  // the block may sit at any alignment in the mapping
+    HIP_TRY(c->ids.reserve((size_t)n * 8));
+    HIP_TRY(hipMemcpy(c->ids.p, c->h_ids.data(), (size_t)n * 8, hipMemcpyHostToDevice));
     return MVF_OK;
 }
 
@@ -1047,8 +1276,9 @@ int mvfgpu_merge_topk_host(const float* scores, const uint64_t* indices, const i
                 ents.push_back({use_raw ? key_from_raw(raw[s], metric) : key_from_score(scores[s], metric), indices[s], s});
             }
         const size_t keep = std::min<size_t>(k, ents.size());
+        // ties: list order, then rank in the list (= ascending global row position for row-range shards in order)
         std::partial_sort(ents.begin(), ents.begin() + keep, ents.end(), [](const Ent& a, const Ent& b) {
-            return a.key < b.key || (a.key == b.key && a.idx < b.idx);
+            return a.key < b.key || (a.key == b.key && a.slot < b.slot);
         });
         for (uint32_t j = 0; j < k; j++) {
             const size_t o = (size_t)q * k + j;

@@ -15,6 +15,7 @@ struct SelectParams {
     uint32_t k;
     uint8_t metric, dtype;
     uint64_t index_base;
+    const uint64_t* ids;    // vector ids per local row (schema/core.fbs:54), or NULL: the reported index is index_base + row
     float* out_scores;      // [nq][k]
     uint64_t* out_indices;
     int32_t* out_raw;       // nullable
@@ -37,14 +38,14 @@ struct ShardMergeParams {
     int32_t* out_raw;         // nullable
 };
 
-constexpr uint32_t kMergeMaxEntries = 8192;  // LDS entries per select / merge block (64 KiB of u64)
+constexpr uint32_t kMergeMaxEntries = 8192;  // nlists * k of one cross-shard merge: 8-byte composites, 64 KiB of LDS
 
 hipError_t launch_select_final(const SelectParams& p, uint32_t nq, hipStream_t s);
 hipError_t launch_merge_shards(const ShardMergeParams& p, hipStream_t s);
 hipError_t launch_synth_rows(unsigned char* rows, uint64_t n, uint32_t dim, uint32_t pitch, uint8_t dtype,
                              uint64_t seed, uint64_t row0, hipStream_t s);
-hipError_t launch_repack_rows(const unsigned char* src, unsigned char* dst, uint64_t n, uint32_t row_bytes, uint32_t pitch,
-                              hipStream_t s);
+hipError_t launch_repack_rows(const unsigned char* src, unsigned char* dst, uint64_t n, uint32_t row_bytes,
+                              uint64_t src_stride, uint32_t pitch, hipStream_t s);
 hipError_t launch_gather_rows(const unsigned char* rows, uint64_t n, uint32_t pitch, uint32_t row_bytes, uint64_t index_base,
                               const uint64_t* d_idx, uint32_t count, unsigned char* d_out, hipStream_t s);
 hipError_t launch_synth_packed(void* out, uint64_t nelem, uint8_t dtype, uint64_t seed, hipStream_t s);

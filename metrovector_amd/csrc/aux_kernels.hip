@@ -33,7 +33,7 @@ __device__ __forceinline__ void write_result(uint64_t comp, uint32_t o, const Se
         s = score_from_key(key, p.metric);
     }
     p.out_scores[o] = s;
-    p.out_indices[o] = p.index_base + (uint32_t)comp;
+    p.out_indices[o] = p.ids ? p.ids[(uint32_t)comp] : p.index_base + (uint32_t)comp;
     if (p.out_raw) p.out_raw[o] = raw;
 }
 
@@ -111,63 +111,46 @@ __global__ void __launch_bounds__(1024) select_final_kernel(SelectParams p) {
     for (uint32_t i = tid; i < p.k; i += 1024) write_result(i < m ? buf[i] : kPadComposite, q * p.k + i, p);
 }
 
-// Cross-shard merge of formatted results: entries are (key u32, global idx u64)
-// with the source slot as payload.  grid (nq); block 256.
+// Cross-shard merge of formatted results.  An entry is the u64 composite (order key << 32 | slot), slot = list * k +
+// rank: ties are broken by list order, then by rank inside the list.  The lists arrive in ascending row-range order
+// (rank order of the all-gather) and each is sorted by (key, row position), so this IS "ascending global row
+// position" -- without needing the position, which a shard that reports vector ids no longer carries.  Padding
+// (index UINT64_MAX) becomes the all-ones composite and sorts behind every real entry, NaN scores included.
+// grid (nq); block 256; LDS P * 8 bytes (P <= 8192: 64 KiB).
 __global__ void __launch_bounds__(256) merge_shards_kernel(ShardMergeParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    uint64_t* idx = reinterpret_cast<uint64_t*>(smem);          // [P]
-    uint32_t* key = reinterpret_cast<uint32_t*>(idx + p.P);     // [P]
-    uint32_t* slot = key + p.P;                                 // [P]
+    uint64_t* buf = reinterpret_cast<uint64_t*>(smem);  // [P]
     const int tid = threadIdx.x;
     const uint32_t q = blockIdx.x;
     const uint32_t total = p.nlists * p.k;
     const bool use_raw = key_is_raw(p.dtype, p.metric) && p.raw != nullptr;
     for (uint32_t i = tid; i < p.P; i += 256) {
-        uint64_t id = ~0ull;
-        uint32_t ky = kNanKey, sl = 0;
+        uint64_t comp = kPadComposite;
         if (i < total) {
             const uint32_t l = i / p.k, j = i % p.k;
             const size_t rem = (size_t)q * p.k + j;
-            sl = i;  // (list, rank) of the entry; the arrays are addressed through their own list strides
-            id = p.indices[l * p.ls_indices + rem];
-            if (id != ~0ull)
-                ky = use_raw ? key_from_raw(p.raw[l * p.ls_raw + rem], p.metric)
-                             : key_from_score(p.scores[l * p.ls_scores + rem], p.metric);
+            if (p.indices[l * p.ls_indices + rem] != ~0ull) {
+                const uint32_t ky = use_raw ? key_from_raw(p.raw[l * p.ls_raw + rem], p.metric)
+                                            : key_from_score(p.scores[l * p.ls_scores + rem], p.metric);
+                comp = ((uint64_t)ky << 32) | i;
+            }
         }
-        idx[i] = id;
-        key[i] = ky;
-        slot[i] = sl;
+        buf[i] = comp;
     }
     __syncthreads();
-    for (uint32_t size = 2; size <= p.P; size <<= 1) {
-        for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
-            for (uint32_t t = tid; t < (p.P >> 1); t += 256) {
-                uint32_t i = 2 * t - (t & (stride - 1));
-                uint32_t j = i + stride;
-                bool up = (i & size) == 0;
-                uint32_t ka = key[i], kb = key[j];
-                uint64_t ia = idx[i], ib = idx[j];
-                bool gt = ka > kb || (ka == kb && ia > ib);
-                if (gt == up) {
-                    key[i] = kb; key[j] = ka;
-                    idx[i] = ib; idx[j] = ia;
-                    uint32_t sa = slot[i]; slot[i] = slot[j]; slot[j] = sa;
-                }
-            }
-            __syncthreads();
-        }
-    }
+    bitonic_sort_u64<256>(buf, p.P, tid);
     for (uint32_t i = tid; i < p.k; i += 256) {
         const uint32_t o = q * p.k + i;
-        if (idx[i] == ~0ull) {
+        const uint64_t comp = i < p.P ? buf[i] : kPadComposite;
+        if (comp == kPadComposite) {
             p.out_scores[o] = pad_score(p.metric);
             p.out_indices[o] = ~0ull;
             if (p.out_raw) p.out_raw[o] = 0;
         } else {
-            const uint32_t l = slot[i] / p.k, j = slot[i] % p.k;
+            const uint32_t slot = (uint32_t)comp, l = slot / p.k, j = slot % p.k;
             const size_t rem = (size_t)q * p.k + j;
             p.out_scores[o] = p.scores[l * p.ls_scores + rem];
-            p.out_indices[o] = idx[i];
+            p.out_indices[o] = p.indices[l * p.ls_indices + rem];
             if (p.out_raw) p.out_raw[o] = p.raw ? p.raw[l * p.ls_raw + rem] : 0;
         }
     }
@@ -199,16 +182,16 @@ __global__ void synth_rows_kernel(unsigned char* rows, uint64_t nvec, uint32_t V
     }
 }
 
-// Re-pitch tightly packed host rows (row_bytes each, uploaded with one 1-D copy) into the device layout
-// (pitch = row_bytes rounded up to 16, zero padded).  One thread per 16-B output vector; GRAN = 4 / 2 / 1 is the
-// widest access both layouts are aligned for.
+// Re-pitch host rows (row_bytes each, src_stride apart, uploaded as they lie with one 1-D copy) into the device layout
+// (pitch = row_bytes rounded up to 16, zero padded; only row_bytes of each source row are read).  One thread per 16-B
+// output vector; GRAN = 4 / 2 / 1 is the widest access both layouts are aligned for.
 template <int GRAN>
 __global__ void repack_rows_kernel(const unsigned char* src, unsigned char* dst, uint64_t nvec, uint32_t V,
-                                   uint32_t row_bytes, uint32_t pitch) {
+                                   uint32_t row_bytes, uint64_t src_stride, uint32_t pitch) {
     for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < nvec; t += (uint64_t)gridDim.x * blockDim.x) {
         const uint64_t r = t / V;
         const uint32_t v = (uint32_t)(t % V);
-        const unsigned char* sp = src + r * row_bytes + (size_t)v * 16;
+        const unsigned char* sp = src + r * src_stride + (size_t)v * 16;
         const uint32_t have = row_bytes - v * 16 < 16u ? row_bytes - v * 16 : 16u;
         uint32_t w[4] = {0, 0, 0, 0};
         if (GRAN == 4) {
@@ -256,7 +239,12 @@ hipError_t launch_select_final(const SelectParams& p, uint32_t nq, hipStream_t s
 }
 
 hipError_t launch_merge_shards(const ShardMergeParams& p, hipStream_t s) {
-    const size_t lds = (size_t)p.P * 16;
+    const size_t lds = (size_t)p.P * 8;  // <= 64 KiB (kMergeMaxEntries); above 48 KiB the attribute is set per launch (per device)
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&merge_shards_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
     hipLaunchKernelGGL(merge_shards_kernel, dim3(p.nq), dim3(256), lds, s, p);
     return hipGetLastError();
 }
@@ -272,16 +260,17 @@ hipError_t launch_synth_rows(unsigned char* rows, uint64_t n, uint32_t dim, uint
     return hipGetLastError();
 }
 
-hipError_t launch_repack_rows(const unsigned char* src, unsigned char* dst, uint64_t n, uint32_t row_bytes, uint32_t pitch,
-                              hipStream_t s) {
+hipError_t launch_repack_rows(const unsigned char* src, unsigned char* dst, uint64_t n, uint32_t row_bytes,
+                              uint64_t src_stride, uint32_t pitch, hipStream_t s) {
     const uint32_t V = pitch / 16;
     const uint64_t nvec = n * V;
     if (nvec == 0) return hipSuccess;
     const uint64_t blocks64 = (nvec + 255) / 256;
     const dim3 grid((unsigned)(blocks64 < 65536 ? blocks64 : 65536));
-    if (row_bytes % 4 == 0) hipLaunchKernelGGL(repack_rows_kernel<4>, grid, dim3(256), 0, s, src, dst, nvec, V, row_bytes, pitch);
-    else if (row_bytes % 2 == 0) hipLaunchKernelGGL(repack_rows_kernel<2>, grid, dim3(256), 0, s, src, dst, nvec, V, row_bytes, pitch);
-    else hipLaunchKernelGGL(repack_rows_kernel<1>, grid, dim3(256), 0, s, src, dst, nvec, V, row_bytes, pitch);
+    const uint64_t al = row_bytes | src_stride;  // both the row size and the row starts must be aligned for GRAN
+    if (al % 4 == 0) hipLaunchKernelGGL(repack_rows_kernel<4>, grid, dim3(256), 0, s, src, dst, nvec, V, row_bytes, src_stride, pitch);
+    else if (al % 2 == 0) hipLaunchKernelGGL(repack_rows_kernel<2>, grid, dim3(256), 0, s, src, dst, nvec, V, row_bytes, src_stride, pitch);
+    else hipLaunchKernelGGL(repack_rows_kernel<1>, grid, dim3(256), 0, s, src, dst, nvec, V, row_bytes, src_stride, pitch);
     return hipGetLastError();
 }
 

@@ -19,6 +19,7 @@
 #include <cerrno>
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -332,6 +333,9 @@ struct SpaceRec {
     uint8_t vector_type = 0, distance_metric = 0, data_type = 0, index_type = 0;
     uint32_t vectors_block_index = 0, vector_ids_block_index = 0;
     bool sparse = false, tombstones = false;
+    uint8_t tomb_format = 0;        // TombstoneInfo, schema/core.fbs:35-39
+    uint32_t tomb_block_index = 0;
+    uint64_t tomb_deleted_count = 0;
 };
 
 }  // namespace
@@ -413,6 +417,15 @@ int parse_footer(mvf_reader* r, size_t fs, size_t fe) {
         s.vector_ids_block_index = u32f(9);
         s.sparse = st.field(10) != 0;
         s.tombstones = st.field(11) != 0;
+        if (s.tombstones) {  // TombstoneInfo { format:ubyte; data_block_index:uint; deleted_count:ulong }
+            size_t tp2;
+            FbTable tt;
+            if (!fb_indirect(v, st.field(11), &tp2) || !fb_table_at(v, tp2, &tt, &why)) return bad("tombstone table: " + why);
+            size_t p0 = tt.field(0), p1 = tt.field(1), p2 = tt.field(2);
+            s.tomb_format = p0 && v.in(p0, 1) ? v.b[p0] : 0;
+            s.tomb_block_index = p1 && v.in(p1, 4) ? rd32(v.b + p1) : 0;
+            s.tomb_deleted_count = p2 && v.in(p2, 8) ? rd64(v.b + p2) : 0;
+        }
     }
 
     size_t f_meta = ft.field(3);
@@ -456,6 +469,10 @@ struct SpaceB {
     uint32_t dimension;
     uint8_t vector_type, distance_metric, data_type;
     std::vector<uint8_t> vectors;
+    std::vector<uint8_t> ids;         // u64 LE per row (vector_ids block), empty = positions are the ids
+    std::vector<uint8_t> tombstones;  // Bitmap or SortedList payload
+    uint8_t tomb_format = 0;
+    uint64_t tomb_deleted = 0;
 };
 struct ColumnB {
     std::string name;
@@ -591,6 +608,9 @@ static void fill_space(const mvf_reader* r, size_t i, mvf_vector_space* out) {
     out->vector_ids_block_index = s.vector_ids_block_index;
     out->has_sparse_metadata = s.sparse;
     out->has_tombstones = s.tombstones;
+    out->tombstone_format = s.tomb_format;
+    out->tombstone_block_index = s.tomb_block_index;
+    out->tombstone_deleted_count = s.tomb_deleted_count;
 }
 
 int mvf_reader_vector_space(const mvf_reader* r, const char* name, mvf_vector_space* out) {
@@ -681,17 +701,29 @@ int mvf_reader_validate_with_checksum(const mvf_reader* r) {
 // ---- VectorSpace / Vector -------------------------------------------------------
 
 // shared prologue of get_vector / map_vector_range: the block bytes
-static int space_block(const mvf_vector_space* s, const uint8_t** block, uint64_t* block_len) {
-    const mvf_reader* r = s->reader;
-    if (s->vectors_block_index >= r->blocks.size())
-        return fail(MVF_ERR_CORRUPTED_DATA, "Invalid vector block index");  // vector_space.rs:110-112
-    const mvf_data_block& b = r->blocks[s->vectors_block_index];
+// One block of the manifest as bytes of the mapping.  Compressed blocks are refused: the reference's builder only ever
+// writes CompressionAlgorithm::None (src/builder.rs:249) and nothing in the reference can read LZ4/Zstd blocks
+// (schema/types.fbs:28-32 is an enum without code) -- scanning the compressed bytes as rows would be silent garbage.
+static int manifest_block(const mvf_reader* r, uint32_t index, const char* what, const uint8_t** block, uint64_t* block_len) {
+    if (index >= r->blocks.size())
+        return fail(MVF_ERR_CORRUPTED_DATA, std::string("Invalid ") + what + " block index");  // vector_space.rs:110-112
+    const mvf_data_block& b = r->blocks[index];
+    if (b.compression != 0)
+        return fail(MVF_ERR_BUILD, std::string("Unsupported compression algorithm ") + std::to_string(b.compression) + " on the " +
+                                       what + " block (only CompressionAlgorithm::None is implemented)");
     uint64_t start = 4 + b.offset;  // METRO_MAGIC.len() + block.offset, vector_space.rs:118-119
-    if (start + b.size > r->len || start + b.size < start)
-        return fail(MVF_ERR_CORRUPTED_DATA, "Vector block extends beyond file");  // the reference would panic on the slice
+    if (start < b.offset || start + b.size > r->len || start + b.size < start)
+        return fail(MVF_ERR_CORRUPTED_DATA, std::string(what) + " block extends beyond file");  // the reference would panic on the slice
     *block = r->data + start;
     *block_len = b.size;
     return MVF_OK;
+}
+
+static int space_block(const mvf_vector_space* s, const uint8_t** block, uint64_t* block_len) {
+    int rc = manifest_block(s->reader, s->vectors_block_index, "vector", block, block_len);
+    if (rc == MVF_ERR_CORRUPTED_DATA && s->vectors_block_index < s->reader->blocks.size())
+        return fail(MVF_ERR_CORRUPTED_DATA, "Vector block extends beyond file");
+    return rc;
 }
 
 int mvf_space_get_vector(const mvf_vector_space* s, uint64_t index, const void** data, uint64_t* len) {
@@ -704,8 +736,10 @@ int mvf_space_get_vector(const mvf_vector_space* s, uint64_t index, const void**
     if (rc) return rc;
     uint32_t es = elem_size(s->data_type);
     if (!es) return fail(MVF_ERR_BUILD, "Unsupported vector data type");  // :126
-    uint64_t vector_size = (uint64_t)s->dimension * es, vector_offset = index * vector_size;
-    if (vector_offset + vector_size > block_len)  // :132-137
+    // dimension and total_vectors come from the (untrusted) footer: no product may wrap
+    uint64_t vector_size = (uint64_t)s->dimension * es, vector_offset = 0;
+    if (__builtin_mul_overflow(index, vector_size, &vector_offset) || vector_offset > block_len ||
+        vector_size > block_len - vector_offset)  // :132-137
         return fail(MVF_ERR_INDEX_OUT_OF_BOUNDS, "Index out of bounds: " + std::to_string(index) + " >= " +
                                                       std::to_string(vector_size ? block_len / vector_size : 0));
     *data = block + vector_offset;
@@ -724,12 +758,104 @@ int mvf_space_map_vector_range(const mvf_vector_space* s, uint64_t start, uint64
     uint32_t es = elem_size(s->data_type);
     if (!es) return fail(MVF_ERR_BUILD, "Unsupported vector data type");  // :174
     uint64_t vector_size = (uint64_t)s->dimension * es;
-    uint64_t range_offset = start * vector_size, range_size = count * vector_size;
-    if (range_offset + range_size > block_len) return fail(MVF_ERR_CORRUPTED_DATA, "Vector range out of bounds");  // :181-183
+    uint64_t range_offset = 0, range_size = 0;  // footer fields are untrusted: no product may wrap
+    if (__builtin_mul_overflow(start, vector_size, &range_offset) || __builtin_mul_overflow(count, vector_size, &range_size) ||
+        range_offset > block_len || range_size > block_len - range_offset)
+        return fail(MVF_ERR_CORRUPTED_DATA, "Vector range out of bounds");  // :181-183
     out->data = block + range_offset;
     out->stride = vector_size;
     out->count = count;
     out->data_type = s->data_type;
+    return MVF_OK;
+}
+
+// ---- vector ids and tombstones (schema/core.fbs:35-39, :54, :56) ------------------------------------------------
+// The reference parses neither (its builder never writes them: src/builder.rs:483-485), so the layout is defined
+// here in the schema's words: the id block is one u64 LE per row ("0 = use positions as IDs": block 0 is always the
+// first space's vectors, so 0 can mean "none"); a Bitmap tombstone block holds bit r of byte r >> 3 (LSB first) per
+// row POSITION; a SortedList block holds ascending u64 LE "deleted IDs" -- vector ids when the space has an id block,
+// positions otherwise.
+int mvf_space_vector_ids(const mvf_vector_space* s, const void** ids_le, uint64_t* count) {
+    if (!s || !s->reader || !ids_le || !count) return fail(MVF_ERR_INVALID_ARGUMENT, "NULL argument");
+    *ids_le = nullptr;
+    *count = 0;
+    if (s->vector_ids_block_index == 0) return MVF_OK;
+    const uint8_t* block;
+    uint64_t len;
+    int rc = manifest_block(s->reader, s->vector_ids_block_index, "vector id", &block, &len);
+    if (rc) return rc;
+    if (len / 8 < s->total_vectors) return fail(MVF_ERR_CORRUPTED_DATA, "Vector id block shorter than total_vectors");
+    *ids_le = block;
+    *count = s->total_vectors;
+    return MVF_OK;
+}
+
+int mvf_space_tombstones(const mvf_vector_space* s, uint8_t* format, const void** data, uint64_t* size, uint64_t* deleted_count) {
+    if (!s || !s->reader || !format || !data || !size) return fail(MVF_ERR_INVALID_ARGUMENT, "NULL argument");
+    *format = 0;
+    *data = nullptr;
+    *size = 0;
+    if (deleted_count) *deleted_count = 0;
+    if (!s->has_tombstones || s->tombstone_format == 0 || s->tombstone_block_index == 0) return MVF_OK;  // "0 if no deletions"
+    if (s->tombstone_format > 2) return fail(MVF_ERR_BUILD, "Unsupported tombstone format " + std::to_string(s->tombstone_format));
+    const uint8_t* block;
+    uint64_t len;
+    int rc = manifest_block(s->reader, s->tombstone_block_index, "tombstone", &block, &len);
+    if (rc) return rc;
+    *format = s->tombstone_format;
+    *data = block;
+    *size = len;
+    if (deleted_count) *deleted_count = s->tombstone_deleted_count;
+    return MVF_OK;
+}
+
+int mvf_space_tombstone_bitmap(const mvf_vector_space* s, uint8_t* bitmap, uint64_t nbytes, uint64_t* deleted) {
+    if (!s || !s->reader || (!bitmap && nbytes)) return fail(MVF_ERR_INVALID_ARGUMENT, "NULL argument");
+    const uint64_t n = s->total_vectors, need = (n + 7) / 8;
+    if (nbytes < need) return fail(MVF_ERR_INVALID_ARGUMENT, "bitmap buffer too small");
+    std::memset(bitmap, 0, nbytes);
+    if (deleted) *deleted = 0;
+    uint8_t fmt;
+    const void* data;
+    uint64_t size;
+    int rc = mvf_space_tombstones(s, &fmt, &data, &size, nullptr);
+    if (rc || fmt == 0) return rc;
+    const uint8_t* p = static_cast<const uint8_t*>(data);
+    uint64_t cnt = 0;
+    if (fmt == 1) {  // Bitmap: bit per vector
+        if (size < need) return fail(MVF_ERR_CORRUPTED_DATA, "Tombstone bitmap shorter than total_vectors");
+        std::memcpy(bitmap, p, need);
+        if (n % 8) bitmap[need - 1] &= (uint8_t)((1u << (n % 8)) - 1);  // bits past the last row do not count
+        for (uint64_t i = 0; i < need; i++) cnt += (uint64_t)__builtin_popcount(bitmap[i]);
+    } else {  // SortedList of deleted ids
+        const void* ids_le;
+        uint64_t nids;
+        rc = mvf_space_vector_ids(s, &ids_le, &nids);
+        if (rc) return rc;
+        std::vector<std::pair<uint64_t, uint64_t>> by_id;  // (id, position), only when an id block exists
+        if (ids_le) {
+            by_id.reserve(n);
+            for (uint64_t r = 0; r < n; r++) by_id.emplace_back(rd64(static_cast<const uint8_t*>(ids_le) + 8 * r), r);
+            std::sort(by_id.begin(), by_id.end());
+        }
+        uint64_t prev = 0;
+        for (uint64_t i = 0; i + 8 <= size; i += 8) {
+            const uint64_t id = rd64(p + i);
+            if (i && id < prev) return fail(MVF_ERR_CORRUPTED_DATA, "Tombstone list is not sorted");
+            prev = id;
+            uint64_t pos = id;
+            if (ids_le) {
+                auto it = std::lower_bound(by_id.begin(), by_id.end(), std::make_pair(id, (uint64_t)0));
+                if (it == by_id.end() || it->first != id) continue;  // deleting an id the space does not hold: no-op
+                pos = it->second;
+            } else if (id >= n) {
+                continue;
+            }
+            if (!(bitmap[pos >> 3] & (1u << (pos & 7)))) cnt++;
+            bitmap[pos >> 3] |= (uint8_t)(1u << (pos & 7));
+        }
+    }
+    if (deleted) *deleted = cnt;
     return MVF_OK;
 }
 
@@ -767,7 +893,7 @@ void mvf_builder_free(mvf_builder* b) { delete b; }
 int mvf_builder_add_vector_space(mvf_builder* b, const char* name, uint32_t dimension, uint8_t vector_type,
                                  uint8_t distance_metric, uint8_t data_type, uint64_t* index_out) {
     if (!b || !name) return fail(MVF_ERR_INVALID_ARGUMENT, "NULL argument");
-    b->spaces.push_back(SpaceB{name, dimension, vector_type, distance_metric, data_type, {}});
+    b->spaces.push_back(SpaceB{name, dimension, vector_type, distance_metric, data_type, {}, {}, {}, 0, 0});
     if (index_out) *index_out = b->spaces.size() - 1;
     return MVF_OK;
 }
@@ -818,7 +944,34 @@ int mvf_builder_add_vectors_raw(mvf_builder* b, const char* space_name, const vo
     else if (s->dimension != dimension)
         return fail(MVF_ERR_DIMENSION_MISMATCH, "Dimension mismatch: expected " + std::to_string(s->dimension) + ", got " + std::to_string(dimension));
     const uint8_t* p = static_cast<const uint8_t*>(rows);
-    s->vectors.insert(s->vectors.end(), p, p + n_vectors * dimension * es);
+    uint64_t nbytes = 0;
+    if (__builtin_mul_overflow(n_vectors, (uint64_t)dimension * es, &nbytes)) return fail(MVF_ERR_INVALID_ARGUMENT, "n_vectors * dimension overflows");
+    s->vectors.insert(s->vectors.end(), p, p + nbytes);
+    return MVF_OK;
+}
+
+// EXTENSION (the reference's builder carries `vector_ids` / `tombstones` fields but has no public setter,
+// src/builder.rs:61-63): attach an id per row / a deletion block to a space.  Layouts: mvf_space_vector_ids above.
+int mvf_builder_set_vector_ids(mvf_builder* b, const char* space_name, const uint64_t* ids, uint64_t n) {
+    if (!b || !space_name || (!ids && n)) return fail(MVF_ERR_INVALID_ARGUMENT, "NULL argument");
+    SpaceB* s = find_space(b, space_name);
+    if (!s) return fail(MVF_ERR_SPACE_NOT_FOUND, std::string("Vector space '") + space_name + "' not found");
+    s->ids.resize(n * 8);
+    for (uint64_t i = 0; i < n; i++)
+        for (int k = 0; k < 8; k++) s->ids[i * 8 + k] = (uint8_t)(ids[i] >> (8 * k));  // to_le_bytes, builder.rs:258-261
+    return MVF_OK;
+}
+
+int mvf_builder_set_tombstones(mvf_builder* b, const char* space_name, uint8_t format, const void* data, uint64_t len,
+                               uint64_t deleted_count) {
+    if (!b || !space_name || (!data && len)) return fail(MVF_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (format > 2) return fail(MVF_ERR_BUILD, "Unsupported tombstone format " + std::to_string(format));
+    SpaceB* s = find_space(b, space_name);
+    if (!s) return fail(MVF_ERR_SPACE_NOT_FOUND, std::string("Vector space '") + space_name + "' not found");
+    const uint8_t* p = static_cast<const uint8_t*>(data);
+    s->tombstones.assign(p, p + len);
+    s->tomb_format = format;
+    s->tomb_deleted = deleted_count;
     return MVF_OK;
 }
 
@@ -839,10 +992,24 @@ int mvf_builder_to_bytes(const mvf_builder* b, uint32_t quirks, uint8_t** out, u
     };
     std::vector<Blk> blks;
     uint64_t cur = 0;
-    for (const auto& s : b->spaces) {
+    std::vector<uint32_t> vec_blk(b->spaces.size(), 0), ids_blk(b->spaces.size(), 0), tomb_blk(b->spaces.size(), 0);
+    for (size_t i = 0; i < b->spaces.size(); i++) {
+        const auto& s = b->spaces[i];
+        vec_blk[i] = (uint32_t)blks.size();
         blks.push_back({cur, s.vectors.size(), crc32_ieee(s.vectors.data(), s.vectors.size()), &s.vectors});
         cur += s.vectors.size();
+        if (!s.ids.empty()) {  // right behind the space's vectors, builder.rs:257-271
+            ids_blk[i] = (uint32_t)blks.size();
+            blks.push_back({cur, s.ids.size(), crc32_ieee(s.ids.data(), s.ids.size()), &s.ids});
+            cur += s.ids.size();
+        }
+        if (s.tomb_format != 0 && !s.tombstones.empty()) {
+            tomb_blk[i] = (uint32_t)blks.size();
+            blks.push_back({cur, s.tombstones.size(), crc32_ieee(s.tombstones.data(), s.tombstones.size()), &s.tombstones});
+            cur += s.tombstones.size();
+        }
     }
+    const uint32_t first_column_blk = (uint32_t)blks.size();
     for (const auto& c : b->columns) {
         blks.push_back({cur, c.data.size(), crc32_ieee(c.data.data(), c.data.size()), &c.data});
         cur += c.data.size();
@@ -858,11 +1025,22 @@ int mvf_builder_to_bytes(const mvf_builder* b, uint32_t quirks, uint8_t** out, u
         uint32_t flat = fb.end_table();
         uint64_t denom = (uint64_t)s.dimension * ((quirks & MVF_QUIRK_TOTAL_VECTORS_DIV4) ? 4u : elem_size(s.data_type));
         uint64_t total = denom ? s.vectors.size() / denom : 0;  // builder.rs:476 divides by dimension*4
+        uint32_t tomb = 0;
+        if (tomb_blk[i]) {
+            fb.start_table(3);  // TombstoneInfo, schema/core.fbs:35-39
+            fb.add_scalar<uint64_t>(2, s.tomb_deleted, 0);
+            fb.add_scalar<uint32_t>(1, tomb_blk[i], 0);
+            fb.add_scalar<uint8_t>(0, s.tomb_format, 0);
+            tomb = fb.end_table();
+        }
         fb.start_table(12);
         fb.add_scalar<uint64_t>(2, total, 0);
+        fb.add_offset(11, tomb);
         fb.add_offset(8, flat);
-        fb.add_scalar<uint32_t>(9, 0, 0);
-        fb.add_scalar<uint32_t>(6, (uint32_t)i, 0);  // vectors_block_index = space ordinal, :480
+        fb.add_scalar<uint32_t>(9, ids_blk[i], 0);
+        // vectors_block_index: the reference writes the space ORDINAL (builder.rs:480), which is the block's index only
+        // while no id / tombstone blocks exist -- all it can produce; with them the real index is the only readable one
+        fb.add_scalar<uint32_t>(6, vec_blk[i], 0);
         fb.add_scalar<uint32_t>(1, s.dimension, 0);
         fb.add_offset(0, name);
         fb.add_scalar<uint8_t>(7, 1, 0);  // index_type_type = FlatIndex
@@ -892,7 +1070,7 @@ int mvf_builder_to_bytes(const mvf_builder* b, uint32_t quirks, uint8_t** out, u
             uint32_t name = fb.create_string(b->columns[i].name);
             fb.start_table(6);  // MetadataColumn, schema/core.fbs:16-25
             fb.add_scalar<uint64_t>(3, 0, 0);
-            fb.add_scalar<uint32_t>(2, (uint32_t)(b->spaces.size() + i), 0);  // builder.rs:512
+            fb.add_scalar<uint32_t>(2, first_column_blk + (uint32_t)i, 0);  // builder.rs:512 (spaces.len() + i: the same without id blocks)
             fb.add_offset(0, name);
             fb.add_scalar<uint8_t>(1, b->columns[i].data_type, 0);
             col_offs.push_back(fb.end_table());

@@ -15,6 +15,7 @@ struct BatchParams {
     const float* xnorm;         // [n] sqrt(sum x^2) (cosine)
     const float* xx2;           // [n] sum x^2 (batched L2)
     const float* xxmax;         // [1] max over rows of sum x^2 (batched L2 error margin)
+    const uint32_t* tomb;       // deletion bitmap over local rows, or NULL
     const uint32_t* tau;        // [nq_pad] order-key thresholds (0xFFFFFFFF = none yet)
     uint64_t* cand;             // [nq_pad][cap] composites
     uint32_t* cnt;              // [nq_pad] entries appended (may exceed cap: overflow)
@@ -41,6 +42,7 @@ struct Batch16Params {
     const int32_t* xnorm_i;      // [n] int rows: sum x^2 (UInt8: of the shifted values x-128)
     const int32_t* xbias_i;      // [n] UInt8 rows: 128 * sum (x-128)
     uint32_t dim;
+    const uint32_t* tomb;        // deletion bitmap over local rows, or NULL
     const uint32_t* tau;
     uint64_t* cand;
     uint32_t* cnt;
@@ -76,6 +78,7 @@ struct CompactParams {
     // final stage only
     uint8_t metric, dtype;
     uint64_t index_base;
+    const uint64_t* ids;  // vector ids per local row, or NULL
     float* out_scores;
     uint64_t* out_indices;
     int32_t* out_raw;
@@ -102,6 +105,7 @@ struct RescoreParams {
     uint32_t pitch, dim;
     uint8_t dtype;              // Float32 or Float16 rows
     uint64_t index_base;
+    const uint64_t* ids;        // vector ids per local row, or NULL
     float* out_scores;
     uint64_t* out_indices;
     int32_t* out_raw;
@@ -115,6 +119,9 @@ uint32_t scan_mfma16_dma_queries_per_block(uint32_t nq);
 uint32_t scan_mfma16_dma_tile_rows(uint32_t bmq);
 hipError_t launch_scan_mfma16_dma(const Batch16Params& p, int dtype, int metric, int num_cus, uint32_t bmq, bool persistent,
                                   hipStream_t s);
+// ping-pong schedule of the 256-query tile (scan_mfma16_pp.hip); same parameters as the LDS-DMA kernel with bmq = 256
+bool scan_mfma16_pp_usable(uint32_t mtiles, int num_cus, uint32_t KT);
+hipError_t launch_scan_mfma16_pp(const Batch16Params& p, int dtype, int metric, int num_cus, hipStream_t s);
 hipError_t launch_prep_queries16(const void* q, int dtype, uint32_t nq, uint32_t nq_pad, uint32_t dim, uint32_t KPB,
                                  unsigned char* qprep, float* qaux0, float* qaux1, hipStream_t s);
 hipError_t launch_shadow_f16(const unsigned char* rows32, uint32_t n, uint32_t pitch32, uint32_t dim, unsigned char* rows16,

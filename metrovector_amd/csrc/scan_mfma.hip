@@ -230,7 +230,10 @@ __global__ void __launch_bounds__(256, 2) scan_mfma_f32_kernel(BatchParams p) {
 #pragma unroll
         for (int j = 0; j < 2; j++) {
             const uint32_t r = r0 + lane_r + j * 32;
-            const bool rok = r < p.row_end;
+            bool rok = r < p.row_end;
+            // deleted rows (tombstone bitmap): never appended; the direct phase stores padding in their slots
+            const bool dead = p.tomb && rok && ((p.tomb[r >> 5] >> (r & 31)) & 1u);
+            if (!p.direct) rok = rok && !dead;
             float xn = 0.f, rx = 1.f, xx = 0.f;
             if (METRIC == MVF_METRIC_COSINE) {
                 if (rok) xn = p.xnorm[r];
@@ -270,7 +273,7 @@ __global__ void __launch_bounds__(256, 2) scan_mfma_f32_kernel(BatchParams p) {
                                 // phase 0 (rows <= cap, no threshold yet): the slot is the row's offset -- 32 lanes
                                 // bumping one counter per query is what made that 4096-row phase cost milliseconds
                                 const uint32_t slot_i = p.direct ? r - p.row_begin : atomicAdd(&p.cnt[q], 1u);
-                                if (slot_i < p.cap) p.cand[(size_t)q * p.cap + slot_i] = ((uint64_t)key << 32) | r;
+                                if (slot_i < p.cap) p.cand[(size_t)q * p.cap + slot_i] = dead ? kPadComposite : ((uint64_t)key << 32) | r;
                             }
                         }
                     }
@@ -389,8 +392,19 @@ __device__ __forceinline__ void write_result_b(uint64_t comp, uint32_t o, const 
         s = score_from_key(key, p.metric);
     }
     p.out_scores[o] = s;
-    p.out_indices[o] = p.index_base + (uint32_t)comp;
+    p.out_indices[o] = p.ids ? p.ids[(uint32_t)comp] : p.index_base + (uint32_t)comp;
     if (p.out_raw) p.out_raw[o] = raw;
+}
+
+// After the sort the padding composites (the direct phase's slots of deleted rows) sit at the end: the live entries
+// are the prefix in front of the first of them.
+__device__ __forceinline__ uint32_t live_prefix(const uint64_t* buf, uint32_t m, int tid, uint32_t* live_s) {
+    if (tid == 0) *live_s = 0;
+    __syncthreads();
+    for (uint32_t i = tid; i < m; i += 1024)
+        if (buf[i] != kPadComposite && (i + 1 >= m || buf[i + 1] == kPadComposite)) *live_s = i + 1;
+    __syncthreads();
+    return *live_s;
 }
 
 template <bool FINAL>
@@ -399,13 +413,15 @@ __global__ void __launch_bounds__(1024) compact_kernel(CompactParams p) {
     uint64_t* buf = reinterpret_cast<uint64_t*>(smem);
     const int tid = threadIdx.x;
     const uint32_t q = blockIdx.x;
+    __shared__ uint32_t live_s;
     const uint32_t raw_cnt = p.direct_cnt ? p.direct_cnt : p.cnt[q];  // direct phase: every row of it, no counter
-    const uint32_t m = raw_cnt < p.cap ? raw_cnt : p.cap;
+    uint32_t m = raw_cnt < p.cap ? raw_cnt : p.cap;
     uint64_t* c = p.cand + (size_t)q * p.cap;
     const uint32_t P2 = next_pow2(m < 2 ? 2 : m);
     for (uint32_t i = tid; i < P2; i += 1024) buf[i] = i < m ? c[i] : kPadComposite;
     __syncthreads();
     bitonic_sort_u64<1024>(buf, P2, tid);
+    m = live_prefix(buf, m, tid, &live_s);
     const uint32_t keep = m < p.k ? m : p.k;
     if (FINAL) {
         for (uint32_t i = tid; i < p.k; i += 1024) write_result_b(i < keep ? buf[i] : kPadComposite, q * p.k + i, p);
@@ -434,14 +450,17 @@ __global__ void __launch_bounds__(1024) compact_margin_kernel(CompactParams p) {
     __shared__ uint32_t keep_s;
     const int tid = threadIdx.x;
     const uint32_t q = blockIdx.x;
+    __shared__ uint32_t live_s;
     const uint32_t raw_cnt = p.direct_cnt ? p.direct_cnt : p.cnt[q];  // direct phase: every row of it, no counter
-    const uint32_t m = raw_cnt < p.cap ? raw_cnt : p.cap;
+    uint32_t m = raw_cnt < p.cap ? raw_cnt : p.cap;
     uint64_t* c = p.cand + (size_t)q * p.cap;
     const uint32_t P2 = next_pow2(m < 2 ? 2 : m);
     for (uint32_t i = tid; i < P2; i += 1024) buf[i] = i < m ? c[i] : kPadComposite;
-    if (tid == 0) keep_s = m;
     __syncthreads();
     bitonic_sort_u64<1024>(buf, P2, tid);
+    m = live_prefix(buf, m, tid, &live_s);
+    if (tid == 0) keep_s = m;
+    __syncthreads();
     uint32_t tkey = kNanKey;
     if (m >= p.k) {
         const float vk = score_from_key((uint32_t)(buf[p.k - 1] >> 32), p.metric);
@@ -553,7 +572,7 @@ __global__ void __launch_bounds__(256) rescore_kernel(RescoreParams p) {
             p.out_indices[o] = ~0ull;
         } else {
             p.out_scores[o] = score_from_key((uint32_t)(comp >> 32), METRIC);
-            p.out_indices[o] = p.index_base + (uint32_t)comp;
+            p.out_indices[o] = p.ids ? p.ids[(uint32_t)comp] : p.index_base + (uint32_t)comp;
         }
         if (p.out_raw) p.out_raw[o] = 0;
     }

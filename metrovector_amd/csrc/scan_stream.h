@@ -10,6 +10,7 @@ struct ScanParams {
     const unsigned char* rows;  // device rows, `pitch` bytes apart, 16-B aligned
     const void* queries;        // device [nq_total][dim]: f32, or the space's int type
     const float* xscale;        // dt1x only: the rows are the scaled-f16 shadow of a Float32 corpus, row r times xscale[r]
+    const uint32_t* tomb;       // deletion bitmap, bit (r & 31) of word (r >> 5) = local row r is deleted; NULL = none
     uint64_t* cand;             // out: [launch queries][gridDim.x][kcap] sorted composites, ~0-padded
     uint32_t n;                 // rows in the shard
     uint32_t pitch;             // bytes per device row (multiple of 16)

@@ -52,16 +52,20 @@ class GpuCorpus:
     # ---- construction ------------------------------------------------------
     @classmethod
     def from_pointer(cls, ptr: int, rows: int, dimension: int, data_type: int, stride_bytes: int,
-                     device: int = 0, index_base: int = 0) -> "GpuCorpus":
+                     device: int = 0, index_base: int = 0, prepare_batched: bool = False, pinned_staging: bool = False,
+                     chunk_mib: int = 0) -> "GpuCorpus":
         """What a Rust caller passes: VectorSlice::as_ptr / stride / count
-        (src/vectors/mem.rs:75-77, vector_space.rs:155-188)."""
+        (src/vectors/mem.rs:75-77, vector_space.rs:155-188).  `prepare_batched` builds the row norms and (Float32
+        spaces) the f16 shadow chunk by chunk beside the copy (`mvfgpu_corpus_create_ex`)."""
         h = C.c_void_p()
-        _lib.gpu_check(_lib.gpu().mvfgpu_corpus_create(C.c_void_p(ptr), rows, dimension, data_type, stride_bytes,
-                                                       device, index_base, C.byref(h)))
+        flags = (_lib.UPLOAD_EAGER_SHADOW if prepare_batched else 0) | (_lib.UPLOAD_PINNED_STAGING if pinned_staging else 0)
+        opts = _lib.UploadOptions(C.sizeof(_lib.UploadOptions), flags, chunk_mib, 0)
+        _lib.gpu_check(_lib.gpu().mvfgpu_corpus_create_ex(C.c_void_p(ptr), rows, dimension, data_type, stride_bytes,
+                                                          device, index_base, C.byref(opts), C.byref(h)))
         return cls(h.value)
 
     @classmethod
-    def from_array(cls, rows: np.ndarray, device: int = 0, index_base: int = 0) -> "GpuCorpus":
+    def from_array(cls, rows: np.ndarray, device: int = 0, index_base: int = 0, **upload) -> "GpuCorpus":
         if rows.ndim != 2:
             raise InvalidArgument("rows must be a 2-D array")
         code = _CODE_OF.get(rows.dtype)
@@ -70,7 +74,7 @@ class GpuCorpus:
         if rows.shape[0] and rows.strides[1] != rows.itemsize:
             rows = np.ascontiguousarray(rows)
         stride = rows.strides[0] if rows.shape[0] else rows.shape[1] * rows.itemsize
-        return cls.from_pointer(rows.ctypes.data, rows.shape[0], rows.shape[1], code, stride, device, index_base)
+        return cls.from_pointer(rows.ctypes.data, rows.shape[0], rows.shape[1], code, stride, device, index_base, **upload)
 
     @classmethod
     def synthetic(cls, rows: int, dimension: int, data_type: int, seed: int, row0: int = 0,
@@ -96,6 +100,23 @@ class GpuCorpus:
 
     def __exit__(self, *exc):
         self.close()
+
+    # ---- deletions / ids (schema/core.fbs:35-39, :54) ---------------------------
+    def set_tombstones(self, bitmap: np.ndarray | None, first_bit: int = 0) -> None:
+        """Mask deleted rows: bit (first_bit + r) of `bitmap` (uint8, LSB first) = local row r is deleted."""
+        if bitmap is None:
+            _lib.gpu_check(_lib.gpu().mvfgpu_corpus_set_tombstones(self._h, None, 0, 0))
+            return
+        b = np.ascontiguousarray(bitmap, np.uint8)
+        _lib.gpu_check(_lib.gpu().mvfgpu_corpus_set_tombstones(self._h, b.ctypes.data_as(C.c_void_p), first_bit, b.size * 8))
+
+    def set_vector_ids(self, ids: np.ndarray | None) -> None:
+        """Report ids[row] instead of index_base + row."""
+        if ids is None:
+            _lib.gpu_check(_lib.gpu().mvfgpu_corpus_set_vector_ids(self._h, None, 0))
+            return
+        a = np.ascontiguousarray(ids, np.uint64)
+        _lib.gpu_check(_lib.gpu().mvfgpu_corpus_set_vector_ids(self._h, a.ctypes.data_as(C.c_void_p), a.size))
 
     # ---- introspection -------------------------------------------------------
     def info(self) -> _lib.CorpusInfo:

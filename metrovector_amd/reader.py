@@ -46,6 +46,13 @@ class DistanceMetric(enum.IntEnum):  # schema/types.fbs:20-25
 _NP_OF = {0: np.float32, 1: np.float16, 2: np.int8, 3: np.uint8}
 
 
+def _alive(owner) -> None:
+    """Views borrow the reader's mapping (VectorSpace<'a>, Vector<'a> in the reference): once the reader is
+    closed they dangle.  Rust rejects that at compile time; here it is a Python error instead of a segfault."""
+    if owner is not None and getattr(owner, "_h", None) is None:
+        raise InvalidArgument("the MvfReader this view borrows from has been closed")
+
+
 def _enum(cls, v):
     try:
         return cls(v)
@@ -66,11 +73,13 @@ class Vector:
         return _enum(DataType, self._dt)
 
     def as_bytes(self) -> bytes:  # vector.rs:61
+        _alive(self._owner)
         return C.string_at(self._ptr, self._nbytes)
 
     def as_f32(self) -> np.ndarray:
         """vector.rs:71-92: Float32/Float16 decode; anything else raises
         BuildError("Cannot convert to f32")."""
+        _alive(self._owner)
         n = C.c_uint64(0)
         _lib.host_check(_lib.host().mvf_vector_as_f32(C.c_void_p(self._ptr), self._nbytes, self._dt, None, 0, C.byref(n)))
         out = np.empty(n.value, np.float32)
@@ -79,6 +88,7 @@ class Vector:
         return out
 
     def as_slice(self, dtype) -> np.ndarray:  # vector.rs:104-119 (zero-copy typed view)
+        _alive(self._owner)
         dt = np.dtype(dtype)
         if self._nbytes % dt.itemsize:
             from .errors import CorruptedData
@@ -98,6 +108,7 @@ class VectorSlice:
         self._cs, self._owner = cs, owner
 
     def as_ptr(self) -> int:  # mem.rs:75-77
+        _alive(self._owner)
         return self._cs.data or 0
 
     @property
@@ -113,7 +124,8 @@ class VectorSlice:
         return _enum(DataType, self._cs.data_type)
 
     def to_numpy(self, dimension: int) -> np.ndarray:
-        """Zero-copy [count, dimension] view of the mapped rows."""
+        """Zero-copy [count, dimension] view of the mapped rows (valid while the reader is open)."""
+        _alive(self._owner)
         dt = np.dtype(_NP_OF[self._cs.data_type])
         nbytes = self._cs.count * self._cs.stride
         if nbytes == 0:
@@ -152,14 +164,41 @@ class VectorSpace:
     def get_vector(self, index: int) -> Vector:  # :101-142
         if index < 0:
             raise InvalidArgument("index must be >= 0")
+        _alive(self._reader)
         p, n = C.c_void_p(), C.c_uint64()
         _lib.host_check(_lib.host().mvf_space_get_vector(C.byref(self._cs), index, C.byref(p), C.byref(n)))
         return Vector(p.value, n.value, self._cs.dimension, self._cs.data_type, self._reader)
 
     def map_vector_range(self, start: int, count: int) -> VectorSlice:  # :155-188
+        _alive(self._reader)
         out = _lib.CVectorSlice()
         _lib.host_check(_lib.host().mvf_space_map_vector_range(C.byref(self._cs), start, count, C.byref(out)))
         return VectorSlice(out, self._reader)
+
+    # ---- vector ids / deletions (schema/core.fbs:54, :56, :35-39; layouts: include/mvf_file.h) -------------------
+    def vector_ids(self) -> np.ndarray | None:
+        """The space's id per row (u64), or None when positions are the ids (vector_ids_block_index = 0)."""
+        _alive(self._reader)
+        p, n = C.c_void_p(), C.c_uint64()
+        _lib.host_check(_lib.host().mvf_space_vector_ids(C.byref(self._cs), C.byref(p), C.byref(n)))
+        if not p.value:
+            return None
+        return np.frombuffer(C.string_at(p.value, n.value * 8), dtype="<u8").copy()
+
+    def deleted_count(self) -> int:
+        return self._cs.tombstone_deleted_count if self._cs.has_tombstones else 0
+
+    def tombstone_bitmap(self) -> np.ndarray | None:
+        """Deleted row POSITIONS as a bitmap (bit r & 7 of byte r >> 3), whichever on-disk format the space uses;
+        None when nothing is deleted."""
+        _alive(self._reader)
+        if not self._cs.has_tombstones:
+            return None
+        out = np.zeros((self._cs.total_vectors + 7) // 8, np.uint8)
+        dead = C.c_uint64()
+        _lib.host_check(_lib.host().mvf_space_tombstone_bitmap(C.byref(self._cs), out.ctypes.data_as(C.c_void_p), out.size,
+                                                               C.byref(dead)))
+        return out if dead.value else None
 
     def clone_concurrent(self) -> "VectorSpace":  # :194-201
         cs = _lib.CVectorSpace()

@@ -35,18 +35,51 @@ class ScoredVector:
     vector: np.ndarray  # decoded like Vector::as_f32 for float spaces; raw ints for Int8/UInt8
 
 
-def upload_space(space: VectorSpace, device: int = 0, first: int = 0, count: int | None = None) -> GpuCorpus:
+def upload_space(space: VectorSpace, device: int = 0, first: int = 0, count: int | None = None,
+                 prepare_batched: bool = False, verify_checksum: bool = False) -> GpuCorpus:
     """HBM-resident copy of rows [first, first+count) of a space, via the
     reference's own hand-off: map_vector_range(..).as_ptr() + stride + count
-    (vector_space.rs:155-188, mem.rs:75-77)."""
+    (vector_space.rs:155-188, mem.rs:75-77).  The space's deletions and vector ids (schema/core.fbs:35-39, :54) travel
+    with it; compressed blocks and Sparse spaces are refused.  `prepare_batched`: norms / f16 shadow are built chunk
+    by chunk beside the copy.  `verify_checksum`: the file's CRC32s (what the reference's validate_with_checksum
+    leaves as todo!(), src/reader.rs:220) are checked on a second thread WHILE the rows upload; a mismatch raises
+    CorruptedData and nothing stays resident."""
     if int(space.vector_type()) != 0:
         raise InvalidVectorType("Invalid vector type: expected Dense, got Sparse")
     total = space.total_vectors()
     if count is None:
         count = total - first
     sl = space.map_vector_range(first, count)
-    return GpuCorpus.from_pointer(sl.as_ptr(), sl.count, space.dimension(), int(space.data_type()), sl.stride,
-                                  device=device, index_base=first)
+    ids = space.vector_ids()
+    tomb = space.tombstone_bitmap()
+    check_err: list[BaseException] = []
+    th = None
+    if verify_checksum:
+        import threading
+
+        def _check():
+            try:
+                space._reader.validate_with_checksum()  # ctypes releases the GIL: runs beside the upload
+            except BaseException as e:  # noqa: BLE001 - re-raised below
+                check_err.append(e)
+
+        th = threading.Thread(target=_check)
+        th.start()
+    corpus = None
+    try:
+        corpus = GpuCorpus.from_pointer(sl.as_ptr(), sl.count, space.dimension(), int(space.data_type()), sl.stride,
+                                        device=device, index_base=first, prepare_batched=prepare_batched)
+        if tomb is not None:
+            corpus.set_tombstones(tomb, first_bit=first)
+        if ids is not None:
+            corpus.set_vector_ids(ids[first:first + count])
+    finally:
+        if th is not None:
+            th.join()
+    if check_err:
+        corpus.close()
+        raise check_err[0]
+    return corpus
 
 
 def find_top_k_similar(space: VectorSpace, query, k: int, metric: int | None = None, corpus: GpuCorpus | None = None,

@@ -360,8 +360,13 @@ int mvfo_merge_topk(const float* scores, const uint64_t* idx, const int32_t* raw
             for (uint32_t j = 0; j < k; j++) {
                 size_t s = ((size_t)l * nq + qi) * k + j;
                 size_t t = (size_t)l * k + j;
-                ids[t] = idx[s];
-                keys[t] = use_raw ? mvfo_key_from_raw(raw[s], metric)
+                /* ties: list order, then rank in the list (the lists come in ascending row-range order and each is
+                 * sorted by (key, position), so this is ascending global position -- also when a shard reports vector
+                 * ids instead of positions); padding sorts behind everything */
+                int pad = idx[s] == UINT64_MAX;
+                ids[t] = pad ? UINT64_MAX : (uint64_t)t;
+                keys[t] = pad ? 0xFFFFFFFFu
+                        : use_raw ? mvfo_key_from_raw(raw[s], metric)
                                   : mvfo_key_from_score(scores[s], metric);
                 src[t] = s;
             }
@@ -374,14 +379,14 @@ int mvfo_merge_topk(const float* scores, const uint64_t* idx, const int32_t* raw
                 if (out_raw) out_raw[o] = 0;
                 continue;
             }
-            /* find the source slot (global indices are unique) */
-            size_t s = 0;
-            for (size_t t = 0; t < m; t++)
-                if (ids[t] == heap[j].idx && keys[t] == heap[j].key) {
-                    s = src[t];
-                    break;
-                }
-            out_idx[o] = heap[j].idx;
+            if (heap[j].idx == UINT64_MAX) { /* fewer than k real entries */
+                out_idx[o] = UINT64_MAX;
+                out_scores[o] = pad_score(metric);
+                if (out_raw) out_raw[o] = 0;
+                continue;
+            }
+            size_t s = src[heap[j].idx];
+            out_idx[o] = idx[s];
             out_scores[o] = scores[s];
             if (out_raw) out_raw[o] = raw ? raw[s] : 0;
         }

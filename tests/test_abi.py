@@ -38,9 +38,23 @@ def test_host_library_exports_header_symbols():
 
 
 def test_struct_layouts_match_header():
-    assert C.sizeof(_lib.CorpusInfo) == 40
-    assert C.sizeof(_lib.Timing) == 48
-    assert C.sizeof(_lib.DataBlock) == 40
+    # sizes the C compiler gives the headers' structs (gcc, x86-64) against their ctypes mirrors
+    want = {"mvfgpu_corpus_info": _lib.CorpusInfo, "mvfgpu_timing": _lib.Timing, "mvfgpu_upload_options": _lib.UploadOptions,
+            "mvf_data_block": _lib.DataBlock, "mvf_vector_space": _lib.CVectorSpace, "mvf_vector_slice": _lib.CVectorSlice}
+    assert C.sizeof(_lib.CorpusInfo) == 48 and C.sizeof(_lib.Timing) == 48 and C.sizeof(_lib.DataBlock) == 40
+    import subprocess
+    import tempfile
+    body = "".join('printf("%s %%zu\\n", sizeof(%s));' % (n, n) for n in want)
+    src = '#include <stdio.h>\n#include "mvf_gpu.h"\n#include "mvf_file.h"\nint main(void){' + body + "return 0;}"
+    with tempfile.TemporaryDirectory() as d:
+        with open(os.path.join(d, "s.c"), "w") as f:
+            f.write(src)
+        subprocess.run(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), os.path.join(d, "s.c"), "-o", os.path.join(d, "s")],
+                       check=True)
+        out = subprocess.run([os.path.join(d, "s")], check=True, capture_output=True, text=True).stdout
+    for line in out.splitlines():
+        name, size = line.split()
+        assert C.sizeof(want[name]) == int(size), f"ctypes mirror of {name}: {C.sizeof(want[name])} bytes, header: {size}"
 
 
 def test_strerror_covers_reference_variants():
