@@ -263,6 +263,45 @@ int mvfgpu_merge_topk_packed_device(const void* d_packed, uint32_t nlists,
                                     uint64_t* d_out_indices, int32_t* d_out_raw,
                                     int device, void* hip_stream);
 
+/* ---- several GPUs in one process ------------------------------------------ */
+
+/*
+ * A shard set = the row-range shards of ONE vector space, one corpus handle per GPU, searched as a whole
+ * (SURVEY.md §8e): every shard searches its rows with global indices on its own device and stream, the per-shard
+ * top-k lists cross xGMI in ONE packed RCCL all-gather (ncclCommInitAll over the shards' devices; single process, no
+ * MPI, no torch), and the (score order, shard order, rank) merge runs on the first shard's device.  This is what a
+ * Rust host that owns all GPUs of a node binds; one process per GPU (torch.distributed / RCCL) composes
+ * mvfgpu_search_device + an all-gather + mvfgpu_merge_topk_packed_device itself (metrovector_amd/sharded.py).
+ *   shards : handles on DISTINCT devices, in ascending row-range order (index_base ascending, ranges disjoint), all of
+ *            one dimension and data type; BORROWED -- they must outlive the set and are not destroyed with it.
+ *            A single shard is allowed (a 1-rank RCCL communicator: the same exchange code path).  Shards that share
+ *            a device (rehearsing the protocol on fewer GPUs than shards; RCCL refuses duplicate devices), or
+ *            MVF_SHARDSET_NO_RCCL=1, exchange their lists with device-to-device copies instead.
+ * RCCL is loaded lazily (dlopen librccl.so) by the first mvfgpu_shardset_create; MVF_ERR_DEVICE if it is needed and
+ * cannot be loaded.  n_shards * k <= 8192.  One search at a time per set (calls serialise); results as mvfgpu_search.
+ */
+typedef struct mvfgpu_shardset mvfgpu_shardset;
+typedef struct mvfgpu_shardset_info {
+    uint32_t n_shards;
+    uint32_t rccl_ranks; /* ranks of the RCCL communicator (= n_shards), 0 when the lists travel by device copies */
+    uint32_t dimension;
+    uint8_t data_type;
+    uint8_t reserved[3];
+    uint64_t rows;       /* over all shards */
+} mvfgpu_shardset_info;
+typedef struct mvfgpu_shardset_timing { /* host wall clock of the newest search, milliseconds */
+    float search_ms;         /* query upload + per-shard searches (all shards concurrently, max over them) */
+    float exchange_merge_ms; /* all-gather + merge + results to the host */
+    uint64_t searches;
+} mvfgpu_shardset_timing;
+int mvfgpu_shardset_create(mvfgpu_corpus* const* shards, int n_shards, mvfgpu_shardset** out);
+void mvfgpu_shardset_destroy(mvfgpu_shardset* set);
+int mvfgpu_shardset_get_info(const mvfgpu_shardset* set, mvfgpu_shardset_info* out);
+int mvfgpu_shardset_search(mvfgpu_shardset* set, uint8_t metric, const void* queries,
+                           uint8_t query_dtype, uint32_t query_dim, uint32_t nq, uint32_t k,
+                           float* out_scores, uint64_t* out_indices, int32_t* out_raw);
+int mvfgpu_shardset_last_timing(const mvfgpu_shardset* set, mvfgpu_shardset_timing* out);
+
 /* ---- utilities ----------------------------------------------------------- */
 
 /* Fill a device buffer [nq][dimension] with synthetic queries (query dtype of

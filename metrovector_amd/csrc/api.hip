@@ -8,6 +8,7 @@
 #include "../../include/mvf_gpu.h"
 
 #include "aux_kernels.h"
+#include "internal.h"
 #include "mvf_common.h"
 #include "scan_mfma.h"
 #include "scan_stream.h"
@@ -71,6 +72,10 @@ struct DevBuf {
 
 }  // namespace
 
+namespace mvf {
+int set_fail(int status, const std::string& msg) { return fail(status, msg); }
+}  // namespace mvf
+
 struct mvfgpu_corpus {
     int device = 0;
     uint64_t n = 0, index_base = 0;
@@ -85,6 +90,7 @@ struct mvfgpu_corpus {
     mutable std::mutex host_mu;  // serialises the host-buffer API's device mirrors
     mutable DevBuf cand;                  // scratch: per-block candidate lists (K1)
     mutable DevBuf bq, bstate, bcand, xnorm;  // K2: padded queries + norms; tau/cnt/overflow; candidates; row norms
+    mutable DevBuf blk;                   // K2 narrow types: per-block candidate regions + their counts (scan_mfma.h)
     mutable DevBuf repair;                // K2 overflow repair: gathered queries + their results
     mutable DevBuf shadow, xscale;        // Float32 corpora: scaled-f16 shadow rows (selection only) + 2^-s_r per row
     DevBuf tomb, ids;                     // deletion bitmap (u32 words over local rows) / vector ids (u64 per local row)
@@ -307,10 +313,13 @@ bool k2_dma_enabled() {
     return !e || atoi(e) != 0;
 }
 
-// 256-query tile: the ping-pong schedule (scan_mfma16_pp.hip) or, with MVF_K2_PP=0, the lockstep LDS-DMA kernel
-bool k2_pp_enabled() {
-    const char* e = getenv("MVF_K2_PP");
-    return !e || atoi(e) != 0;
+// 256-query tile: the ping-pong schedule (scan_mfma16_pp.hip) or the lockstep LDS-DMA kernel.  Measured (MI355X,
+// profiles/r02_k2_ab.txt): Float16 rows / the f16 shadow 5 % faster on the ping-pong kernel once a block walks several
+// tiles (cfg5 last phase 20.7 -> 19.7 ms), short phases and Int8 rows a few percent slower (its longer prologue; cfg4
+// 6.94 vs 7.02 ms).  MVF_K2_PP=0|1 forces one of them (A/B runs).
+bool k2_pp_wanted(uint8_t kdtype, uint32_t ntiles, uint32_t mtiles, int num_cus) {
+    if (const char* e = getenv("MVF_K2_PP")) return atoi(e) != 0;
+    return kdtype == MVF_DTYPE_FLOAT16 && (uint64_t)ntiles * mtiles >= 8ull * (uint64_t)num_cus;
 }
 
 uint32_t k2_growth_cap() {  // largest phase-to-phase growth of the K2 scan (MVF_K2_GROWTH overrides, for A/B runs)
@@ -534,6 +543,12 @@ int search_batched_path(const mvfgpu_corpus* c, uint8_t metric, const void* d_qu
     hp.nq_pad = nq_pad;
     hp.mtiles = nq_pad / qpb;
     hp.cap = cap;
+    if (dma) {  // candidates leave the kernel through per-block regions (no global atomics in the epilogue)
+        HIP_TRY(c->blk.reserve((size_t)kBlkMaxBlocks * kBlkCap * 16 + (size_t)kBlkMaxBlocks * 4));
+        hp.blk_cand = static_cast<uint4*>(c->blk.p);
+        hp.blk_cnt = reinterpret_cast<uint32_t*>(static_cast<unsigned char*>(c->blk.p) + (size_t)kBlkMaxBlocks * kBlkCap * 16);
+        hp.blk_cap = kBlkCap;
+    }
 
     CompactParams cp{};
     cp.cand = bp.cand;
@@ -579,9 +594,12 @@ int search_batched_path(const mvfgpu_corpus* c, uint8_t metric, const void* d_qu
             bp.row_end = hp.row_end = (uint32_t)end;
             bp.ntiles = hp.ntiles = (uint32_t)((end - begin + tile_rows - 1) / tile_rows);
             bp.direct = hp.direct = (begin == 0 && end - begin <= cap) ? 1u : 0u;
+            const bool regions = hp.blk_cand && !hp.direct;
+            if (regions) HIP_TRY(hipMemsetAsync(hp.blk_cnt, 0, (size_t)kBlkMaxBlocks * 4, s));
             if (ps && last) HIP_TRY(hipEventRecord(ps->e[0], s));
             if (wide) HIP_TRY(launch_scan_mfma_f32(bp, metric, c->num_cus, s));
-            else if (dma && qpb == 256u && k2_pp_enabled() && scan_mfma16_pp_usable(hp.mtiles, c->num_cus, KT))
+            else if (dma && qpb == 256u && k2_pp_wanted(kdtype, hp.ntiles, hp.mtiles, c->num_cus) &&
+                     scan_mfma16_pp_usable(hp.mtiles, c->num_cus, KT))
                 HIP_TRY(launch_scan_mfma16_pp(hp, kdtype, metric, c->num_cus, s));
             else if (dma) HIP_TRY(launch_scan_mfma16_dma(hp, kdtype, metric, c->num_cus, qpb, k2_dma_persistent(kdtype), s));
             else HIP_TRY(launch_scan_mfma16(hp, kdtype, metric, c->num_cus, s));
@@ -592,6 +610,7 @@ int search_batched_path(const mvfgpu_corpus* c, uint8_t metric, const void* d_qu
                 tm.scan_flops = 2ull * nq * (end - begin) * c->dim;
             }
             tm.scan_launches++;
+            if (regions) HIP_TRY(launch_scatter_cand(hp, kBlkMaxBlocks, s));
         }
         cp.direct_cnt = (begin == 0 && end > begin && end - begin <= cap) ? (uint32_t)(end - begin) : 0u;
         if (approx) HIP_TRY(launch_compact_margin(cp, nq, s));
@@ -1031,6 +1050,7 @@ void mvfgpu_corpus_destroy(mvfgpu_corpus* c) {
         c->bq.release();
         c->bstate.release();
         c->bcand.release();
+        c->blk.release();
         c->xnorm.release();
         c->repair.release();
         c->shadow.release();
@@ -1064,7 +1084,7 @@ int mvfgpu_corpus_get_info(const mvfgpu_corpus* c, mvfgpu_corpus_info* out) {
     out->deleted_rows = c->deleted;
     std::lock_guard<std::mutex> lk(c->mu);
     out->device_bytes = c->tomb.bytes + c->ids.bytes + c->rows_bytes + c->cand.bytes + c->bq.bytes + c->bstate.bytes + c->bcand.bytes + c->xnorm.bytes +
-                        c->repair.bytes + c->shadow.bytes + c->xscale.bytes + c->h_q.bytes + c->h_s.bytes + c->h_i.bytes +
+                        c->repair.bytes + c->blk.bytes + c->shadow.bytes + c->xscale.bytes + c->h_q.bytes + c->h_s.bytes + c->h_i.bytes +
                         c->h_r.bytes;
     return MVF_OK;
 }

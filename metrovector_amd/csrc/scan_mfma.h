@@ -53,7 +53,18 @@ struct Batch16Params {
     uint32_t ntiles, mtiles;     // ceil(rows/256), nq_pad / queries-per-block
     uint32_t cap;
     uint32_t direct;             // phase 0: candidate slot = row - row_begin, no counter
+    // Candidate hand-off without global atomics (persistent grids of <= kBlkMaxBlocks blocks): a block appends
+    // {key, row, query, 0} records to ITS OWN region blk_cand[blockIdx.x][blk_cap], the slot from a counter in LDS
+    // (a returning GLOBAL atomic here would stall the appending wave for microseconds and, behind the barriers, the
+    // whole block); the final count goes to blk_cnt[blockIdx.x] and scatter_cand_kernel files the records into the
+    // per-query lists cand[] / cnt[] before the compaction.  NULL: the epilogue appends to cand[] / cnt[] directly.
+    uint4* blk_cand;
+    uint32_t* blk_cnt;
+    uint32_t blk_cap;
 };
+
+constexpr uint32_t kBlkMaxBlocks = 512;  // grids this size or smaller use per-block candidate regions ...
+constexpr uint32_t kBlkCap = 8192;       // ... of this many 16-byte records each (64 MiB in all)
 
 struct CompactParams {
     uint64_t* cand;
@@ -122,6 +133,8 @@ hipError_t launch_scan_mfma16_dma(const Batch16Params& p, int dtype, int metric,
 // ping-pong schedule of the 256-query tile (scan_mfma16_pp.hip); same parameters as the LDS-DMA kernel with bmq = 256
 bool scan_mfma16_pp_usable(uint32_t mtiles, int num_cus, uint32_t KT);
 hipError_t launch_scan_mfma16_pp(const Batch16Params& p, int dtype, int metric, int num_cus, hipStream_t s);
+// files the per-block candidate records of one K2 launch into the per-query lists (p.cand / p.cnt)
+hipError_t launch_scatter_cand(const Batch16Params& p, uint32_t nblocks, hipStream_t s);
 hipError_t launch_prep_queries16(const void* q, int dtype, uint32_t nq, uint32_t nq_pad, uint32_t dim, uint32_t KPB,
                                  unsigned char* qprep, float* qaux0, float* qaux1, hipStream_t s);
 hipError_t launch_shadow_f16(const unsigned char* rows32, uint32_t n, uint32_t pitch32, uint32_t dim, unsigned char* rows16,

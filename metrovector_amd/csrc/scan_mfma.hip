@@ -373,6 +373,21 @@ __global__ void __launch_bounds__(256) row_norms_f32_kernel(const unsigned char*
     if (lane == 0 && mx > 0.f) atomicMax(reinterpret_cast<unsigned int*>(xxmax), __float_as_uint(mx));  // non-negative floats order as uints
 }
 
+// ---- candidate hand-off: per-block regions -> per-query lists ---------------------------------------------------
+// The narrow-type K2 kernels append {key, row, query} records to per-block regions with an LDS counter (scan_mfma.h);
+// this pass files them under their queries.  Here the returning atomics cost nothing: thousands of threads, nobody
+// waits for anybody.  grid (4, regions); block 256.
+__global__ void __launch_bounds__(256) scatter_cand_kernel(const uint4* blk_cand, const uint32_t* blk_cnt, uint32_t blk_cap,
+                                                            uint64_t* cand, uint32_t* cnt, uint32_t cap) {
+    const uint32_t b = blockIdx.y;
+    const uint32_t n = min(blk_cnt[b], blk_cap);
+    for (uint32_t e = blockIdx.x * 256u + threadIdx.x; e < n; e += gridDim.x * 256u) {
+        const uint4 rec = blk_cand[(size_t)b * blk_cap + e];
+        const uint32_t slot = atomicAdd(&cnt[rec.z], 1u);
+        if (slot < cap) cand[(size_t)rec.z * cap + slot] = ((uint64_t)rec.x << 32) | rec.y;
+    }
+}
+
 // ---- candidate compaction: keep each query's k best, publish the new threshold ----
 // grid (nq); block 1024; LDS cap*8.  FINAL additionally formats the results.
 __device__ __forceinline__ void write_result_b(uint64_t comp, uint32_t o, const CompactParams& p) {
@@ -624,6 +639,12 @@ hipError_t launch_row_norms_f32(const unsigned char* rows, uint32_t n, uint32_t 
     if (n == 0) return hipSuccess;
     const uint32_t blocks = (uint32_t)std::min<uint64_t>(((uint64_t)n + 3) / 4, 256u * 8u);
     hipLaunchKernelGGL(row_norms_f32_kernel, dim3(blocks), dim3(256), 0, s, rows, n, pitch, pitch / 16, xnorm, xx2, xxmax);
+    return hipGetLastError();
+}
+
+hipError_t launch_scatter_cand(const Batch16Params& p, uint32_t nblocks, hipStream_t s) {
+    if (!p.blk_cand || nblocks == 0) return hipSuccess;
+    hipLaunchKernelGGL(scatter_cand_kernel, dim3(4, nblocks), dim3(256), 0, s, p.blk_cand, p.blk_cnt, p.blk_cap, p.cand, p.cnt, p.cap);
     return hipGetLastError();
 }
 

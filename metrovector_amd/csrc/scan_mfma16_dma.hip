@@ -67,7 +67,7 @@ template <int BMQ_> struct CfT {
     static constexpr int BPW = BR / 16 / NW;                    //                                      B
     static constexpr int PIECES = APW + BPW;
     static constexpr int INFLIGHT = PIECES * (NSTAGE - 2);      // pieces left in flight across the barrier
-    static constexpr size_t LDS = (size_t)NSTAGE * STAGE_B + 4 * BMQ * 4;  // ring + qaux0 + tau + qaux1 + prefilter
+    static constexpr size_t LDS = (size_t)NSTAGE * STAGE_B + 4 * BMQ * 4 + 16;  // ring + qaux0 + tau + qaux1 + prefilter + candidate counter
 };
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -93,6 +93,7 @@ __global__ void __launch_bounds__(512, 2) scan_mfma16_dma_kernel(Batch16Params p
     uint32_t* tau_s = reinterpret_cast<uint32_t*>(qa_s + BMQ);        // [BMQ]
     float* qb_s = reinterpret_cast<float*>(tau_s + BMQ);              // [BMQ] f16: |q|
     float* thr_s = qb_s + BMQ;                                        // [BMQ] pre-filter threshold
+    uint32_t* bc_s = reinterpret_cast<uint32_t*>(thr_s + BMQ);        // records in the block's candidate region
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -112,6 +113,7 @@ __global__ void __launch_bounds__(512, 2) scan_mfma16_dma_kernel(Batch16Params p
     }
     if (my_tiles == 0) return;
     const uint32_t G = my_tiles * p.KT;
+    if (tid == 0) *bc_s = 0;  // published by the barrier after the prologue
 
     // ---- DMA: 1-KB pieces (16 rows x 64 B); wave w fills A pieces [w APW, (w+1) APW) and B pieces [w BPW, (w+1) BPW) ----
     const uint32_t rl = (uint32_t)lane >> 2;                              // row inside a piece
@@ -223,7 +225,8 @@ __global__ void __launch_bounds__(512, 2) scan_mfma16_dma_kernel(Batch16Params p
         cs = cs + 1 == NSTAGE ? 0 : cs + 1;
         ds = ds + 1 == NSTAGE ? 0 : ds + 1;
         if (++c_kt == p.KT) {  // tile finished: its successor's first k-tiles are already in the ring
-            epilogue16<DT, METRIC, DIRECT, XS, BMQ, SH, WQ, WR, Cf::BR>(p, acc, c_nt, c_mt, wm, wn, lane, qa_s, qb_s, tau_s, thr_s);
+            epilogue16<DT, METRIC, DIRECT, XS, BMQ, SH, WQ, WR, Cf::BR>(p, acc, c_nt, c_mt, wm, wn, lane, qa_s, qb_s, tau_s, thr_s,
+                                                                        nullptr, nullptr, p.blk_cand ? bc_s : nullptr);
             zero_acc();
             c_kt = 0;
             if (++c_n < my_tiles) {
@@ -244,6 +247,7 @@ __global__ void __launch_bounds__(512, 2) scan_mfma16_dma_kernel(Batch16Params p
     }
     // the DMAs issued for k-tiles past the end target this block's own LDS: let them land before the wave exits
     __builtin_amdgcn_s_waitcnt(0x0070 | 0x0F00);  // vmcnt(0)
+    if (tid == 0 && p.blk_cnt) p.blk_cnt[blockIdx.x] = min(*bc_s, p.blk_cap);  // behind the loop's last barrier: every epilogue is done
 }
 
 template <int DT, int METRIC, int BMQ>
@@ -295,7 +299,9 @@ hipError_t launch_scan_mfma16_dma(const Batch16Params& p, int dtype, int metric,
     uint32_t nls = std::max(1u, (uint32_t)num_cus / 8u);
     if (nls > p.mtiles) nls -= nls % p.mtiles;
     const dim3 grid(persistent ? std::min(total, nls * 8u) : total);
-    return bmq == 64 ? launch_bmq<64>(p, dtype, metric, grid, s) : launch_bmq<256>(p, dtype, metric, grid, s);
+    Batch16Params q = p;
+    if (grid.x > kBlkMaxBlocks) q.blk_cand = nullptr, q.blk_cnt = nullptr;  // one candidate region per block: small grids only
+    return bmq == 64 ? launch_bmq<64>(q, dtype, metric, grid, s) : launch_bmq<256>(q, dtype, metric, grid, s);
 }
 
 }  // namespace mvf

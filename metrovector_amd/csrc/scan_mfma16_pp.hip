@@ -49,7 +49,7 @@ constexpr int NSA = 4, NSB = 5;            // ring depths (stages of 16 KB)
 constexpr int STG = 256 * DKB;             // one stage of either operand: 256 rows x 64 B
 constexpr int PPW = 4;                     // 1-KB DMA pieces per wave per k-tile (16 pieces of its operand / 4 waves)
 constexpr int NRC = 4;                     // row-constant buffers (tile ordinal mod 4), two 1-KB arrays each
-constexpr size_t PP_LDS = (size_t)(NSA + NSB) * STG + 4 * BMQ * 4 + NRC * 2 * BR * 4;
+constexpr size_t PP_LDS = (size_t)(NSA + NSB) * STG + 4 * BMQ * 4 + NRC * 2 * BR * 4 + 16;  // + the candidate counter
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* glb_ptr_t;
@@ -82,6 +82,7 @@ __global__ void __launch_bounds__(512, 2) scan_mfma16_pp_kernel(Batch16Params p)
     float* qb_s = reinterpret_cast<float*>(tau_s + BMQ);
     float* thr_s = qb_s + BMQ;
     uint32_t* rc_s = reinterpret_cast<uint32_t*>(thr_s + BMQ);  // [NRC][2][BR]
+    uint32_t* bc_s = rc_s + NRC * 2 * BR;                       // records in the block's candidate region
     const uint32_t* arr0 = F16 ? reinterpret_cast<const uint32_t*>(METRIC == MVF_METRIC_COSINE ? p.xnorm_f : p.xx2)
                                : reinterpret_cast<const uint32_t*>(p.xnorm_i);
     const uint32_t* arr1 = F16 ? reinterpret_cast<const uint32_t*>(p.xscale) : reinterpret_cast<const uint32_t*>(p.xbias_i);
@@ -156,6 +157,7 @@ __global__ void __launch_bounds__(512, 2) scan_mfma16_pp_kernel(Batch16Params p)
     zero_acc();
 
     load_query_consts16<DT, METRIC, BMQ>(p, mt * BMQ, tid, qa_s, qb_s, tau_s, thr_s);
+    if (tid == 0) *bc_s = 0;
     set_dma_tile(0);
     // prologue: A k-tiles 0, 1 (group 0) / B k-tiles 0 .. 3 (group 1)
     {
@@ -246,7 +248,7 @@ __global__ void __launch_bounds__(512, 2) scan_mfma16_pp_kernel(Batch16Params p)
             if (false)
 #endif
             epilogue16<DT, METRIC, DIRECT, XS, BMQ, SH, WQ, WR, BR, true>(p, acc, c_nt, mt, wm, wn, lane, qa_s, qb_s, tau_s, thr_s,
-                                                                          rc, rc + BR);
+                                                                          rc, rc + BR, p.blk_cand ? bc_s : nullptr);
             zero_acc();
             c_kt = 0;
             if (++c_n < my_tiles) c_nt = slot_nt(c_n);
@@ -254,6 +256,8 @@ __global__ void __launch_bounds__(512, 2) scan_mfma16_pp_kernel(Batch16Params p)
     }
     if (grp == 0) PP_BARRIER();                  // group 1 ran one barrier ahead at the start: even the counts
     __builtin_amdgcn_s_waitcnt(0x0070 | 0x0F00);  // vmcnt(0): the DMAs issued past the end target this block's own LDS
+    __syncthreads();                             // every wave's last epilogue has counted its candidates
+    if (tid == 0 && p.blk_cnt) p.blk_cnt[blockIdx.x] = min(*bc_s, p.blk_cap);
 }
 
 static_assert(PPW * (NSB - 2) < 16 && PPW * (NSA - 3) < 16, "vmcnt low field");

@@ -1,0 +1,339 @@
+// shardset.hip — the multi-GPU form of the search behind the C ABI (include/mvf_gpu.h, mvfgpu_shardset_*).
+//
+// the corpus is sharded by contiguous row range, one mvfgpu_corpus per GPU; a search runs on every
+// shard with global indices and ends in ONE exchange step -- an RCCL all-gather of the per-shard top-k lists over xGMI
+// -- followed by the (key, list, rank) merge.  This file is the single-process form of it (a Rust or C host holds all
+// GPUs of the node): ncclCommInitAll over the shards' devices, one HIP stream per device, the lists travel PACKED
+// ({u64 indices | f32 scores | i32 raw} = 16 bytes per result, MVFGPU_PACKED_LIST_BYTES) so the exchange is one
+// collective, not three.  The one-process-per-GPU form (torch.distributed) is metrovector_amd/sharded.py; both call the
+// same mvfgpu_search_device / mvfgpu_merge_topk_packed_device.
+//
+// RCCL is loaded lazily (dlopen) the first time a shard set is created: a process that never shards does not pay for
+// the library, and libmvf_gpu.so keeps loading where RCCL is absent.  Shards that SHARE a device (a rehearsal of the
+// protocol on fewer GPUs than shards; RCCL refuses duplicate devices) exchange their lists with device-to-device
+// copies instead -- same packed layout, same merge.
+
+#include "../../include/mvf_gpu.h"
+
+#include "internal.h"
+
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <dlfcn.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <set>
+#include <string>
+#include <thread>
+#include <vector>
+
+using mvf::set_fail;
+
+namespace {
+
+#define SS_HIP(expr)                                                                                   \
+    do {                                                                                               \
+        hipError_t e__ = (expr);                                                                       \
+        if (e__ != hipSuccess) return set_fail(MVF_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e__)); \
+    } while (0)
+
+struct Rccl {
+    void* lib = nullptr;
+    ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    std::string why;
+};
+
+Rccl* rccl() {  // loaded once; nullptr-lib + reason when unavailable
+    static Rccl r;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        // a copy already in the process (torch ships its own librccl.so) is preferred over loading a second one
+        const char* names[] = {"librccl.so", "librccl.so.1"};
+        for (int pass = 0; pass < 2 && !r.lib; pass++)
+            for (const char* n : names)
+                if ((r.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL | (pass == 0 ? RTLD_NOLOAD : 0)))) break;
+        if (!r.lib) {
+            r.why = std::string("cannot load librccl: ") + (dlerror() ? dlerror() : "not found");
+            return;
+        }
+        auto sym = [&](const char* n) {
+            void* p = dlsym(r.lib, n);
+            if (!p && r.why.empty()) r.why = std::string("librccl lacks ") + n;
+            return p;
+        };
+        r.CommInitAll = reinterpret_cast<decltype(r.CommInitAll)>(sym("ncclCommInitAll"));
+        r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(sym("ncclCommDestroy"));
+        r.GroupStart = reinterpret_cast<decltype(r.GroupStart)>(sym("ncclGroupStart"));
+        r.GroupEnd = reinterpret_cast<decltype(r.GroupEnd)>(sym("ncclGroupEnd"));
+        r.AllGather = reinterpret_cast<decltype(r.AllGather)>(sym("ncclAllGather"));
+        r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(sym("ncclGetErrorString"));
+        if (!r.why.empty()) r.lib = nullptr;
+    });
+    return &r;
+}
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    int dev = 0;
+    hipError_t reserve(int device, size_t need) {
+        if (need <= bytes) return hipSuccess;
+        (void)hipSetDevice(device);
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+        dev = device;
+        hipError_t e = hipMalloc(&p, need);
+        if (e == hipSuccess) bytes = need;
+        return e;
+    }
+    void release() {
+        if (!p) return;
+        (void)hipSetDevice(dev);
+        (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+};
+
+}  // namespace
+
+struct mvfgpu_shardset {
+    std::vector<mvfgpu_corpus*> shards;  // borrowed, ascending row-range order
+    std::vector<int> dev;
+    std::vector<hipStream_t> st;
+    std::vector<hipEvent_t> ev;
+    std::vector<ncclComm_t> comms;       // one per shard when RCCL is in use
+    bool use_rccl = false;
+    uint32_t dim = 0;
+    uint8_t dtype = 0;
+    uint64_t rows = 0;
+    std::mutex mu;                       // one search at a time per set (the gather buffers are per set)
+    std::vector<DevBuf> d_q, d_gather;   // per shard: queries; [n_shards] packed lists (its own list at slot s)
+    DevBuf d_out;                        // shard 0's device: merged scores | indices | raw
+    mvfgpu_shardset_timing tm{};
+};
+
+extern "C" {
+
+int mvfgpu_shardset_create(mvfgpu_corpus* const* shards, int n_shards, mvfgpu_shardset** out) {
+    if (!out) return set_fail(MVF_ERR_INVALID_ARGUMENT, "out is NULL");
+    *out = nullptr;
+    if (!shards || n_shards < 1 || n_shards > 64) return set_fail(MVF_ERR_INVALID_ARGUMENT, "n_shards must be 1..64");
+    auto* ss = new mvfgpu_shardset();
+    uint64_t prev_end = 0;
+    for (int s = 0; s < n_shards; s++) {
+        mvfgpu_corpus_info inf;
+        if (!shards[s] || mvfgpu_corpus_get_info(shards[s], &inf) != MVF_OK) {
+            delete ss;
+            return set_fail(MVF_ERR_INVALID_ARGUMENT, "shard " + std::to_string(s) + " is not a corpus handle");
+        }
+        if (s == 0) {
+            ss->dim = inf.dimension;
+            ss->dtype = inf.data_type;
+        } else if (inf.dimension != ss->dim || inf.data_type != ss->dtype) {
+            delete ss;
+            return set_fail(MVF_ERR_DIMENSION_MISMATCH, "Dimension mismatch: expected " + std::to_string(ss->dim) + ", got " +
+                                                            std::to_string(inf.dimension) + " (shards of one space share dimension and data type)");
+        }
+        if (s > 0 && inf.index_base < prev_end) {
+            delete ss;
+            return set_fail(MVF_ERR_INVALID_ARGUMENT, "shards must come in ascending, non-overlapping row-range order (the merge breaks ties by shard order)");
+        }
+        prev_end = inf.index_base + inf.rows;
+        ss->rows += inf.rows;
+        ss->shards.push_back(shards[s]);
+        ss->dev.push_back(inf.device);
+    }
+    ss->st.assign(n_shards, nullptr);
+    ss->ev.assign(n_shards, nullptr);
+    ss->d_q.resize(n_shards);
+    ss->d_gather.resize(n_shards);
+    int rc = MVF_OK;
+    for (int s = 0; s < n_shards && rc == MVF_OK; s++) {
+        if (hipSetDevice(ss->dev[s]) != hipSuccess || hipStreamCreateWithFlags(&ss->st[s], hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&ss->ev[s], hipEventDisableTiming) != hipSuccess)
+            rc = set_fail(MVF_ERR_DEVICE, "stream / event creation failed on device " + std::to_string(ss->dev[s]));
+    }
+    // RCCL over the shards' devices -- also for a single shard (a 1-rank communicator: the exchange step is then the
+    // same code path a node runs).  Shards sharing a device cannot form a communicator: device-to-device copies instead.
+    const bool distinct = std::set<int>(ss->dev.begin(), ss->dev.end()).size() == ss->dev.size();
+    const char* off = getenv("MVF_SHARDSET_NO_RCCL");
+    if (rc == MVF_OK && distinct && !(off && atoi(off) != 0)) {
+        Rccl* r = rccl();
+        if (!r->lib) {
+            rc = set_fail(MVF_ERR_DEVICE, "RCCL is required for a shard set over distinct devices: " + r->why);
+        } else {
+            ss->comms.assign(n_shards, nullptr);
+            ncclResult_t e = r->CommInitAll(ss->comms.data(), n_shards, ss->dev.data());
+            if (e != ncclSuccess) {
+                ss->comms.clear();
+                rc = set_fail(MVF_ERR_DEVICE, std::string("ncclCommInitAll: ") + r->GetErrorString(e));
+            } else {
+                ss->use_rccl = true;
+            }
+        }
+    }
+    if (rc != MVF_OK) {
+        mvfgpu_shardset_destroy(ss);
+        return rc;
+    }
+    *out = ss;
+    return MVF_OK;
+}
+
+void mvfgpu_shardset_destroy(mvfgpu_shardset* ss) {
+    if (!ss) return;
+    int prev = -1;
+    (void)hipGetDevice(&prev);
+    for (size_t s = 0; s < ss->shards.size(); s++) {
+        (void)hipSetDevice(ss->dev[s]);
+        if (ss->st[s]) (void)hipStreamSynchronize(ss->st[s]);
+    }
+    if (ss->use_rccl)
+        for (auto c : ss->comms)
+            if (c) (void)rccl()->CommDestroy(c);
+    for (size_t s = 0; s < ss->shards.size(); s++) {
+        (void)hipSetDevice(ss->dev[s]);
+        if (ss->st[s]) (void)hipStreamDestroy(ss->st[s]);
+        if (ss->ev[s]) (void)hipEventDestroy(ss->ev[s]);
+        ss->d_q[s].release();
+        ss->d_gather[s].release();
+    }
+    ss->d_out.release();
+    if (prev >= 0) (void)hipSetDevice(prev);
+    delete ss;
+}
+
+int mvfgpu_shardset_get_info(const mvfgpu_shardset* ss, mvfgpu_shardset_info* out) {
+    if (!ss || !out) return set_fail(MVF_ERR_INVALID_ARGUMENT, "NULL argument");
+    std::memset(out, 0, sizeof(*out));
+    out->n_shards = (uint32_t)ss->shards.size();
+    out->rccl_ranks = ss->use_rccl ? (uint32_t)ss->comms.size() : 0u;
+    out->dimension = ss->dim;
+    out->data_type = ss->dtype;
+    out->rows = ss->rows;
+    return MVF_OK;
+}
+
+int mvfgpu_shardset_last_timing(const mvfgpu_shardset* ss, mvfgpu_shardset_timing* out) {
+    if (!ss || !out) return set_fail(MVF_ERR_INVALID_ARGUMENT, "NULL argument");
+    *out = ss->tm;
+    return MVF_OK;
+}
+
+int mvfgpu_shardset_search(mvfgpu_shardset* ss, uint8_t metric, const void* queries, uint8_t query_dtype, uint32_t query_dim,
+                           uint32_t nq, uint32_t k, float* out_scores, uint64_t* out_indices, int32_t* out_raw) {
+    if (!ss) return set_fail(MVF_ERR_INVALID_ARGUMENT, "shard set is NULL");
+    if (!queries || !out_scores || !out_indices) return set_fail(MVF_ERR_INVALID_ARGUMENT, "NULL buffer");
+    if (nq == 0 || k == 0 || k > MVFGPU_MAX_K) return set_fail(MVF_ERR_INVALID_ARGUMENT, "nq must be > 0 and k in 1..1024");
+    const int S = (int)ss->shards.size();
+    if ((uint64_t)S * k > 8192) return set_fail(MVF_ERR_INVALID_ARGUMENT, "n_shards * k exceeds 8192 (the cross-shard merge's capacity)");
+    std::lock_guard<std::mutex> lk(ss->mu);
+    int prev = -1;
+    (void)hipGetDevice(&prev);
+    struct Restore {
+        int d;
+        ~Restore() {
+            if (d >= 0) (void)hipSetDevice(d);
+        }
+    } restore{prev};
+
+    const size_t nres = (size_t)nq * k, list_bytes = MVFGPU_PACKED_LIST_BYTES(nq, k);
+    const size_t qbytes = (size_t)nq * query_dim * (query_dtype == MVF_DTYPE_FLOAT32 ? 4u : 1u);
+    for (int s = 0; s < S; s++) {
+        SS_HIP(ss->d_q[s].reserve(ss->dev[s], qbytes));
+        SS_HIP(ss->d_gather[s].reserve(ss->dev[s], list_bytes * S));
+    }
+    SS_HIP(ss->d_out.reserve(ss->dev[0], nres * 16));
+
+    // ---- per-shard searches, concurrently: one host thread per shard (the batched path of a search ends in a
+    // device-to-host flag read, so sequential calls would serialise the GPUs).  Each writes its packed list straight
+    // into its slot of its own gather buffer (in-place all-gather).
+    std::vector<int> rcs(S, MVF_OK);
+    std::vector<std::string> msgs(S);
+    const auto t0 = std::chrono::steady_clock::now();
+    auto work = [&](int s) {
+        if (hipSetDevice(ss->dev[s]) != hipSuccess) {
+            rcs[s] = MVF_ERR_DEVICE;
+            msgs[s] = "hipSetDevice failed";
+            return;
+        }
+        unsigned char* slot = static_cast<unsigned char*>(ss->d_gather[s].p) + list_bytes * s;
+        hipError_t e = hipMemcpyAsync(ss->d_q[s].p, queries, qbytes, hipMemcpyHostToDevice, ss->st[s]);
+        if (e != hipSuccess) {
+            rcs[s] = MVF_ERR_DEVICE;
+            msgs[s] = std::string("query upload: ") + hipGetErrorString(e);
+            return;
+        }
+        rcs[s] = mvfgpu_search_device(ss->shards[s], metric, ss->d_q[s].p, query_dtype, query_dim, nq, k,
+                                      reinterpret_cast<float*>(slot + 8 * nres), reinterpret_cast<uint64_t*>(slot),
+                                      reinterpret_cast<int32_t*>(slot + 12 * nres), ss->st[s]);
+        if (rcs[s] != MVF_OK) msgs[s] = mvfgpu_last_error_message();
+    };
+    if (S == 1) {
+        work(0);
+    } else {
+        std::vector<std::thread> th;
+        for (int s = 0; s < S; s++) th.emplace_back(work, s);
+        for (auto& t : th) t.join();
+    }
+    for (int s = 0; s < S; s++)
+        if (rcs[s] != MVF_OK) return set_fail(rcs[s], "shard " + std::to_string(s) + ": " + msgs[s]);
+    const auto t1 = std::chrono::steady_clock::now();
+
+    // ---- the exchange step: ONE grouped all-gather of the packed lists (stream-ordered behind each shard's search)
+    if (ss->use_rccl) {
+        Rccl* r = rccl();
+        ncclResult_t e = r->GroupStart();
+        for (int s = 0; s < S && e == ncclSuccess; s++) {
+            unsigned char* g = static_cast<unsigned char*>(ss->d_gather[s].p);
+            e = r->AllGather(g + list_bytes * s, g, list_bytes, ncclInt8, ss->comms[s], ss->st[s]);
+        }
+        ncclResult_t e2 = r->GroupEnd();
+        if (e == ncclSuccess) e = e2;
+        if (e != ncclSuccess) return set_fail(MVF_ERR_DEVICE, std::string("ncclAllGather: ") + r->GetErrorString(e));
+    } else {
+        // shards share a device (rehearsal): gather to shard 0's buffer with device-to-device copies
+        for (int s = 1; s < S; s++) {
+            (void)hipSetDevice(ss->dev[s]);
+            SS_HIP(hipEventRecord(ss->ev[s], ss->st[s]));
+            (void)hipSetDevice(ss->dev[0]);
+            SS_HIP(hipStreamWaitEvent(ss->st[0], ss->ev[s], 0));
+            SS_HIP(hipMemcpyPeerAsync(static_cast<unsigned char*>(ss->d_gather[0].p) + list_bytes * s, ss->dev[0],
+                                      static_cast<unsigned char*>(ss->d_gather[s].p) + list_bytes * s, ss->dev[s], list_bytes,
+                                      ss->st[0]));
+        }
+    }
+    // ---- merge on shard 0's device, results to the host
+    (void)hipSetDevice(ss->dev[0]);
+    float* ms = static_cast<float*>(ss->d_out.p);
+    uint64_t* mi = reinterpret_cast<uint64_t*>(static_cast<unsigned char*>(ss->d_out.p) + 4 * nres);
+    int32_t* mr = reinterpret_cast<int32_t*>(static_cast<unsigned char*>(ss->d_out.p) + 12 * nres);
+    int rc = mvfgpu_merge_topk_packed_device(ss->d_gather[0].p, (uint32_t)S, nq, k, metric, ss->dtype, ms, mi, mr, ss->dev[0], ss->st[0]);
+    if (rc != MVF_OK) return rc;
+    SS_HIP(hipMemcpyAsync(out_scores, ms, nres * 4, hipMemcpyDeviceToHost, ss->st[0]));
+    SS_HIP(hipMemcpyAsync(out_indices, mi, nres * 8, hipMemcpyDeviceToHost, ss->st[0]));
+    if (out_raw) SS_HIP(hipMemcpyAsync(out_raw, mr, nres * 4, hipMemcpyDeviceToHost, ss->st[0]));
+    for (int s = 0; s < S; s++) {  // every rank's part of the collective has to finish before the buffers are reused
+        (void)hipSetDevice(ss->dev[s]);
+        SS_HIP(hipStreamSynchronize(ss->st[s]));
+    }
+    const auto t2 = std::chrono::steady_clock::now();
+    ss->tm.search_ms = std::chrono::duration<float, std::milli>(t1 - t0).count();
+    ss->tm.exchange_merge_ms = std::chrono::duration<float, std::milli>(t2 - t1).count();
+    ss->tm.searches++;
+    return MVF_OK;
+}
+
+}  // extern "C"

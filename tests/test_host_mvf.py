@@ -287,3 +287,111 @@ def test_reader_survives_corrupted_footers():
         except E.MvfError:
             outcomes["err"] += 1
     assert outcomes["err"] > 500 and outcomes["ok"] > 0
+
+
+# ---- vector ids, tombstones, compression (schema/core.fbs:35-39, :54, :56; schema/types.fbs:28-39) ---------------
+# The reference never writes these (src/builder.rs:483-485), so there is no reference behaviour to mirror: the layouts
+# are the ones include/mvf_file.h defines in the schema's words.
+
+def _ids_tomb_file(fmt, with_ids=True):
+    rows = np.arange(40 * 4, dtype=np.float32).reshape(40, 4)
+    ids = (np.arange(40, dtype=np.uint64) * 7 + 1000)[::-1].copy()  # not monotonic in position
+    dead_pos = [0, 3, 17, 39]
+    b = MvfBuilder()
+    b.add_vector_space("a", 4, VectorType.Dense, DistanceMetric.L2, DataType.Float32)
+    b.add_vectors("a", rows)
+    if with_ids:
+        b.set_vector_ids("a", ids)
+    if fmt == 1:
+        bm = np.zeros(5, np.uint8)
+        for p in dead_pos:
+            bm[p >> 3] |= 1 << (p & 7)
+        b.set_tombstones("a", 1, bm.tobytes(), len(dead_pos))
+    elif fmt == 2:
+        lst = np.sort(ids[dead_pos]) if with_ids else np.array(dead_pos, np.uint64)
+        b.set_tombstones("a", 2, lst.astype("<u8").tobytes(), len(dead_pos))
+    b.add_vector_space("b", 2, VectorType.Dense, DistanceMetric.Cosine, DataType.Float16)  # a second space behind the extra blocks
+    b.add_vectors("b", [[1.0, 2.0], [3.0, 4.0]])
+    b.add_metadata_column("m", DataType.UInt32, b"\x01\x02\x03\x04")
+    return b.build().to_bytes(), rows, ids, dead_pos
+
+
+@pytest.mark.parametrize("fmt,with_ids", [(1, True), (2, True), (2, False), (1, False), (0, True)])
+def test_vector_ids_and_tombstones_roundtrip(fmt, with_ids):
+    img, rows, ids, dead_pos = _ids_tomb_file(fmt, with_ids)
+    r = MvfReader.from_bytes(img)
+    s = r.vector_space("a")
+    assert (s.map_vector_range(0, 40).to_numpy(4) == rows).all()            # vectors_block_index points past nothing wrong
+    got_ids = s.vector_ids()
+    assert (got_ids is None) == (not with_ids)
+    if with_ids:
+        assert (got_ids == ids).all()
+    bm = s.tombstone_bitmap()
+    if fmt == 0:
+        assert bm is None and s.deleted_count() == 0
+    else:
+        assert s.deleted_count() == len(dead_pos)
+        assert sorted(np.nonzero(np.unpackbits(bm, bitorder="little")[:40])[0].tolist()) == dead_pos
+    s2 = r.vector_space("b")                                                  # block indices behind the id / tombstone blocks
+    assert s2.get_vector(1).as_f32().tolist() == [3.0, 4.0] and s2.vector_ids() is None and s2.tombstone_bitmap() is None
+    assert r.metadata_column_names() == ["m"]
+    r.validate_with_checksum()                                                # the extra blocks carry checksums too
+
+
+def test_file_without_ids_keeps_the_reference_layout():
+    """No id / tombstone blocks -> byte-identical to what the builder wrote before they existed:
+    vectors_block_index = space ordinal (src/builder.rs:480), slot 9 and slot 11 absent."""
+    a = create_test_mvf().to_bytes()
+    b = MvfBuilder()
+    b.add_vector_space("test_space", 4, VectorType.Dense, DistanceMetric.L2, DataType.Float32)
+    b.add_vectors("test_space", T)
+    b.set_vector_ids("test_space", [])
+    assert b.build().to_bytes() == a
+
+
+def test_compressed_blocks_are_refused():
+    """CompressionAlgorithm::LZ4 / Zstd (schema/types.fbs:28-32) have no codec in the reference; scanning the bytes as
+    rows would be silent garbage, so every access to such a block fails."""
+    img = bytearray(create_test_mvf().to_bytes())
+    (footer_len,) = struct.unpack("<I", img[-8:-4])
+    foot = len(img) - 8 - footer_len
+    blk = bytes(struct.pack("<QQ", 0, 48))                                     # the DataBlock struct of the only block
+    at = img.index(blk, foot)
+    img[at + 16] = 1                                                          # compression = LZ4
+    r = MvfReader.from_bytes(bytes(img))                                      # open() itself does not look at blocks
+    s = r.vector_space("test_space")
+    for call in (lambda: s.get_vector(0), lambda: s.map_vector_range(0, 3)):
+        with pytest.raises(E.BuildError, match="compression"):
+            call()
+
+
+def test_footer_products_cannot_wrap():
+    """total_vectors and dimension come from the untrusted footer: index * row_bytes must not wrap into range."""
+    img = bytearray(create_test_mvf().to_bytes())
+    (footer_len,) = struct.unpack("<I", img[-8:-4])
+    foot = len(img) - 8 - footer_len
+    at = img.index(struct.pack("<Q", 3), foot)                                # total_vectors = 3
+    img[at:at + 8] = struct.pack("<Q", 1 << 61)
+    s = MvfReader.from_bytes(bytes(img)).vector_space("test_space")
+    assert s.total_vectors() == 1 << 61
+    with pytest.raises(E.IndexOutOfBounds):
+        s.get_vector(1 << 60)                                                 # (1 << 60) * 16 == 0 mod 2^64
+    with pytest.raises(E.CorruptedData):
+        s.map_vector_range(1 << 60, 1)
+    with pytest.raises(E.CorruptedData):
+        s.map_vector_range(0, 1 << 60)
+    assert s.get_vector(2).as_f32().tolist() == T[2]
+
+
+def test_views_of_a_closed_reader_raise_instead_of_crashing(tmp_path):
+    p = tmp_path / "t.mvf"
+    create_test_mvf().save(p)
+    r = MvfReader.open(p)
+    s = r.vector_space("test_space")
+    v = s.get_vector(0)
+    sl = s.map_vector_range(0, 3)
+    r.close()
+    for call in (lambda: s.get_vector(0), lambda: s.map_vector_range(0, 1), lambda: s.vector_ids(), v.as_f32, v.as_bytes,
+                 lambda: v.as_slice(np.float32), sl.as_ptr, lambda: sl.to_numpy(4)):
+        with pytest.raises(E.InvalidArgument, match="closed"):
+            call()
