@@ -9,7 +9,7 @@ use std::ffi::{c_char, c_int, c_void, CStr};
 
 use metrovector::{
     errors::{MvfError, Result},
-    mvf_fbs::{DataType, DistanceMetric},
+    mvf_fbs::{DataType, DistanceMetric, VectorType},
     vectors::vector_space::VectorSpace,
 };
 
@@ -33,18 +33,62 @@ extern "C" {
     /// 0 automatic, 1 streaming kernel, 2 exact MFMA on the stored rows, 3 MFMA with the f16 shadow (the automatic
     /// choice for Float32 spaces), 4 additionally streams the f16 shadow for 1-2 queries (include/mvf_gpu.h).
     fn mvfgpu_set_scan_path(corpus: *mut MvfGpuCorpus, path: c_int) -> c_int;
+    /// Deletion bitmap over the shard's rows / one u64 id per row (include/mvf_gpu.h; schema/core.fbs:35-39, :54).
+    fn mvfgpu_corpus_set_tombstones(corpus: *mut MvfGpuCorpus, bitmap: *const u8, first_bit: u64, nbits: u64) -> c_int;
+    fn mvfgpu_corpus_set_vector_ids(corpus: *mut MvfGpuCorpus, ids_le: *const c_void, n: u64) -> c_int;
+    /// Several GPUs in one process: per-shard searches + ONE packed RCCL all-gather + merge (include/mvf_gpu.h).
+    fn mvfgpu_shardset_create(shards: *const *mut MvfGpuCorpus, n_shards: c_int, out: *mut *mut MvfGpuShardset) -> c_int;
+    fn mvfgpu_shardset_destroy(set: *mut MvfGpuShardset);
+    fn mvfgpu_shardset_search(set: *mut MvfGpuShardset, metric: u8, queries: *const c_void, query_dtype: u8,
+                              query_dim: u32, nq: u32, k: u32, out_scores: *mut f32, out_indices: *mut u64,
+                              out_raw: *mut i32) -> c_int;
 }
 
+#[repr(C)]
+pub struct MvfGpuShardset {
+    _private: [u8; 0],
+}
+
+/// First two unsigned integers found in `msg` ("Index out of bounds: 7 >= 3", "Dimension mismatch: expected 768,
+/// got 4", "Unsupported version: got 2, expected 1"): the C ABI carries the numbers of the structured variants in the
+/// detail text, phrased exactly like the reference's `#[error(...)]` strings (src/errors.rs:8-40).
+fn two_numbers(msg: &str) -> (usize, usize) {
+    let mut it = msg
+        .split(|c: char| !c.is_ascii_digit())
+        .filter(|t| !t.is_empty())
+        .filter_map(|t| t.parse::<usize>().ok());
+    (it.next().unwrap_or(0), it.next().unwrap_or(0))
+}
+
+/// `enum mvf_status` (include/mvf_status.h) -> `MvfError` (src/errors.rs:8-40), every code explicitly.
+/// The two codes without a reference variant (11 Device, 12 InvalidArgument) become `Extension`: "something outside
+/// the file format failed", with the code's name in front so callers can still tell them apart.
 fn status_to_error(status: c_int) -> MvfError {
     let msg = unsafe { CStr::from_ptr(mvfgpu_last_error_message()) }.to_string_lossy().into_owned();
     match status {
+        1 => MvfError::Io(std::io::Error::new(std::io::ErrorKind::Other, msg)),
         2 => MvfError::InvalidFormat(msg),
+        3 => {
+            let (got, expected) = two_numbers(&msg); // "Unsupported version: got {got}, expected {expected}"
+            MvfError::UnsupportedVersion { got: got as u16, expected: expected as u16 }
+        }
         4 => MvfError::VectorSpaceNotFound(msg),
-        5 => MvfError::IndexOutOfBounds { index: 0, len: 0 },
-        6 => MvfError::DimensionMismatch { expected: 0, actual: 0 },
+        5 => {
+            let (index, len) = two_numbers(&msg); // "Index out of bounds: {index} >= {len}"
+            MvfError::IndexOutOfBounds { index, len }
+        }
+        6 => {
+            let (expected, actual) = two_numbers(&msg); // "Dimension mismatch: expected {expected}, got {actual}"
+            MvfError::DimensionMismatch { expected, actual }
+        }
+        // the only way the GPU path produces it: a Sparse space where a Dense one is required
+        7 => MvfError::InvalidVectorType { expected: VectorType::Dense, actual: VectorType::Sparse },
         8 => MvfError::CorruptedData(msg),
         9 => MvfError::Extension(msg),
-        _ => MvfError::Build(msg), // 10 Build, 11 Device, 12 InvalidArgument
+        10 => MvfError::Build(msg),
+        11 => MvfError::Extension(format!("Device error: {msg}")),
+        12 => MvfError::Extension(format!("Invalid argument: {msg}")),
+        other => MvfError::Extension(format!("unknown libmvf_gpu status {other}: {msg}")),
     }
 }
 
@@ -149,4 +193,68 @@ impl Drop for GpuCorpus {
 /// Same name and argument meaning as examples/similarity_search.rs:140-144.
 pub fn find_top_k_similar(space: &VectorSpace, query: &[f32], k: usize) -> Result<Vec<(u64, f32)>> {
     GpuCorpus::from_space(space, 0)?.search(space.distance_metric(), query, k)
+}
+
+/// One vector space sharded by row range over several GPUs of this node: `devices.len()` shards of
+/// near-equal size, searched as a whole -- per-shard top-k, one RCCL all-gather over xGMI, merge.
+pub struct ShardedCorpus {
+    set: *mut MvfGpuShardset,
+    shards: Vec<GpuCorpus>, // borrowed by the set: dropped after it
+    dimension: u32,
+}
+
+unsafe impl Send for ShardedCorpus {}
+
+impl ShardedCorpus {
+    pub fn from_space(space: &VectorSpace, devices: &[i32]) -> Result<Self> {
+        let total = space.total_vectors();
+        let g = devices.len().max(1) as u64;
+        let per = (total + g - 1) / g;
+        let stride = space.dimension() as u64 * elem_size(space.data_type())? as u64;
+        let mut shards = Vec::new();
+        for (i, &dev) in devices.iter().enumerate() {
+            let first = (i as u64 * per).min(total);
+            let count = per.min(total - first);
+            let slice = space.map_vector_range(first, count)?;
+            let mut handle = std::ptr::null_mut();
+            let rc = unsafe {
+                mvfgpu_corpus_create(slice.as_ptr::<u8>() as *const c_void, count, space.dimension(),
+                                     space.data_type().0, stride, dev, first, &mut handle)
+            };
+            if rc != 0 {
+                return Err(status_to_error(rc));
+            }
+            shards.push(GpuCorpus { handle, dimension: space.dimension() });
+        }
+        let handles: Vec<*mut MvfGpuCorpus> = shards.iter().map(|s| s.handle).collect();
+        let mut set = std::ptr::null_mut();
+        let rc = unsafe { mvfgpu_shardset_create(handles.as_ptr(), handles.len() as c_int, &mut set) };
+        if rc != 0 {
+            return Err(status_to_error(rc));
+        }
+        Ok(Self { set, shards, dimension: space.dimension() })
+    }
+
+    pub fn search_batch(&mut self, metric: DistanceMetric, queries: &[f32], nq: usize, k: usize) -> Result<Vec<Vec<(u64, f32)>>> {
+        let mut scores = vec![0f32; nq * k];
+        let mut indices = vec![0u64; nq * k];
+        let rc = unsafe {
+            mvfgpu_shardset_search(self.set, metric.0, queries.as_ptr() as *const c_void, DataType::Float32.0,
+                                   self.dimension, nq as u32, k as u32, scores.as_mut_ptr(), indices.as_mut_ptr(),
+                                   std::ptr::null_mut())
+        };
+        if rc != 0 {
+            return Err(status_to_error(rc));
+        }
+        let _ = &self.shards;
+        Ok((0..nq)
+            .map(|q| (0..k).map(|j| (indices[q * k + j], scores[q * k + j])).take_while(|(i, _)| *i != u64::MAX).collect())
+            .collect())
+    }
+}
+
+impl Drop for ShardedCorpus {
+    fn drop(&mut self) {
+        unsafe { mvfgpu_shardset_destroy(self.set) } // before the shards it borrows
+    }
 }

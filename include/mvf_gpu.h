@@ -209,15 +209,13 @@ int mvfgpu_search(const mvfgpu_corpus* corpus, uint8_t metric,
  * asynchronous on `hip_stream` (a hipStream_t; NULL = the default stream).
  * This is the timed region of bench.py and the producer of the per-shard
  * lists that RCCL all-gathers.  d_raw may be NULL.
- * Small batches run the streaming kernel and return without waiting (below
- * 32 queries on corpora under 1 GiB; on larger ones a single query, below 5
- * for Int8/UInt8 and below 9 for Float32 without the f16 shadow — the
- * measured crossovers: the streaming kernel takes up to 4 queries per pass
- * over the rows, the MFMA path uses a 64-query tile up to 128 queries).  Larger
- * batches run the MFMA path, whose
- * last step reads back per-query overflow flags (an adversarially ordered
- * corpus can overflow a candidate buffer; such queries are redone exactly by
- * the streaming kernel): that call returns after the stream has drained.
+ * The call never waits for the device.  Small batches run the streaming kernel (below 32 queries on corpora under
+ * 1 GiB; on larger ones a single query, below 5 for Int8/UInt8 and below 9 for Float32 without the f16 shadow -- the
+ * measured crossovers: the streaming kernel takes up to 4 queries per pass over the rows, the MFMA path uses a
+ * 64-query tile up to 128 queries).  Larger batches run the MFMA path in phases; an adversarially ordered corpus can
+ * overflow a query's candidate buffer there, and such queries are redone exactly by the streaming kernel in REPAIR
+ * launches that follow every batched search and decide ON THE DEVICE whether they have anything to do (round 1 read
+ * the flags back and synchronised; now e.g. an RCCL all-gather can be queued right behind the search).
  */
 int mvfgpu_search_device(const mvfgpu_corpus* corpus, uint8_t metric,
                          const void* d_queries, uint8_t query_dtype,

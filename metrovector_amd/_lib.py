@@ -33,6 +33,15 @@ class UploadOptions(C.Structure):
 UPLOAD_EAGER_NORMS, UPLOAD_EAGER_SHADOW, UPLOAD_PINNED_STAGING = 1, 2, 4
 
 
+class ShardsetInfo(C.Structure):
+    _fields_ = [("n_shards", C.c_uint32), ("rccl_ranks", C.c_uint32), ("dimension", C.c_uint32), ("data_type", C.c_uint8),
+                ("reserved", C.c_uint8 * 3), ("rows", C.c_uint64)]
+
+
+class ShardsetTiming(C.Structure):
+    _fields_ = [("search_ms", C.c_float), ("exchange_merge_ms", C.c_float), ("searches", C.c_uint64)]
+
+
 class Timing(C.Structure):
     _fields_ = [("scan_ms", C.c_float), ("select_ms", C.c_float), ("total_ms", C.c_float),
                 ("scan_ms_avg", C.c_float), ("select_ms_avg", C.c_float), ("samples", C.c_uint32),
@@ -74,6 +83,12 @@ def gpu() -> C.CDLL:
     lib.mvfgpu_corpus_set_tombstones.argtypes = [vp, vp, u64, u64]
     lib.mvfgpu_corpus_set_vector_ids.argtypes = [vp, vp, u64]
     lib.mvfgpu_corpus_create_synthetic.argtypes = [u64, u32, u8, u64, u64, i32, pp]
+    lib.mvfgpu_shardset_create.argtypes = [C.POINTER(vp), i32, pp]
+    lib.mvfgpu_shardset_destroy.restype = None
+    lib.mvfgpu_shardset_destroy.argtypes = [vp]
+    lib.mvfgpu_shardset_get_info.argtypes = [vp, C.POINTER(ShardsetInfo)]
+    lib.mvfgpu_shardset_search.argtypes = [vp, u8, vp, u8, u32, u32, u32, vp, vp, vp]
+    lib.mvfgpu_shardset_last_timing.argtypes = [vp, C.POINTER(ShardsetTiming)]
     lib.mvfgpu_corpus_destroy.restype = None
     lib.mvfgpu_corpus_destroy.argtypes = [vp]
     lib.mvfgpu_corpus_get_info.argtypes = [vp, C.POINTER(CorpusInfo)]
@@ -89,7 +104,8 @@ def gpu() -> C.CDLL:
     lib.mvfgpu_last_timing.argtypes = [vp, C.POINTER(Timing)]
     lib.mvfgpu_set_scan_path.argtypes = [vp, i32]
     for name in ("mvfgpu_device_count", "mvfgpu_corpus_create", "mvfgpu_corpus_create_ex", "mvfgpu_corpus_create_synthetic",
-                 "mvfgpu_corpus_set_tombstones", "mvfgpu_corpus_set_vector_ids",
+                 "mvfgpu_corpus_set_tombstones", "mvfgpu_corpus_set_vector_ids", "mvfgpu_shardset_create",
+                 "mvfgpu_shardset_get_info", "mvfgpu_shardset_search", "mvfgpu_shardset_last_timing",
                  "mvfgpu_corpus_get_info", "mvfgpu_corpus_read_rows", "mvfgpu_corpus_gather_rows", "mvfgpu_search", "mvfgpu_search_device",
                  "mvfgpu_merge_topk_host", "mvfgpu_merge_topk_device", "mvfgpu_merge_topk_packed_device",
                  "mvfgpu_synth_queries_device",

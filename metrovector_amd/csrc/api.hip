@@ -178,12 +178,12 @@ hipError_t scan_launch(uint8_t dtype, const ScanParams& p, int metric, int G, in
     }
 }
 
-const void* scan_kernel(uint8_t dtype, int metric, int G, int nqv) {
+const void* scan_kernel(uint8_t dtype, int metric, int G, int nqv, bool redo = false) {
     switch (dtype) {
-    case MVF_DTYPE_FLOAT32: return scan_stream_kernel_ptr_dt0(metric, G, nqv);
-    case MVF_DTYPE_FLOAT16: return scan_stream_kernel_ptr_dt1(metric, G, nqv);
-    case MVF_DTYPE_INT8: return scan_stream_kernel_ptr_dt2(metric, G, nqv);
-    default: return scan_stream_kernel_ptr_dt3(metric, G, nqv);
+    case MVF_DTYPE_FLOAT32: return scan_stream_kernel_ptr_dt0(metric, G, nqv, redo);
+    case MVF_DTYPE_FLOAT16: return scan_stream_kernel_ptr_dt1(metric, G, nqv, redo);
+    case MVF_DTYPE_INT8: return scan_stream_kernel_ptr_dt2(metric, G, nqv, redo);
+    default: return scan_stream_kernel_ptr_dt3(metric, G, nqv, redo);
     }
 }
 
@@ -401,46 +401,98 @@ int ensure_norms(const mvfgpu_corpus* c, hipStream_t s) {
 }
 
 // Queries whose candidate budget overflowed (or whose margin reached past a truncated list) are redone exactly by K1 on
-// the stored rows: the flags are read back (host sync), the flagged queries gathered so that K1 takes them four per pass.
+// the stored rows -- DECIDED ON THE DEVICE, so the search stays asynchronous (round 1 read the flags back and
+// synchronised the stream): flag_compact_kernel turns the flags into a dense list + count; then ceil(nq / R) pairs of
+// REPAIR launches follow unconditionally -- K1's repair variant (every block walks its window of the list in groups of
+// four queries, one pass over the rows per group) and select_final's -- each of which reads the count and exits at once
+// when its window is empty.  The common case (nothing flagged) costs a few empty launches (~2.5 us each on the device,
+// hidden behind the scan on the host); an adversarial corpus is still answered exactly.  R (queries per pair) is what
+// 256 MiB of per-block lists hold.
 int repair_flagged_queries(const mvfgpu_corpus* c, uint8_t metric, const void* d_queries, uint32_t nq, uint32_t nq_pad,
                            uint32_t k, uint32_t* overflow, float* d_scores, uint64_t* d_indices, int32_t* d_raw,
                            hipStream_t s) {
-    std::vector<uint32_t> flags(nq);
-    HIP_TRY(hipMemcpyAsync(flags.data(), overflow, (size_t)nq * 4, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
-    std::vector<uint32_t> redo;
-    for (uint32_t q = 0; q < nq; q++)
-        if (flags[q]) redo.push_back(q);
-    if (redo.empty()) return MVF_OK;
-    HIP_TRY(hipMemsetAsync(overflow, 0, (size_t)nq_pad * 4, s));
-    const size_t nf = redo.size();
-    if (getenv("MVF_DEBUG_REPAIR")) fprintf(stderr, "[mvfgpu] overflow repair: %zu of %u queries redone by K1\n", nf, nq);
-    const size_t qbytes = (size_t)c->dim * (is_int_dtype(c->dtype) ? 1u : 4u);
-    const size_t qarea = (nf * qbytes + 15u) & ~(size_t)15u, nres = nf * k;
-    HIP_TRY(c->repair.reserve(qarea + nres * 16));
-    unsigned char* gq = static_cast<unsigned char*>(c->repair.p);
-    uint64_t* ti = reinterpret_cast<uint64_t*>(gq + qarea);
-    float* ts = reinterpret_cast<float*>(ti + nres);
-    int32_t* tr = reinterpret_cast<int32_t*>(ts + nres);
-    for (size_t i = 0; i < nf; i++)
-        HIP_TRY(hipMemcpyAsync(gq + i * qbytes, static_cast<const unsigned char*>(d_queries) + redo[i] * qbytes, qbytes,
-                               hipMemcpyDeviceToDevice, s));
-    int rc = search_stream_path(c, metric, gq, (uint32_t)nf, k, ts, ti, tr, s, /*profile=*/false);
-    if (rc != MVF_OK) return rc;
-    for (size_t i = 0; i < nf; i++) {
-        const size_t o = (size_t)redo[i] * k;
-        HIP_TRY(hipMemcpyAsync(d_scores + o, ts + i * k, (size_t)k * 4, hipMemcpyDeviceToDevice, s));
-        HIP_TRY(hipMemcpyAsync(d_indices + o, ti + i * k, (size_t)k * 8, hipMemcpyDeviceToDevice, s));
-        if (d_raw) HIP_TRY(hipMemcpyAsync(d_raw + o, tr + i * k, (size_t)k * 4, hipMemcpyDeviceToDevice, s));
+    (void)nq_pad;
+    if (c->n == 0) return MVF_OK;
+    const uint32_t kcap = next_pow2(k);
+    const int G = c->G;
+    const uint32_t chunk_rows = scan_chunk_rows(G);
+    const uint32_t nchunks = (uint32_t)((c->n + chunk_rows - 1) / chunk_rows);
+    const uint32_t pmax = next_pow2(k + chunk_rows);
+    int nqv = 4;
+    size_t lds = scan_lds_bytes(c->dtype, G, c->J, nqv, pmax);
+    if (lds > 150 * 1024) {
+        nqv = 1;
+        lds = scan_lds_bytes(c->dtype, G, c->J, nqv, pmax);
     }
-    HIP_TRY(hipStreamSynchronize(s));
+    if (lds > 160 * 1024) return fail(MVF_ERR_BUILD, "dimension too large for the streaming kernel's LDS query tile");
+    const void* kfn = scan_kernel(c->dtype, metric, G, nqv, /*redo=*/true);
+    if (lds > 48 * 1024) HIP_TRY(hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    int occ = 0;
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kfn, 256, lds));
+    if (occ < 1) occ = 1;
+    const uint32_t nblocks = std::min<uint32_t>(nchunks, (uint32_t)occ * (uint32_t)c->num_cus);
+    const size_t per_query = (size_t)nblocks * kcap * 8;
+    const uint32_t R = (uint32_t)std::min<size_t>(64, std::max<size_t>(4, ((size_t)256 << 20) / per_query));
+    HIP_TRY(c->repair.reserve((size_t)R * per_query + (size_t)nq * 4 + 16));
+    uint64_t* lists = static_cast<uint64_t*>(c->repair.p);
+    uint32_t* redo_cnt = reinterpret_cast<uint32_t*>(static_cast<unsigned char*>(c->repair.p) + (size_t)R * per_query);
+    uint32_t* redo_list = redo_cnt + 4;
+    HIP_TRY(launch_flag_compact(overflow, nq, redo_list, redo_cnt, s));
+    for (uint32_t base = 0; base < nq; base += R) {
+        ScanParams sp{};
+        sp.rows = c->d_rows;
+        sp.queries = d_queries;
+        sp.tomb = static_cast<const uint32_t*>(c->tomb.p);
+        sp.cand = lists;
+        sp.n = (uint32_t)c->n;
+        sp.pitch = c->pitch;
+        sp.dim = c->dim;
+        sp.V = c->V;
+        sp.J = c->J;
+        sp.q0 = 0;
+        sp.nq_total = nq;
+        sp.k = k;
+        sp.kcap = kcap;
+        sp.pmax = pmax;
+        sp.chunk_rows = chunk_rows;
+        sp.nchunks = nchunks;
+        sp.redo_list = redo_list;
+        sp.redo_cnt = redo_cnt;
+        sp.redo_base = base;
+        sp.redo_max = R;
+        HIP_TRY(scan_launch(c->dtype, sp, metric, G, nqv, dim3(nblocks), lds, s));
+        SelectParams fp{};
+        fp.lists = lists;
+        fp.nlists = nblocks;
+        fp.kcap = kcap;
+        fp.heads = (k + nblocks - 1) / nblocks;
+        fp.P = 4096;
+        fp.k = k;
+        fp.metric = metric;
+        fp.dtype = c->dtype;
+        fp.index_base = c->index_base;
+        fp.ids = static_cast<const uint64_t*>(c->ids.p);
+        fp.out_scores = d_scores;
+        fp.out_indices = d_indices;
+        fp.out_raw = d_raw;
+        fp.redo_list = redo_list;
+        fp.redo_cnt = redo_cnt;
+        fp.redo_base = base;
+        HIP_TRY(launch_select_final(fp, std::min(R, nq - base), s));
+    }
+    if (getenv("MVF_DEBUG_REPAIR")) {  // diagnostics only: how many queries took the repair path (synchronises)
+        uint32_t n = 0;
+        HIP_TRY(hipMemcpyAsync(&n, redo_cnt, 4, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        if (n) fprintf(stderr, "[mvfgpu] overflow repair: %u of %u queries redone by K1\n", n, nq);
+    }
     return MVF_OK;
 }
 
 // K2 path: MFMA batched scan in geometric phases with per-query candidate
 // compaction between them (scan_mfma.hip for Float32 rows, scan_mfma16.hip for
-// Float16 / Int8 rows).  Blocking at the end: the overflow flags are read back
-// and any flagged query is redone exactly with K1.
+// Float16 / Int8 rows).  Asynchronous: queries whose candidate budget overflowed are
+// redone exactly by K1 in repair launches that decide on the device whether to run.
 int search_batched_path(const mvfgpu_corpus* c, uint8_t metric, const void* d_queries, uint32_t nq, uint32_t k,
                         float* d_scores, uint64_t* d_indices, int32_t* d_raw, hipStream_t s) {
     // Float32 rows: either the exact f32 MFMA kernel on the rows themselves, or -- 4x faster -- the f16 kernel on a
@@ -651,8 +703,8 @@ int search_batched_path(const mvfgpu_corpus* c, uint8_t metric, const void* d_qu
 // stored rows, so half the time of the HBM-bound K1 -- with the batched path's select-with-a-margin / re-score-exactly
 // scheme: K1 (dt1x unit: f16 rows times xscale[r]) keeps the k' > k best approximate scores; every candidate within
 // twice the error bound of the k-th is re-scored from the stored f32 rows and the f32 query; if ALL k' are inside the
-// margin (rows beyond the cut may be too) the query is flagged and redone by the exact K1.  Ends with the flag
-// read-back, i.e. it is synchronous like the batched path.
+// margin (rows beyond the cut may be too) the query is flagged and redone by the exact K1 (on-device conditional
+// repair launches, like the batched path: asynchronous).
 //   x~ = x (1 + e), |e| <= 2^-11 per element:  |q.x~ - q.x| <= 2^-11 |q||x|;  | |q - x~| - |q - x| | <= 2^-11 |x|;
 //   cosine (numerator and denominator both from x~) <= 2 * 2^-11; plus the f32 accumulation, (dim + 16) 2^-23.
 int search_stream_shadow_path(const mvfgpu_corpus* c, uint8_t metric, const void* d_queries, uint32_t nq, uint32_t k,

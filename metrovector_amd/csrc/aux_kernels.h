@@ -24,7 +24,15 @@ struct SelectParams {
     uint64_t* out_cand;     // nullable
     uint32_t* out_cnt;
     uint32_t cand_cap;
+    // repair launches: block b serves query redo_list[redo_base + b] (its lists are the b-th of the launch) and exits
+    // at once when *redo_cnt <= redo_base + b
+    const uint32_t* redo_list;  // nullable
+    const uint32_t* redo_cnt;
+    uint32_t redo_base;
 };
+
+// queries flagged by the K2 compactions -> a dense list + its length, flags cleared (one block)
+hipError_t launch_flag_compact(uint32_t* overflow, uint32_t nq, uint32_t* redo_list, uint32_t* redo_cnt, hipStream_t s);
 
 struct ShardMergeParams {
     const float* scores;      // list l, query q, rank j at [l * ls_scores + q * k + j]

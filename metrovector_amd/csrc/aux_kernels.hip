@@ -53,6 +53,11 @@ __global__ void __launch_bounds__(1024) select_final_kernel(SelectParams p) {
     uint32_t* cnt = reinterpret_cast<uint32_t*>(buf + p.P);
     const int tid = threadIdx.x;
     const uint32_t q = blockIdx.x;
+    uint32_t qout = q;  // the query whose result row this block writes
+    if (p.redo_list) {
+        if (p.redo_base + q >= *p.redo_cnt) return;  // block-uniform: nothing (more) to repair
+        qout = p.redo_list[p.redo_base + q];
+    }
     const uint64_t* lists = p.lists + (size_t)q * p.nlists * p.kcap;
 
     // 1. threshold from the list heads
@@ -108,7 +113,23 @@ __global__ void __launch_bounds__(1024) select_final_kernel(SelectParams p) {
         if (tid == 0) p.out_cnt[q] = keep;
         return;
     }
-    for (uint32_t i = tid; i < p.k; i += 1024) write_result(i < m ? buf[i] : kPadComposite, q * p.k + i, p);
+    for (uint32_t i = tid; i < p.k; i += 1024) write_result(i < m ? buf[i] : kPadComposite, qout * p.k + i, p);
+}
+
+// The K2 compactions flag queries whose candidate budget overflowed (overflow[q] != 0).  One block turns the flags into
+// a dense list for the repair launches and clears them.  Order within the list is irrelevant.
+__global__ void __launch_bounds__(1024) flag_compact_kernel(uint32_t* overflow, uint32_t nq, uint32_t* redo_list, uint32_t* redo_cnt) {
+    __shared__ uint32_t n_s;
+    if (threadIdx.x == 0) n_s = 0;
+    __syncthreads();
+    for (uint32_t q = threadIdx.x; q < nq; q += 1024) {
+        if (overflow[q]) {
+            redo_list[atomicAdd(&n_s, 1u)] = q;
+            overflow[q] = 0;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) *redo_cnt = n_s;
 }
 
 // Cross-shard merge of formatted results.  An entry is the u64 composite (order key << 32 | slot), slot = list * k +
@@ -235,6 +256,11 @@ __global__ void synth_packed_kernel(void* out, uint64_t nelem, uint8_t dtype, ui
 
 hipError_t launch_select_final(const SelectParams& p, uint32_t nq, hipStream_t s) {
     hipLaunchKernelGGL(select_final_kernel, dim3(nq), dim3(1024), (size_t)p.P * 8 + 16, s, p);
+    return hipGetLastError();
+}
+
+hipError_t launch_flag_compact(uint32_t* overflow, uint32_t nq, uint32_t* redo_list, uint32_t* redo_cnt, hipStream_t s) {
+    hipLaunchKernelGGL(flag_compact_kernel, dim3(1), dim3(1024), 0, s, overflow, nq, redo_list, redo_cnt);
     return hipGetLastError();
 }
 

@@ -24,13 +24,19 @@ struct ScanParams {
     uint32_t pmax;              // next_pow2(k + chunk_rows): LDS buffer entries per query
     uint32_t chunk_rows;
     uint32_t nchunks;
+    // REPAIR launches (api.hip: queries whose K2 candidate budget overflowed are redone exactly, decided ON THE DEVICE):
+    // the queries are redo_list[redo_base + i], i < min(*redo_cnt - redo_base, redo_max); the block walks them in
+    // groups of NQ (one pass over the rows per group) and emits list (i, block).  *redo_cnt <= redo_base: exit at once.
+    const uint32_t* redo_list;
+    const uint32_t* redo_cnt;
+    uint32_t redo_base, redo_max;
 };
 
-// nqv: queries per launch, 1 or 4
+// nqv: queries per pass, 1 or 4; p.redo_list != NULL selects the repair variant of the kernel
 #define MVF_DECL_SCAN(dt)                                                                          \
     hipError_t scan_stream_launch_dt##dt(const ScanParams& p, int metric, int G, int nqv, dim3 grid, \
                                          size_t lds, hipStream_t s);                               \
-    const void* scan_stream_kernel_ptr_dt##dt(int metric, int G, int nqv);
+    const void* scan_stream_kernel_ptr_dt##dt(int metric, int G, int nqv, bool redo = false);
 MVF_DECL_SCAN(0)
 MVF_DECL_SCAN(1)
 MVF_DECL_SCAN(2)

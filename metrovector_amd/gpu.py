@@ -193,6 +193,62 @@ class GpuCorpus:
         _lib.gpu_check(_lib.gpu().mvfgpu_set_scan_path(self._h, path))
 
 
+class ShardSet:
+    """Several GPUs in ONE process (`mvfgpu_shardset_*`): per-shard searches on every device, one packed RCCL
+    all-gather of the top-k lists, merge on the first shard's device.  The shards are borrowed."""
+
+    def __init__(self, shards: list[GpuCorpus]):
+        self._shards = list(shards)  # keeps them alive
+        arr = (C.c_void_p * len(shards))(*[s._h for s in shards])
+        h = C.c_void_p()
+        _lib.gpu_check(_lib.gpu().mvfgpu_shardset_create(arr, len(shards), C.byref(h)))
+        self._h = h
+
+    def close(self) -> None:
+        if self._h is not None and self._h.value:
+            _lib.gpu().mvfgpu_shardset_destroy(self._h)
+        self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def info(self) -> _lib.ShardsetInfo:
+        out = _lib.ShardsetInfo()
+        _lib.gpu_check(_lib.gpu().mvfgpu_shardset_get_info(self._h, C.byref(out)))
+        return out
+
+    def last_timing(self) -> _lib.ShardsetTiming:
+        out = _lib.ShardsetTiming()
+        _lib.gpu_check(_lib.gpu().mvfgpu_shardset_last_timing(self._h, C.byref(out)))
+        return out
+
+    def search(self, queries: np.ndarray, k: int, metric: int = L2) -> SearchResult:
+        q = np.asarray(queries)
+        if q.ndim == 1:
+            q = q[None, :]
+        qcode = _CODE_OF.get(q.dtype)
+        if qcode is None:
+            raise BuildError(f"unsupported query dtype {q.dtype}")
+        q = np.ascontiguousarray(q)
+        nq, qdim = q.shape
+        sc = np.empty((nq, k), np.float32)
+        idx = np.empty((nq, k), np.uint64)
+        raw = np.empty((nq, k), np.int32)
+        _lib.gpu_check(_lib.gpu().mvfgpu_shardset_search(self._h, metric, q.ctypes.data_as(C.c_void_p), qcode, qdim, nq, k,
+                                                         sc.ctypes.data_as(C.c_void_p), idx.ctypes.data_as(C.c_void_p),
+                                                         raw.ctypes.data_as(C.c_void_p)))
+        return SearchResult(sc, idx, raw)
+
+
 def merge_topk_host(scores: np.ndarray, indices: np.ndarray, raw: np.ndarray | None, metric: int,
                     data_type: int) -> SearchResult:
     """Merge per-shard results [nlists, nq, k] (host) — `mvfgpu_merge_topk_host`."""
