@@ -4,21 +4,25 @@
     python bench.py --gpus N --steps K --warmup W
     (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
-Workload (BASELINE.json configs[1]): 10M x 768 Float32, cosine, ONE query,
-top-100 — the HBM-bound streaming scan.  A "step" = one search of the whole
-resident corpus: query already on the device, kernels + on-device top-k,
-results left on the device.  Corpus upload / generation is outside the timed
-region (it is done once; DESIGN.md §7 gives the PCIe-inclusive figure).
+`value` (the contract line's workload, BASELINE.json configs[1]): 10M x 768 Float32, cosine, ONE query, top-100 per
+GPU -- the HBM-bound streaming scan.  A "step" = one search of the whole resident corpus: query already on the device,
+kernels + on-device top-k, results left on the device.  Corpus upload / generation is outside the timed region (done
+once; DESIGN.md §6 gives the PCIe-inclusive figure).  N > 1 is WEAK scaling: every rank holds its own 10M-row shard of
+an N*10M-row corpus (row-range sharding, metrovector_amd/sharded.py); a step adds the RCCL all-gather of the per-shard
+top-k and the merge; value = all rows of all ranks * nq / time (max over ranks, barriers on both sides).
 
-N > 1 is WEAK scaling: every rank holds its own 10M-row shard of an N*10M-row
-corpus (row range sharding, metrovector_amd/sharded.py); a step adds the RCCL
-all-gather of the per-shard top-k and the merge.  value = all rows of all
-ranks * nq / time.
+Second leg at EVERY N, `cfg5_sharded` (BASELINE.json configs[4], the config north_star names for 8 GPUs): every rank
+holds a 12.5M x 1024 Float16 shard (N = 8: the 100M-row corpus), 1024 batched queries, L2, top-100 -- MFMA path on each
+shard, one packed RCCL all-gather, merge; per-rank scan ms, exchange ms and the RCCL ranks the process group reports
+are printed with it.
 
-One JSON line on rank 0; `roofline` prices the streaming-scan kernel against
-8 TB/s HBM3E using HIP events recorded on the kernel's own stream during the
-timed steps; `cpu_baseline` times the oracle's faithful single-thread
-restatement of the reference loop on a bounded sample.
+N = 1 only: recall@k against an exact oracle top-k over all rows, the metric's second leg on the same corpus (1024
+batched queries: default path and exact f32 MFMA), `host_api` (the same search through the host-buffer entry point
+mvfgpu_search: query H2D + kernels + results D2H), `cpu_baseline` (the oracle's faithful single-thread restatement of the
+reference loop) and `cpu_baseline_best_effort` (OpenMP over rows, all host cores, no per-row allocation).
+
+One JSON line on rank 0.  `roofline` prices the dominant kernel of the `value` workload against 8 TB/s HBM3E from HIP
+events recorded on the kernel's own stream during the timed steps.
 """
 from __future__ import annotations
 
@@ -36,26 +40,36 @@ sys.path.insert(0, ROOT)
 SEED = 0x4D564631  # "MVF1"
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 MFMA_F32_PEAK_TF = 157.3  # same guide: dense f32-input MFMA peak (v_mfma_f32_32x32x2_f32)
-MFMA_F16_PEAK_TF = 2500.0  # same guide: ~2.5 PF dense bf16/f16 (v_mfma_f32_32x32x16_f16)
-MFMA_I8_PEAK_TOPS = 5000.0  # same guide: int8 = 2x the bf16 rate per clock (v_mfma_i32_32x32x32_i8)
+MFMA_F16_PEAK_TF = 2500.0  # same guide: ~2.5 PF dense bf16/f16
+MFMA_I8_PEAK_TOPS = 5000.0  # same guide: int8 = 2x the bf16 rate per clock
+DT_NAME = {0: "f32", 1: "f16", 2: "i8", 3: "u8"}
+M_NAME = {0: "L2", 1: "dot", 2: "cosine"}
 
 
 def mfma_roofline(tm, dtype):
-    """Roofline of the batched path's dominant launch (the LAST, largest phase) from the live HIP-event timing.
+    """Roofline of the batched path from the live HIP-event timing: the dominant launch (the LAST, largest phase) and
+    the WHOLE search (every phase, compactions, re-scoring and repair launches included).
     tm.scan_kernel: 2 = f32 MFMA kernel on Float32 rows, 3 = f16/int8 kernel on the stored rows, 4 = f16 kernel on
     the scaled-f16 shadow of a Float32 corpus (selection; the kept rows are re-scored exactly)."""
     ach = tm.scan_flops / (tm.scan_ms_avg * 1e-3) / 1e12
     if tm.scan_kernel == 2:
         peak, unit, kernel = MFMA_F32_PEAK_TF, "TFLOP/s", "scan_mfma_f32_kernel (last phase)"
     elif tm.scan_kernel == 3 and dtype in (2, 3):
-        peak, unit, kernel = MFMA_I8_PEAK_TOPS, "TOP/s", "scan_mfma16_kernel<int8> (last phase)"
+        peak, unit, kernel = MFMA_I8_PEAK_TOPS, "TOP/s", "scan_mfma16 kernel <int8> (last phase)"
     else:
         peak, unit = MFMA_F16_PEAK_TF, "TFLOP/s"
-        kernel = "scan_mfma16_kernel<f16> (last phase)" + (" on the f16 shadow of the f32 rows" if tm.scan_kernel == 4 else "")
-    return {"bound": "mfma", "achieved": ach, "peak": peak, "unit": unit, "frac": ach / peak, "traffic": None,
-            "kernel": kernel, "kernel_ms_avg": tm.scan_ms_avg, "launches_timed": tm.samples,
-            "scan_launches_per_search": tm.scan_launches, "algorithmic_flops_per_launch": float(tm.scan_flops),
-            "algorithmic_bytes_per_launch": float(tm.scan_bytes)}
+        kernel = "scan_mfma16 kernel <f16> (last phase)" + (" on the f16 shadow of the f32 rows" if tm.scan_kernel == 4 else "")
+    out = {"bound": "mfma", "achieved": ach, "peak": peak, "unit": unit, "frac": ach / peak, "traffic": None,
+           "kernel": kernel, "kernel_ms_avg": tm.scan_ms_avg, "launches_timed": tm.samples,
+           "scan_launches_per_search": tm.scan_launches, "algorithmic_flops_per_launch": float(tm.scan_flops),
+           "algorithmic_bytes_per_launch": float(tm.scan_bytes)}
+    if tm.search_ms_avg > 0 and tm.search_flops:
+        whole = tm.search_flops / (tm.search_ms_avg * 1e-3) / 1e12
+        out["whole_search"] = {"device_ms_avg": tm.search_ms_avg, "achieved": whole, "unit": unit, "frac": whole / peak,
+                               "algorithmic_flops": float(tm.search_flops),
+                               "covers": "first to last kernel of the search on its stream (query prep, all phases, "
+                                         "compactions, re-scoring, repair launches)"}
+    return out
 
 
 def parse_args():
@@ -71,17 +85,29 @@ def parse_args():
     ap.add_argument("--k", type=int, default=100)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-recall", action="store_true")
-    ap.add_argument("--no-batched", action="store_true", help="skip the extra q=1024 leg of the default N=1 run")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-baseline budget")
+    ap.add_argument("--no-batched", action="store_true", help="skip the extra q=1024 legs of the default N=1 run")
+    ap.add_argument("--no-cfg5", action="store_true", help="skip the cfg5_sharded leg")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-baseline budget per leg")
     return ap.parse_args()
 
 
+def host_description():
+    model = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    aff = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    return {"cpu_model": model, "nproc": os.cpu_count() or 1, "cpus_allowed": aff}
+
+
 def cpu_baseline(args, oracle):
-    """Faithful single-thread restatement of the reference loop
-    (examples/similarity_search.rs:140-176: per-row address math, as_f32
-    alloc+decode, strict serial f32 L2 + sqrt, BinaryHeap) on a bounded
-    sample of the same corpus.  The reference computes L2 only, so the CPU
-    leg is L2 whatever --metric says; its cost per row is the same."""
+    """Faithful single-thread restatement of the reference loop (examples/similarity_search.rs:140-176: per-row
+    address math, as_f32 alloc+decode, strict serial f32 L2 + sqrt, BinaryHeap) on a bounded sample of the same corpus.
+    The reference computes L2 only, so the CPU leg is L2 whatever --metric says; its cost per row is the same."""
     if args.dtype not in (0, 1):
         return None
     chunk = 250_000
@@ -100,6 +126,29 @@ def cpu_baseline(args, oracle):
                       f"reference computes), k={args.k}, oracle faithful restatement single-threaded, {spent:.1f} s of CPU work"}
 
 
+def cpu_baseline_best_effort(args, oracle):
+    """What the host can do when it tries: OpenMP over rows on every core the box grants, no per-row allocation, the
+    requested metric -- the oracle's search (same strict-order f32 arithmetic per row as the reference).  Reported so
+    that the GPU / CPU ratio is not inflated by the reference's single thread."""
+    threads = oracle._cpu_budget()
+    chunk = 500_000
+    buf = np.empty((chunk, args.dim), oracle.NP_DTYPE[args.dtype])
+    q = oracle.synth_queries(SEED + 1, 1, args.dim, args.dtype)
+    rows_done, spent = 0, 0.0
+    while spent < args.cpu_seconds and rows_done < args.rows:
+        n = min(chunk, args.rows - rows_done)
+        rows = oracle.synth_rows(SEED, rows_done, n, args.dim, args.dtype, out=buf)
+        t0 = time.perf_counter()
+        oracle.search(rows, args.dtype, args.metric, q, args.k, index_base=rows_done)
+        spent += time.perf_counter() - t0
+        rows_done += n
+    out = {"value": rows_done / spent, "unit": "distance-ops/s", "cores": threads, "kind": "port",
+           "sample": f"first {rows_done} rows of the same synthetic corpus, dim {args.dim}, {M_NAME[args.metric]}, k={args.k}, "
+                     f"oracle search: OpenMP over rows ({threads} threads), strict-order f32 per row, {spent:.1f} s wall"}
+    out.update(host_description())
+    return out
+
+
 def oracle_topk_full(args, oracle, q):
     """Exact oracle top-k over the whole N=1 corpus, streamed in chunks (OpenMP)."""
     chunk = 250_000
@@ -115,6 +164,81 @@ def oracle_topk_full(args, oracle, q):
     return sc, idx
 
 
+def timed_steps(step, warmup, steps, world, dist, torch):
+    """W untimed steps, then exactly K steps between barrier + synchronize on both sides; max over ranks."""
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    return time.perf_counter() - t0, out
+
+
+def max_over_ranks(x, world, dist, torch, device):
+    if world == 1:
+        return x
+    t = torch.tensor([x], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def cfg5_sharded_leg(args, rank, local_rank, world, backend, dist, torch, G, ShardedSearcher, _lib):
+    """BASELINE.json configs[4] per rank: 12.5M x 1024 f16 L2, 1024 batched queries, top-100; N = 8 is the 100M-row
+    corpus north_star names.  Returns the leg's dict on rank 0 (None elsewhere)."""
+    rows, dim, dtype, metric, nq, k = 12_500_000, 1024, 1, 0, 1024, args.k
+    steps, warmup = max(3, args.steps // 5), 2
+    dev = f"cuda:{local_rank}"
+    corpus = G.GpuCorpus.synthetic(rows, dim, dtype, SEED, row0=rank * rows, device=local_rank)
+    searcher = ShardedSearcher(corpus)
+    dq = torch.empty((nq, dim), dtype=torch.float32, device=dev)
+    _lib.gpu_check(_lib.gpu().mvfgpu_synth_queries_device(dq.data_ptr(), nq, dim, dtype, SEED + 1, local_rank, None))
+    torch.cuda.synchronize()
+
+    def step():
+        return searcher.search(dq, k, metric)
+
+    for _ in range(warmup):
+        step()
+    corpus.set_profiling(True)
+    searcher.timing = True
+    elapsed, out = timed_steps(step, 0, steps, world, dist, torch)
+    tm = corpus.last_timing()
+    corpus.set_profiling(False)
+    scan_ms, exch_ms = searcher.take_timings()
+    searcher.timing = False
+    elapsed = max_over_ranks(elapsed, world, dist, torch, dev if backend == "nccl" else "cpu")
+    per_rank = [(scan_ms, exch_ms, tm.scan_ms_avg, tm.search_ms_avg)]
+    if world > 1:
+        gathered = [None] * world
+        dist.all_gather_object(gathered, per_rank[0])
+        per_rank = gathered
+    leg = None
+    if rank == 0:
+        idx = out[1].cpu().numpy().view(np.uint64)
+        leg = {"workload": f"{world} x (12.5M x 1024 f16) rows = {world * rows / 1e6:g}M x 1024 f16 L2, {nq} batched queries, "
+                           f"top-{k}, row-range sharded x{world} (BASELINE.json configs[4]{'' if world == 8 else ': its per-GPU shard at every N'})",
+               "value": float(nq) * rows * world * steps / elapsed, "unit": "distance-ops/s", "n_gpus": world, "steps": steps,
+               "warmup": warmup, "ms_per_step": elapsed / steps * 1e3, "scaling": "weak", "dtype": "f16",
+               "rccl_ranks": (dist.get_world_size() if world > 1 and backend == "nccl" else 0),
+               "process_group_backend": (dist.get_backend() if world > 1 else None),
+               "per_rank": [{"rank": r, "local_search_ms": a, "exchange_merge_ms": b, "last_phase_scan_ms": c_, "search_device_ms": d}
+                            for r, (a, b, c_, d) in enumerate(per_rank)],
+               "result_check": {"indices_in_range": bool(idx.max() < world * rows), "unique_per_query": bool(
+                   all(len(set(r.tolist())) == k for r in idx[:8]))}}
+        if tm.samples and tm.scan_ms_avg > 0 and tm.scan_kernel >= 2:
+            leg["roofline"] = mfma_roofline(tm, dtype)
+    corpus.close()
+    return leg
+
+
 def main():
     args = parse_args()
     rank = int(os.environ.get("RANK", "0"))
@@ -127,7 +251,7 @@ def main():
 
     import torch
     import torch.distributed as dist
-    from metrovector_amd import gpu as G
+    from metrovector_amd import _lib, gpu as G
     from metrovector_amd.sharded import ShardedSearcher
 
     if not torch.cuda.is_available():
@@ -136,6 +260,7 @@ def main():
     if backend != "nccl":
         local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
+    dev = f"cuda:{local_rank}"
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
@@ -151,8 +276,7 @@ def main():
     searcher = ShardedSearcher(corpus)
     qcode = G.query_dtype_code(args.dtype)
     qdt = {0: torch.float32, 2: torch.int8, 3: torch.uint8}[qcode]
-    dq = torch.empty((args.queries, args.dim), dtype=qdt, device=f"cuda:{local_rank}")
-    from metrovector_amd import _lib
+    dq = torch.empty((args.queries, args.dim), dtype=qdt, device=dev)
     _lib.gpu_check(_lib.gpu().mvfgpu_synth_queries_device(dq.data_ptr(), args.queries, args.dim, args.dtype, SEED + 1,
                                                           local_rank, None))
     torch.cuda.synchronize()
@@ -162,33 +286,21 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
     corpus.set_profiling(True)  # records HIP events around the scan kernel; never waits inside a step
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
+    searcher.timing = True
+    elapsed, out = timed_steps(step, 0, args.steps, world, dist, torch)
     tm = corpus.last_timing()
     corpus.set_profiling(False)
+    local_ms, exch_ms = searcher.take_timings()
+    searcher.timing = False
+    elapsed = max_over_ranks(elapsed, world, dist, torch, dev if backend == "nccl" else "cpu")
 
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}" if backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
+    result = None
     if rank == 0:
         total_rows = args.rows * world
         ops = float(args.queries) * total_rows * args.steps
         es = {0: 4, 1: 2, 2: 1, 3: 1}[args.dtype]
-        dtname = {0: "f32", 1: "f16", 2: "i8", 3: "u8"}[args.dtype]
-        mname = {0: "L2", 1: "dot", 2: "cosine"}[args.metric]
+        dtname, mname = DT_NAME[args.dtype], M_NAME[args.metric]
         result = {
             "metric": "distance-ops/sec",
             "value": ops / elapsed,
@@ -204,8 +316,12 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"{args.rows // 1_000_000}M x {args.dim} {dtname} {mname}, {args.queries} query, "
                                    f"top-{args.k}, per GPU (BASELINE.json configs[1] at --gpus 1)",
+                       "second_workload": None if args.no_cfg5 else
+                       "cfg5_sharded: 12.5M x 1024 f16 L2 per GPU, 1024 batched queries, top-100 (BASELINE.json configs[4])",
                        "rows_per_gpu": args.rows, "dim": args.dim, "queries": args.queries, "k": args.k,
                        "metric": mname, "sharding": f"row-range x{world}" if world > 1 else "none"},
+            "rank0_local_search_ms": local_ms, "rank0_exchange_merge_ms": exch_ms,
+            "rccl_ranks": (dist.get_world_size() if world > 1 and backend == "nccl" else 0),
         }
         # ---- roofline of the dominant kernel (rank 0's shard) ---------------------------
         alg_bytes = float(args.rows) * args.dim * es  # N*d*es per launch
@@ -216,15 +332,15 @@ def main():
             result["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                   "frac": ach / HBM_PEAK_GBS, "traffic": None,
                                   "kernel": "scan_stream_kernel", "kernel_ms_avg": tm.scan_ms_avg,
-                                  "select_ms_avg": tm.select_ms_avg, "launches_timed": tm.samples,
-                                  "algorithmic_bytes_per_launch": alg_bytes}
+                                  "select_ms_avg": tm.select_ms_avg, "search_device_ms_avg": tm.search_ms_avg,
+                                  "launches_timed": tm.samples, "algorithmic_bytes_per_launch": alg_bytes}
         # HBM bytes per launch from the PMC counters: they need their own rocprofv3 --pmc passes (FETCH_SIZE x2 for
         # wide streaming reads on gfx950 + WRITE_SIZE, MI355X_MICROARCH.md §HBM), so the figure is the committed
         # summary of those passes for this exact workload, not a live measurement.
         if "roofline" in result:
-            for name in ("r01_bench_n1_hbm_traffic.json", "r01_bench_n1_q1024_hbm_traffic.json"):
+            for name in ("r02_bench_n1_hbm_traffic.json", "r01_bench_n1_hbm_traffic.json", "r01_bench_n1_q1024_hbm_traffic.json"):
                 tp = os.path.join(ROOT, "profiles", name)
-                if not os.path.exists(tp):
+                if not os.path.exists(tp) or result["roofline"].get("traffic"):
                     continue
                 prof = json.load(open(tp))
                 w = prof.get("workload", {})
@@ -234,99 +350,123 @@ def main():
                     result["roofline"]["traffic_source"] = "profiles/" + name
         result["corpus_generation_s"] = gen_s
 
-        if world == 1:
-            from oracle import mvf_oracle as oracle
-            oracle.build()
-            q = dq.cpu().numpy()
+    if rank == 0 and world == 1:
+        from oracle import mvf_oracle as oracle
+        oracle.build()
+        q = dq.cpu().numpy()
+        # ---- the same search through the HOST-buffer entry point: query H2D + kernels + results D2H (SURVEY.md §8d's
+        # timed region); blocking per call
+        hq = q.copy()
+        for _ in range(args.warmup):
+            corpus.search(hq, args.k, args.metric)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            corpus.search(hq, args.k, args.metric)
+        eh = time.perf_counter() - t0
+        result["host_api"] = {"entry_point": "mvfgpu_search (host buffers: query H2D + search + results D2H, blocking)",
+                              "ms_per_step": eh / args.steps * 1e3, "value": float(args.queries) * args.rows * args.steps / eh,
+                              "unit": "distance-ops/s", "steps": args.steps}
+        result["host_api_ms_per_step"] = eh / args.steps * 1e3
+        if not args.no_recall:
+            t1 = time.perf_counter()
+            sel = sorted(set([0, args.queries // 3, 2 * args.queries // 3, args.queries - 1]))  # <= 4 sampled queries
+            osc, oidx = oracle_topk_full(args, oracle, q[sel])
+            gi = out[1].cpu().numpy().view(np.uint64)[sel]
+            hits = sum(len(set(a.tolist()) & set(b.tolist())) for a, b in zip(gi, oidx))
+            result["recall_at_k"] = hits / oidx.size
+            result["recall_queries_checked"] = len(sel)
+            result["recall_oracle_s"] = time.perf_counter() - t1
+        if not args.no_cpu_baseline:
+            cb = cpu_baseline(args, oracle)
+            if cb:
+                result["cpu_baseline"] = cb
+            result["cpu_baseline_best_effort"] = cpu_baseline_best_effort(args, oracle)
+        # ---- opt-in single-query path (scan path 4): K1 streams the scaled-f16 shadow of the rows (half the bytes),
+        # candidates within a proven margin are re-scored from the f32 rows -- same results, ~1.8x sooner.  Not the
+        # default: `value` above is the scan of the stored f32 rows.
+        if args.queries == 1 and args.dtype == 0 and not args.no_batched:
+            corpus.set_scan_path(4)
+            for _ in range(args.warmup):
+                step()
+            torch.cuda.synchronize()
+            corpus.set_profiling(True)
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                outs = step()
+            torch.cuda.synchronize()
+            es_ = time.perf_counter() - t0
+            tms = corpus.last_timing()
+            corpus.set_profiling(False)
+            corpus.set_scan_path(0)
+            leg = {"workload": result["config"]["workload"], "scan_path": "4 (K1 streams the f16 shadow; exact re-score)",
+                   "value": float(args.rows) * args.steps / es_, "unit": "distance-ops/s", "steps": args.steps,
+                   "ms_per_step": es_ / args.steps * 1e3}
+            if tms.samples and tms.scan_ms_avg > 0 and tms.scan_kernel == 5:
+                achs = tms.scan_bytes / (tms.scan_ms_avg * 1e-3) / 1e9
+                leg["roofline"] = {"bound": "hbm", "achieved": achs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                   "frac": achs / HBM_PEAK_GBS, "traffic": None,
+                                   "kernel": "scan_stream_kernel (f16 shadow rows x per-row scale)",
+                                   "kernel_ms_avg": tms.scan_ms_avg, "launches_timed": tms.samples,
+                                   "algorithmic_bytes_per_launch": float(tms.scan_bytes)}
             if not args.no_recall:
-                t1 = time.perf_counter()
-                sel = sorted(set([0, args.queries // 3, 2 * args.queries // 3, args.queries - 1]))  # <= 4 sampled queries
-                osc, oidx = oracle_topk_full(args, oracle, q[sel])
-                gi = out[1].cpu().numpy().view(np.uint64)[sel]
-                hits = sum(len(set(a.tolist()) & set(b.tolist())) for a, b in zip(gi, oidx))
-                result["recall_at_k"] = hits / oidx.size
-                result["recall_queries_checked"] = len(sel)
-                result["recall_oracle_s"] = time.perf_counter() - t1
-            if not args.no_cpu_baseline:
-                cb = cpu_baseline(args, oracle)
-                if cb:
-                    result["cpu_baseline"] = cb
-            # ---- opt-in single-query path (scan path 4): K1 streams the scaled-f16 shadow of the rows (half the bytes),
-            # candidates within a proven margin are re-scored from the f32 rows -- same results, ~1.8x sooner.  Not the
-            # default: `value` above is the scan of the stored f32 rows.
-            if args.queries == 1 and args.dtype == 0 and not args.no_batched:
-                corpus.set_scan_path(4)
-                for _ in range(args.warmup):
-                    step()
+                gi = outs[1].cpu().numpy().view(np.uint64)[sel]
+                leg["recall_at_k"] = sum(len(set(a.tolist()) & set(b.tolist())) for a, b in zip(gi, oidx)) / oidx.size
+            result["single_query_f16_shadow_stream"] = leg
+        # ---- the metric's second leg: the same resident corpus, 1024 batched queries (MFMA path) ----------
+        # Two ways, same results: the default (f16 MFMA kernel selecting on the scaled-f16 shadow of the rows,
+        # kept rows re-scored exactly from the f32 rows) and the exact f32 MFMA kernel on the rows themselves.
+        if args.queries == 1 and args.dtype == 0 and not args.no_batched:
+            nqb, bsteps = 1024, 5
+            dqb = torch.empty((nqb, args.dim), dtype=qdt, device=dev)
+            _lib.gpu_check(_lib.gpu().mvfgpu_synth_queries_device(dqb.data_ptr(), nqb, args.dim, args.dtype, SEED + 1,
+                                                                  local_rank, None))
+            sel = [0, nqb // 3, 2 * nqb // 3, nqb - 1]
+            oidx = None
+            if not args.no_recall:
+                osc, oidx = oracle_topk_full(args, oracle, dqb.cpu().numpy()[sel])
+            for name, path in (("batched_q1024", 0), ("batched_q1024_f32_mfma", 2)):
+                corpus.set_scan_path(path)
+                searcher.search(dqb, args.k, args.metric)  # warm-up (builds the row norms / the shadow once)
                 torch.cuda.synchronize()
                 corpus.set_profiling(True)
                 t0 = time.perf_counter()
-                for _ in range(args.steps):
-                    outs = step()
+                for _ in range(bsteps):
+                    outb = searcher.search(dqb, args.k, args.metric)
                 torch.cuda.synchronize()
-                es = time.perf_counter() - t0
-                tms = corpus.last_timing()
+                eb = time.perf_counter() - t0
+                tmb = corpus.last_timing()
                 corpus.set_profiling(False)
-                corpus.set_scan_path(0)
-                leg = {"workload": result["config"]["workload"], "scan_path": "4 (K1 streams the f16 shadow; exact re-score)",
-                       "value": float(args.rows) * args.steps / es, "unit": "distance-ops/s", "steps": args.steps,
-                       "ms_per_step": es / args.steps * 1e3}
-                if tms.samples and tms.scan_ms_avg > 0 and tms.scan_kernel == 5:
-                    achs = tms.scan_bytes / (tms.scan_ms_avg * 1e-3) / 1e9
-                    leg["roofline"] = {"bound": "hbm", "achieved": achs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                       "frac": achs / HBM_PEAK_GBS, "traffic": None,
-                                       "kernel": "scan_stream_kernel (f16 shadow rows x per-row scale)",
-                                       "kernel_ms_avg": tms.scan_ms_avg, "launches_timed": tms.samples,
-                                       "algorithmic_bytes_per_launch": float(tms.scan_bytes)}
-                if not args.no_recall:
-                    gi = outs[1].cpu().numpy().view(np.uint64)[sel]
+                leg = {"workload": f"{args.rows // 1_000_000}M x {args.dim} {dtname} {mname}, {nqb} batched queries, top-{args.k}",
+                       "scan_path": "automatic" if path == 0 else "2 (exact f32 MFMA on the stored rows)",
+                       "value": float(nqb) * args.rows * bsteps / eb, "unit": "distance-ops/s", "steps": bsteps,
+                       "ms_per_step": eb / bsteps * 1e3}
+                if tmb.samples and tmb.scan_ms_avg > 0 and tmb.scan_kernel >= 2:
+                    leg["roofline"] = mfma_roofline(tmb, args.dtype)
+                    # HBM bytes per launch from the committed PMC passes of this exact workload and kernel
+                    tp = os.path.join(ROOT, "profiles", {2: "r01_bench_n1_q1024_hbm_traffic.json",
+                                                         4: "r01_bench_n1_q1024_shadow_hbm_traffic.json"}.get(tmb.scan_kernel, "-"))
+                    if os.path.exists(tp):
+                        leg["roofline"]["traffic"] = json.load(open(tp))["roofline_traffic_bytes_per_launch"]
+                        leg["roofline"]["traffic_source"] = "profiles/" + os.path.basename(tp)
+                if oidx is not None:
+                    gi = outb[1].cpu().numpy().view(np.uint64)[sel]
                     leg["recall_at_k"] = sum(len(set(a.tolist()) & set(b.tolist())) for a, b in zip(gi, oidx)) / oidx.size
-                result["single_query_f16_shadow_stream"] = leg
-            # ---- the metric's second leg: the same resident corpus, 1024 batched queries (MFMA path) ----------
-            # Two ways, same results: the default (f16 MFMA kernel selecting on the scaled-f16 shadow of the rows,
-            # kept rows re-scored exactly from the f32 rows) and the exact f32 MFMA kernel on the rows themselves.
-            if args.queries == 1 and args.dtype == 0 and not args.no_batched:
-                nqb, bsteps = 1024, 5
-                dqb = torch.empty((nqb, args.dim), dtype=qdt, device=f"cuda:{local_rank}")
-                _lib.gpu_check(_lib.gpu().mvfgpu_synth_queries_device(dqb.data_ptr(), nqb, args.dim, args.dtype, SEED + 1,
-                                                                      local_rank, None))
-                sel = [0, nqb // 3, 2 * nqb // 3, nqb - 1]
-                oidx = None
-                if not args.no_recall:
-                    osc, oidx = oracle_topk_full(args, oracle, dqb.cpu().numpy()[sel])
-                for name, path in (("batched_q1024", 0), ("batched_q1024_f32_mfma", 2)):
-                    corpus.set_scan_path(path)
-                    searcher.search(dqb, args.k, args.metric)  # warm-up (builds the row norms / the shadow once)
-                    torch.cuda.synchronize()
-                    corpus.set_profiling(True)
-                    t0 = time.perf_counter()
-                    for _ in range(bsteps):
-                        outb = searcher.search(dqb, args.k, args.metric)
-                    torch.cuda.synchronize()
-                    eb = time.perf_counter() - t0
-                    tmb = corpus.last_timing()
-                    corpus.set_profiling(False)
-                    leg = {"workload": f"{args.rows // 1_000_000}M x {args.dim} {dtname} {mname}, {nqb} batched queries, top-{args.k}",
-                           "scan_path": "automatic" if path == 0 else "2 (exact f32 MFMA on the stored rows)",
-                           "value": float(nqb) * args.rows * bsteps / eb, "unit": "distance-ops/s", "steps": bsteps,
-                           "ms_per_step": eb / bsteps * 1e3}
-                    if tmb.samples and tmb.scan_ms_avg > 0 and tmb.scan_kernel >= 2:
-                        leg["roofline"] = mfma_roofline(tmb, args.dtype)
-                        # HBM bytes per launch from the committed PMC passes of this exact workload and kernel
-                        tp = os.path.join(ROOT, "profiles", {2: "r01_bench_n1_q1024_hbm_traffic.json",
-                                                             4: "r01_bench_n1_q1024_shadow_hbm_traffic.json"}.get(tmb.scan_kernel, "-"))
-                        if os.path.exists(tp):
-                            leg["roofline"]["traffic"] = json.load(open(tp))["roofline_traffic_bytes_per_launch"]
-                            leg["roofline"]["traffic_source"] = "profiles/" + os.path.basename(tp)
-                    if oidx is not None:
-                        gi = outb[1].cpu().numpy().view(np.uint64)[sel]
-                        leg["recall_at_k"] = sum(len(set(a.tolist()) & set(b.tolist())) for a, b in zip(gi, oidx)) / oidx.size
-                        leg["recall_queries_checked"] = len(sel)
-                    result[name] = leg
-                corpus.set_scan_path(0)
-        print(json.dumps(result), flush=True)
+                    leg["recall_queries_checked"] = len(sel)
+                result[name] = leg
+            corpus.set_scan_path(0)
 
     corpus.close()
+    del searcher
+    torch.cuda.empty_cache()
+
+    # ---- second workload, every N: BASELINE.json configs[4] per rank ----------------------------------------------
+    if not args.no_cfg5:
+        leg = cfg5_sharded_leg(args, rank, local_rank, world, backend, dist, torch, G, ShardedSearcher, _lib)
+        if rank == 0:
+            result["cfg5_sharded"] = leg
+
+    if rank == 0:
+        print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -84,6 +84,11 @@ typedef struct mvfgpu_timing {
     uint32_t scan_launches; /* scan launches of one search (timing covers the first) */
     uint64_t scan_bytes; /* algorithmic bytes one scan launch reads */
     uint64_t scan_flops; /* algorithmic flops of one scan launch (2*nq*rows*dim) */
+    /* the WHOLE search on the device: first to last kernel of the call on its stream (query preparation, every scan
+     * phase, compactions, re-scoring, the repair launches) */
+    float search_ms;      /* newest search */
+    float search_ms_avg;  /* mean over the profiled searches */
+    uint64_t search_flops; /* 2 * nq * rows * dim of the whole search */
 } mvfgpu_timing;
 
 /* ---- library / device ---------------------------------------------------- */
@@ -127,13 +132,15 @@ int mvfgpu_corpus_create(const void* rows, uint64_t n, uint32_t dimension,
 typedef struct mvfgpu_upload_options {
     uint32_t struct_size; /* sizeof(mvfgpu_upload_options): lets the struct grow */
     uint32_t flags;       /* MVFGPU_UPLOAD_* */
-    uint32_t chunk_mib;   /* chunk size in MiB, 0 = 256 */
+    uint32_t chunk_mib;   /* chunk size in MiB, 0 = default (64 with pinned staging, else 256) */
     uint32_t reserved;
 } mvfgpu_upload_options;
 #define MVFGPU_UPLOAD_EAGER_NORMS 1u    /* row norms (K4) per chunk, beside the copy of the next */
 #define MVFGPU_UPLOAD_EAGER_SHADOW 2u   /* Float32 spaces: norms + the f16 shadow per chunk */
-#define MVFGPU_UPLOAD_PINNED_STAGING 4u /* double-buffer through pinned host chunks filled by memcpy threads instead of
-                                           handing the pageable source to the runtime (A/B: scripts/probe_upload.py) */
+#define MVFGPU_UPLOAD_PINNED_STAGING 4u /* double-buffer through two pinned host chunks filled by memcpy threads: the default
+                                           for uploads of >= 256 MiB (50 GB/s measured against 10-21 GB/s for the
+                                           pageable source handed to the runtime); this flag forces it for small ones */
+#define MVFGPU_UPLOAD_PAGEABLE 8u       /* never stage: hand the (pageable / mmap'd) source to the runtime as it is */
 int mvfgpu_corpus_create_ex(const void* rows, uint64_t n, uint32_t dimension,
                             uint8_t data_type, uint64_t stride_bytes, int device,
                             uint64_t index_base, const mvfgpu_upload_options* options,

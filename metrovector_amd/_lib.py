@@ -30,7 +30,7 @@ class UploadOptions(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("flags", C.c_uint32), ("chunk_mib", C.c_uint32), ("reserved", C.c_uint32)]
 
 
-UPLOAD_EAGER_NORMS, UPLOAD_EAGER_SHADOW, UPLOAD_PINNED_STAGING = 1, 2, 4
+UPLOAD_EAGER_NORMS, UPLOAD_EAGER_SHADOW, UPLOAD_PINNED_STAGING, UPLOAD_PAGEABLE = 1, 2, 4, 8
 
 
 class ShardsetInfo(C.Structure):
@@ -46,7 +46,8 @@ class Timing(C.Structure):
     _fields_ = [("scan_ms", C.c_float), ("select_ms", C.c_float), ("total_ms", C.c_float),
                 ("scan_ms_avg", C.c_float), ("select_ms_avg", C.c_float), ("samples", C.c_uint32),
                 ("scan_kernel", C.c_uint32), ("scan_launches", C.c_uint32), ("scan_bytes", C.c_uint64),
-                ("scan_flops", C.c_uint64)]
+                ("scan_flops", C.c_uint64), ("search_ms", C.c_float), ("search_ms_avg", C.c_float),
+                ("search_flops", C.c_uint64)]
 
 
 def _preload_torch_hip() -> None:

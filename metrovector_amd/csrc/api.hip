@@ -110,8 +110,8 @@ struct mvfgpu_corpus {
     bool profiling = false;
     int scan_path = 0;
     struct ProfSlot {
-        hipEvent_t e[3] = {nullptr, nullptr, nullptr};
-        bool scanned = false;
+        hipEvent_t e[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // [0,1] the timed scan launch, [2] end of its select; [3,4] the whole search
+        bool scanned = false, whole = false;
     };
     static constexpr int kProfSlots = 64;
     mutable ProfSlot prof[kProfSlots];
@@ -121,22 +121,23 @@ struct mvfgpu_corpus {
 
 namespace {
 
-void choose_group(uint32_t V, int* G_out, uint32_t* J_out) {
-    // lanes per row: the widest of {64,16,4,1} whose lane utilisation is within 80 % of the best
-    const int cand[4] = {64, 16, 4, 1};
-    double best = 0;
-    for (int g : cand) {
-        uint32_t j = (V + g - 1) / g;
-        best = std::max(best, (double)V / ((double)j * g));
+// Lanes per row for K1, from the measured sweep of every data type over 64 <= dim <= 2048 at every width the kernel has
+// (profiles/r02_k1_shape_sweep.csv, scripts/sweep_k1_shapes.py) and the full-size check of the benchmark shapes
+// (profiles/r02_k1_group_full_size.txt).  V = 16-byte vectors per row.
+//   V <= 2 (rows <= 32 B): one lane per row; V <= 8 (<= 128 B): 4 lanes; up to 3 KiB rows: 16 lanes -- the widest group
+//   is NOT the fastest there (a 2-KiB Float16 row: 6.7 vs 6.3 TB/s; 768-B Int8 rows: 6.6 vs 3.9 TB/s: with 64 lanes on a
+//   short row most of the wave idles in the row's last step); 64 lanes from 3 KiB on (10M x 768 f32: 6.9 vs 6.6 TB/s).
+//   Four queries per pass (NQ = 4) carry 16 sums per lane group: 16 lanes stay ahead up to 8 KiB rows.
+// round 1 picked "the widest group within 80 % of the best lane utilisation": up to 46 % off the best width on the
+// shapes it had not been measured on (dim 100 / 200 f32, 512 f16, 384 / 1024 int8).  MVF_K1_G forces a width (sweeps).
+void choose_group(uint32_t V, int nqv, int* G_out, uint32_t* J_out) {
+    int g = V <= 2 ? 1 : V <= 8 ? 4 : (V < 192 || (nqv == 4 && V < 512)) ? 16 : 64;
+    if (const char* e = getenv("MVF_K1_G")) {
+        const int f = atoi(e);
+        if (f == 64 || f == 16 || f == 4 || f == 1) g = f;
     }
-    for (int g : cand) {
-        uint32_t j = (V + g - 1) / g;
-        if ((double)V / ((double)j * g) >= 0.8 * best) {
-            *G_out = g;
-            *J_out = j;
-            return;
-        }
-    }
+    *G_out = g;
+    *J_out = (V + g - 1) / g;
 }
 
 int init_common(mvfgpu_corpus* c) {
@@ -162,7 +163,7 @@ int validate_shape(uint64_t n, uint32_t dim, uint8_t dtype) {
 int alloc_rows(mvfgpu_corpus* c) {
     c->pitch = (c->dim * elem_size(c->dtype) + 15u) & ~15u;
     c->V = c->pitch / 16;
-    choose_group(c->V, &c->G, &c->J);
+    choose_group(c->V, 1, &c->G, &c->J);
     c->rows_bytes = (size_t)c->n * c->pitch;
     if (c->rows_bytes) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_rows), c->rows_bytes));
     return MVF_OK;
@@ -203,12 +204,8 @@ int search_stream_path(const mvfgpu_corpus* c, uint8_t metric, const void* d_que
                        float* d_scores, uint64_t* d_indices, int32_t* d_raw, hipStream_t s, bool profile = true,
                        const ShadowStream* alt = nullptr) {
     const uint32_t kcap = next_pow2(k);
-    const int G = alt ? alt->G : c->G;
-    const uint32_t J = alt ? alt->J : c->J;
     const uint8_t kdtype = alt ? (uint8_t)MVF_DTYPE_FLOAT16 : c->dtype;
-    const uint32_t chunk_rows = scan_chunk_rows(G);
-    const uint32_t nchunks = (uint32_t)((c->n + chunk_rows - 1) / chunk_rows);
-    const uint32_t pmax = next_pow2(k + chunk_rows);
+    const uint32_t kV = alt ? alt->V : c->V;
 
     mvfgpu_timing tm{};
     tm.scan_kernel = alt ? 5u : 1u;
@@ -223,11 +220,19 @@ int search_stream_path(const mvfgpu_corpus* c, uint8_t metric, const void* d_que
 
     for (uint32_t q0 = 0; q0 < nq;) {
         int nqv = (nq - q0) >= 2 && !alt ? 4 : 1;
+        int G;
+        uint32_t J;
+        choose_group(kV, nqv, &G, &J);  // the lane-group width depends on the queries per pass
+        uint32_t chunk_rows = scan_chunk_rows(G), pmax = next_pow2(k + chunk_rows);
         size_t lds = scan_lds_bytes(kdtype, G, J, nqv, pmax);
         if (nqv == 4 && lds > 150 * 1024) {
             nqv = 1;
+            choose_group(kV, nqv, &G, &J);
+            chunk_rows = scan_chunk_rows(G);
+            pmax = next_pow2(k + chunk_rows);
             lds = scan_lds_bytes(kdtype, G, J, nqv, pmax);
         }
+        const uint32_t nchunks = (uint32_t)((c->n + chunk_rows - 1) / chunk_rows);
         if (lds > 160 * 1024) return fail(MVF_ERR_BUILD, "dimension too large for the streaming kernel's LDS query tile");
         const uint32_t nq_here = std::min<uint32_t>(nqv, nq - q0);
 
@@ -414,16 +419,19 @@ int repair_flagged_queries(const mvfgpu_corpus* c, uint8_t metric, const void* d
     (void)nq_pad;
     if (c->n == 0) return MVF_OK;
     const uint32_t kcap = next_pow2(k);
-    const int G = c->G;
-    const uint32_t chunk_rows = scan_chunk_rows(G);
-    const uint32_t nchunks = (uint32_t)((c->n + chunk_rows - 1) / chunk_rows);
-    const uint32_t pmax = next_pow2(k + chunk_rows);
-    int nqv = 4;
-    size_t lds = scan_lds_bytes(c->dtype, G, c->J, nqv, pmax);
+    int nqv = 4, G;
+    uint32_t J;
+    choose_group(c->V, nqv, &G, &J);
+    uint32_t chunk_rows = scan_chunk_rows(G), pmax = next_pow2(k + chunk_rows);
+    size_t lds = scan_lds_bytes(c->dtype, G, J, nqv, pmax);
     if (lds > 150 * 1024) {
         nqv = 1;
-        lds = scan_lds_bytes(c->dtype, G, c->J, nqv, pmax);
+        choose_group(c->V, nqv, &G, &J);
+        chunk_rows = scan_chunk_rows(G);
+        pmax = next_pow2(k + chunk_rows);
+        lds = scan_lds_bytes(c->dtype, G, J, nqv, pmax);
     }
+    const uint32_t nchunks = (uint32_t)((c->n + chunk_rows - 1) / chunk_rows);
     if (lds > 160 * 1024) return fail(MVF_ERR_BUILD, "dimension too large for the streaming kernel's LDS query tile");
     const void* kfn = scan_kernel(c->dtype, metric, G, nqv, /*redo=*/true);
     if (lds > 48 * 1024) HIP_TRY(hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -448,7 +456,7 @@ int repair_flagged_queries(const mvfgpu_corpus* c, uint8_t metric, const void* d
         sp.pitch = c->pitch;
         sp.dim = c->dim;
         sp.V = c->V;
-        sp.J = c->J;
+        sp.J = J;
         sp.q0 = 0;
         sp.nq_total = nq;
         sp.k = k;
@@ -733,7 +741,7 @@ int search_stream_shadow_path(const mvfgpu_corpus* c, uint8_t metric, const void
     alt.xscale = static_cast<const float*>(c->xscale.p);
     alt.pitch = shadow_pitch(c->dim);
     alt.V = alt.pitch / 16;
-    choose_group(alt.V, &alt.G, &alt.J);
+    choose_group(alt.V, 1, &alt.G, &alt.J);
     alt.cand = static_cast<uint64_t*>(c->bcand.p);
     alt.cnt = cnt;
     alt.cand_cap = cap;
@@ -871,8 +879,12 @@ int upload_rows(mvfgpu_corpus* c, const void* rows, uint64_t stride, const mvfgp
     const uint64_t n = c->n, row_bytes = (uint64_t)c->dim * elem_size(c->dtype);
     const bool direct = stride == row_bytes && row_bytes == c->pitch;
     const bool sparse = !direct && stride > 2 * row_bytes;  // 2-D copies: do not move the gaps
-    const bool pinned = (o.flags & MVFGPU_UPLOAD_PINNED_STAGING) != 0 && !sparse;
-    const uint64_t chunk_bytes = (uint64_t)(o.chunk_mib ? o.chunk_mib : 256u) << 20;
+    // pinned double-buffered staging is the default for uploads of 256 MiB and more (measured, 30.72 GB of pageable rows,
+    // profiles/r02_upload_pipeline.txt: 50 GB/s against 10-21 GB/s handing the pageable source to the runtime)
+    const uint64_t total_span = (n - 1) * stride + row_bytes;
+    const bool pinned = !sparse && ((o.flags & MVFGPU_UPLOAD_PINNED_STAGING) != 0 ||
+                                    ((o.flags & MVFGPU_UPLOAD_PAGEABLE) == 0 && total_span >= ((uint64_t)256 << 20)));
+    const uint64_t chunk_bytes = (uint64_t)(o.chunk_mib ? o.chunk_mib : (pinned ? 64u : 256u)) << 20;
     const uint64_t chunk_rows = std::max<uint64_t>(1, chunk_bytes / stride);
     const unsigned char* src = static_cast<const unsigned char*>(rows);
     HIP_TRY(hipStreamCreateWithFlags(&c->up_stream, hipStreamNonBlocking));
@@ -910,7 +922,8 @@ int upload_rows(mvfgpu_corpus* c, const void* rows, uint64_t stride, const mvfgp
     if (pinned)
         for (auto& q : pin.p) HIP_TRY(hipHostMalloc(&q, span_max, hipHostMallocDefault));
     if (sparse && c->pitch != row_bytes) HIP_TRY(hipMemsetAsync(c->d_rows, 0, c->rows_bytes, s_copy));  // the 16-B padding
-    const unsigned threads = std::min(8u, std::max(1u, std::thread::hardware_concurrency()));
+    unsigned threads = std::min(8u, std::max(1u, std::thread::hardware_concurrency()));
+    if (const char* e = getenv("MVF_UPLOAD_THREADS")) threads = (unsigned)std::max(1, atoi(e));
 
     uint64_t i = 0;
     for (uint64_t r0 = 0; r0 < n; r0 += chunk_rows, i++) {
@@ -1273,6 +1286,15 @@ int mvfgpu_search_device(const mvfgpu_corpus* c, uint8_t metric, const void* d_q
     std::lock_guard<std::mutex> lk(c->mu);
     // the scratch buffers are stream-ordered: a call on another stream waits for the previous one
     if (c->has_done && c->last_stream != s) HIP_TRY(hipStreamWaitEvent(s, c->ev_done, 0));
+    mvfgpu_corpus::ProfSlot* wps = nullptr;  // whole-search events: every kernel of this call on the stream
+    const uint64_t prof_before = c->prof_next;
+    if (c->profiling) {
+        wps = &c->prof[c->prof_next % mvfgpu_corpus::kProfSlots];
+        for (auto& e : wps->e)
+            if (!e) HIP_TRY(hipEventCreate(&e));
+        wps->whole = false;
+        HIP_TRY(hipEventRecord(wps->e[3], s));
+    }
     bool shadow_stream = false;
     if (stream_shadow_wanted(c, nq)) {
         hipError_t e = ensure_shadow(c, s, c->scan_path == 4);
@@ -1283,6 +1305,11 @@ int mvfgpu_search_device(const mvfgpu_corpus* c, uint8_t metric, const void* d_q
          : use_batched_path(c, metric, nq) ? search_batched_path(c, metric, d_queries, nq, k, d_scores, d_indices, d_raw, s)
                                            : search_stream_path(c, metric, d_queries, nq, k, d_scores, d_indices, d_raw, s);
     if (rc != MVF_OK) return rc;
+    if (wps && c->prof_next == prof_before + 1) {  // the path filled this slot
+        HIP_TRY(hipEventRecord(wps->e[4], s));
+        wps->whole = true;
+        c->timing.search_flops = 2ull * nq * c->n * c->dim;
+    }
     HIP_TRY(hipEventRecord(c->ev_done, s));
     c->has_done = true;
     c->last_stream = s;
@@ -1451,20 +1478,26 @@ int mvfgpu_last_timing(const mvfgpu_corpus* c, mvfgpu_timing* out) {
         DeviceGuard guard(c->device);
         const uint64_t newest = c->prof_next - 1;
         const uint64_t oldest = c->prof_next > mvfgpu_corpus::kProfSlots ? c->prof_next - mvfgpu_corpus::kProfSlots : 0;
-        double ssum = 0, lsum = 0;
-        uint32_t cnt = 0;
+        double ssum = 0, lsum = 0, wsum = 0;
+        uint32_t cnt = 0, wcnt = 0;
         for (uint64_t i = newest + 1; i-- > oldest;) {
             const auto& ps = c->prof[i % mvfgpu_corpus::kProfSlots];
-            HIP_TRY(hipEventSynchronize(ps.e[2]));
-            float a = 0, b = 0;
+            HIP_TRY(hipEventSynchronize(ps.whole ? ps.e[4] : ps.e[2]));
+            float a = 0, b = 0, w = 0;
             if (ps.scanned) {
                 HIP_TRY(hipEventElapsedTime(&a, ps.e[0], ps.e[1]));
                 HIP_TRY(hipEventElapsedTime(&b, ps.e[1], ps.e[2]));
+            }
+            if (ps.whole) {
+                HIP_TRY(hipEventElapsedTime(&w, ps.e[3], ps.e[4]));
+                wsum += w;
+                wcnt++;
             }
             if (i == newest) {
                 tm.scan_ms = a;
                 tm.select_ms = b;
                 tm.total_ms = a + b;
+                tm.search_ms = w;
             }
             ssum += a;
             lsum += b;
@@ -1473,6 +1506,7 @@ int mvfgpu_last_timing(const mvfgpu_corpus* c, mvfgpu_timing* out) {
         tm.samples = cnt;
         tm.scan_ms_avg = cnt ? (float)(ssum / cnt) : 0.f;
         tm.select_ms_avg = cnt ? (float)(lsum / cnt) : 0.f;
+        tm.search_ms_avg = wcnt ? (float)(wsum / wcnt) : 0.f;
     }
     *out = tm;
     return MVF_OK;

@@ -52,13 +52,15 @@ class GpuCorpus:
     # ---- construction ------------------------------------------------------
     @classmethod
     def from_pointer(cls, ptr: int, rows: int, dimension: int, data_type: int, stride_bytes: int,
-                     device: int = 0, index_base: int = 0, prepare_batched: bool = False, pinned_staging: bool = False,
+                     device: int = 0, index_base: int = 0, prepare_batched: bool = False, pinned_staging: bool | None = None,
                      chunk_mib: int = 0) -> "GpuCorpus":
         """What a Rust caller passes: VectorSlice::as_ptr / stride / count
         (src/vectors/mem.rs:75-77, vector_space.rs:155-188).  `prepare_batched` builds the row norms and (Float32
         spaces) the f16 shadow chunk by chunk beside the copy (`mvfgpu_corpus_create_ex`)."""
         h = C.c_void_p()
-        flags = (_lib.UPLOAD_EAGER_SHADOW if prepare_batched else 0) | (_lib.UPLOAD_PINNED_STAGING if pinned_staging else 0)
+        flags = _lib.UPLOAD_EAGER_SHADOW if prepare_batched else 0
+        if pinned_staging is not None:  # None: the library's choice (pinned staging from 256 MiB up)
+            flags |= _lib.UPLOAD_PINNED_STAGING if pinned_staging else _lib.UPLOAD_PAGEABLE
         opts = _lib.UploadOptions(C.sizeof(_lib.UploadOptions), flags, chunk_mib, 0)
         _lib.gpu_check(_lib.gpu().mvfgpu_corpus_create_ex(C.c_void_p(ptr), rows, dimension, data_type, stride_bytes,
                                                           device, index_base, C.byref(opts), C.byref(h)))

@@ -64,6 +64,8 @@ class ShardedSearcher:
         self.dim = inf.dimension
         self.device = torch.device("cuda", inf.device)
         self._bufs = {}
+        self.timing = False  # record CUDA events around the local search and the exchange step (bench.py)
+        self._ev = []
 
     def _buffers(self, nq: int, k: int, world: int):
         import torch
@@ -92,9 +94,17 @@ class ShardedSearcher:
         nq = d_queries.shape[0]
         b = self._buffers(nq, k, world)
         stream = torch.cuda.current_stream(self.device).cuda_stream
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)] if self.timing else None
+        if ev:
+            ev[0].record()
         self.corpus.search_device(d_queries.data_ptr(), query_dtype_code(self.dtype), d_queries.shape[1], nq, k, metric,
                                   b["s"].data_ptr(), b["i"].data_ptr(), b["r"].data_ptr(), stream)
+        if ev:
+            ev[1].record()
         if world == 1 and not (self.always_exchange and dist.is_initialized()):
+            if ev:
+                ev[2].record()
+                self._ev.append(ev)
             return b["s"], b["i"], b["r"]
         if dist.get_backend(self.group) == "gloo":
             # rehearsal only (several ranks sharing one GPU, where RCCL refuses duplicate devices):
@@ -107,7 +117,22 @@ class ShardedSearcher:
         _lib.gpu_check(_lib.gpu().mvfgpu_merge_topk_packed_device(
             b["all"].data_ptr(), world, nq, k, metric, self.dtype,
             b["os"].data_ptr(), b["oi"].data_ptr(), b["orr"].data_ptr(), self.device.index or 0, C.c_void_p(stream)))
+        if ev:
+            ev[2].record()
+            self._ev.append(ev)
         return b["os"], b["oi"], b["orr"]
+
+    def take_timings(self):
+        """(mean local-search ms, mean exchange+merge ms) over the searches since timing was switched on; device
+        time between events on torch's current stream.  Synchronises."""
+        import torch
+        torch.cuda.synchronize(self.device)
+        evs, self._ev = self._ev, []
+        if not evs:
+            return 0.0, 0.0
+        a = sum(e[0].elapsed_time(e[1]) for e in evs) / len(evs)
+        b = sum(e[1].elapsed_time(e[2]) for e in evs) / len(evs)
+        return a, b
 
 
 def sharded_search_host(local_search: Callable[[], SearchResult], metric: int, data_type: int, group=None) -> SearchResult:

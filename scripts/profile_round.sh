@@ -1,0 +1,31 @@
+#!/bin/bash
+# Collect the round's bench line and rocprofv3 summaries on the GPU box (run through gpurun from the repo root):
+#   bash scripts/profile_round.sh r02
+# Writes everything under gpurun_out/prof_$1/ ; copy the summaries you want judged into profiles/.
+# The profiled program goes directly after `--` (python3 ...): no wrapper, no exec hop behind the profiler.
+set -o pipefail
+R=${1:-r02}
+O=gpurun_out/prof_$R
+mkdir -p $O
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
+S=scripts/rocprof_summarize.py
+echo "== bench (unprofiled)"; timeout -k 10 900 python3 bench.py > $O/${R}_bench_n1.json 2> $O/bench.err || { tail -5 $O/bench.err; exit 1; }
+echo "== kernel trace of the default bench"
+timeout -k 10 900 rocprofv3 --kernel-trace --output-format csv -d $O/kt_bench -- python3 bench.py --no-cpu-baseline --no-recall > $O/kt_bench.log 2>&1 || { tail -5 $O/kt_bench.log; exit 1; }
+python3 $S stats $O/kt_bench $O/${R}_bench_n1_kernel_stats.csv "rocprofv3 --kernel-trace -- python3 bench.py --no-cpu-baseline --no-recall (q=1 leg 5+50 searches, host-API leg 5+50, f16-shadow stream leg 5+50, two batched legs 1+5 each, cfg5 shard leg 2+10); durations in us"
+python3 $S launches $O/kt_bench $O/${R}_cfg3_shadow_q1024_scan_launches.csv "scan_mfma16" "per-launch durations of the f16 K2 kernels in the default bench run: the cfg3 shadow leg (10M x 768 f32 cosine, 1024 queries; XS = true instantiations) and the cfg5 shard leg (12.5M x 1024 f16 L2)"
+rm -rf $O/kt_bench
+echo "== PMC passes for the single-query scan (FETCH_SIZE, WRITE_SIZE: separate runs)"
+for c in FETCH_SIZE WRITE_SIZE; do
+  timeout -k 10 600 rocprofv3 --pmc $c --output-format csv -d $O/pmc_$c -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-recall --no-batched --no-cfg5 > $O/pmc_$c.log 2>&1 || { tail -5 $O/pmc_$c.log; exit 1; }
+done
+python3 $S traffic $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE $O/${R}_bench_n1_hbm_traffic.json 10000000 768 0 2 1 100 "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, no tracing), python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-recall --no-batched --no-cfg5, MI355X, round ${R#r}"
+for c in FETCH_SIZE WRITE_SIZE; do f=$(find $O/pmc_$c -name '*counter_collection.csv' | head -1); grep -E "Correlation_Id|scan_stream_kernel|select_final" "$f" | head -40 > $O/${R}_bench_n1_pmc_$(echo $c | tr A-Z a-z).csv; rm -rf $O/pmc_$c; done
+echo "== cfg4 / cfg5 kernel traces"
+for cfg in cfg4 cfg5; do
+  timeout -k 10 400 rocprofv3 --kernel-trace --output-format csv -d $O/kt_$cfg -- python3 scripts/probe_k2_ab.py $cfg 1 > $O/kt_$cfg.log 2>&1 || { tail -5 $O/kt_$cfg.log; exit 1; }
+  python3 $S launches $O/kt_$cfg $O/${R}_${cfg}_scan_launches.csv "scan_mfma16" "rocprofv3 --kernel-trace -- python3 scripts/probe_k2_ab.py $cfg 1: every K2 launch of 2 x 3 searches per variant (lockstep = scan_mfma16_dma_kernel, pingpong = scan_mfma16_pp_kernel), interleaved in one process"
+  python3 $S stats $O/kt_$cfg $O/${R}_${cfg}_kernel_stats.csv "same run: per-kernel totals"
+  rm -rf $O/kt_$cfg
+done
+ls -la $O
