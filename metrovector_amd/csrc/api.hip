@@ -327,9 +327,14 @@ bool k2_pp_wanted(uint8_t kdtype, uint32_t ntiles, uint32_t mtiles, int num_cus)
     return kdtype == MVF_DTYPE_FLOAT16 && (uint64_t)ntiles * mtiles >= 8ull * (uint64_t)num_cus;
 }
 
-uint32_t k2_growth_cap() {  // largest phase-to-phase growth of the K2 scan (MVF_K2_GROWTH overrides, for A/B runs)
+// Largest phase-to-phase growth of the K2 scan (MVF_K2_GROWTH overrides, for A/B runs).  A phase lets through
+// ~k (g - 1) candidates per query (its threshold is the k-th best of 1/g of the rows it sees); with 1024 queries that is
+// several per 256 x 256 tile at g = 8, and every candidate sends its wave through the epilogue's second stage.  g = 4
+// costs one or two more (small) launches and measured 2-3 % faster on cfg3 / cfg5 / cfg4 (profiles/r02_k2_ab.txt); g = 16
+// and 32 were 4 % slower in round 1.
+uint32_t k2_growth_cap() {
     if (const char* e = getenv("MVF_K2_GROWTH")) return (uint32_t)std::max(2, atoi(e));
-    return 8u;
+    return 4u;
 }
 
 bool k2_dma_persistent(uint8_t) {  // measured: int8 15 % and f16 5 % faster with one persistent block per CU

@@ -25,7 +25,12 @@ CFGS = {
     "cfg4z": (50_000_000, 768, 2, 1, 256),
     "cfg5b": (12_500_000, 1024, 1, 0, 1024),  # bf16-compatible f16 bit patterns (MVF_DIAG_BF16 builds)
 }
-VARIANTS = [("lockstep", {"MVF_K2_PP": "0"}), ("pingpong", {"MVF_K2_PP": "1"})]
+ALL_VARIANTS = {"lockstep": {"MVF_K2_PP": "0", "MVF_K2_GROWTH": "8"}, "pingpong": {"MVF_K2_PP": "1", "MVF_K2_GROWTH": "8"},
+                "default": {"MVF_K2_PP": None, "MVF_K2_GROWTH": None},
+                "pp_g4": {"MVF_K2_PP": "1", "MVF_K2_GROWTH": "4"}, "pp_g3": {"MVF_K2_PP": "1", "MVF_K2_GROWTH": "3"},
+                "pp_g16": {"MVF_K2_PP": "1", "MVF_K2_GROWTH": "16"},
+                "ls_g4": {"MVF_K2_PP": "0", "MVF_K2_GROWTH": "4"}, "ls_g3": {"MVF_K2_PP": "0", "MVF_K2_GROWTH": "3"}}
+VARIANTS = [(v, ALL_VARIANTS[v]) for v in (sys.argv[3].split(",") if len(sys.argv) > 3 else ["lockstep", "pingpong"])]
 
 
 def main():
@@ -68,7 +73,11 @@ def main():
         res = {v: [] for v, _ in VARIANTS}
         for rnd in range(rounds + 1):  # round 0 = warm-up (norms, shadow, scratch)
             for vname, env in VARIANTS:
-                os.environ.update(env)
+                for ek, ev in env.items():
+                    if ev is None:
+                        os.environ.pop(ek, None)
+                    else:
+                        os.environ[ek] = ev
                 c.set_profiling(True)
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
