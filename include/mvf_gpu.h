@@ -80,7 +80,8 @@ typedef struct mvfgpu_timing {
     uint32_t samples;    /* searches averaged */
     uint32_t scan_kernel; /* 1 = streaming (K1) on the stored rows, 5 = K1 on the f16 shadow of a Float32
                              corpus (scan path 4); MFMA batched (K2): 2 = f32 kernel on Float32 rows,
-                             3 = f16/int8 kernel on the stored rows, 4 = f16 kernel on the f16 shadow */
+                             3 = f16/int8 kernel on the stored rows, 4 = f16 kernel on the f16 shadow,
+                             6 = int8 kernel on the int8 shadow of a Float32 / Float16 corpus (scan path 5) */
     uint32_t scan_launches; /* scan launches of one search (timing covers the first) */
     uint64_t scan_bytes; /* algorithmic bytes one scan launch reads */
     uint64_t scan_flops; /* algorithmic flops of one scan launch (2*nq*rows*dim) */
@@ -324,9 +325,17 @@ int mvfgpu_last_timing(const mvfgpu_corpus* corpus, mvfgpu_timing* out);
  * the other types), 4 = as 0, but one or two queries on a Float32 corpus
  * STREAM THE F16 SHADOW instead of the stored rows (half the bytes, so about
  * half the time; same proven-margin selection and exact re-scoring as the
- * batched path, hence the same results; synchronous; also enabled by
+ * batched path, hence the same results; also enabled by
  * MVF_STREAM_SHADOW=1 in the environment).  Off by default: the default
- * single-query path reads the stored f32 rows and returns asynchronously.
+ * single-query path reads the stored f32 rows.
+ * 5 = K2 selecting on an INT8 SHADOW of a Float32 / Float16 corpus (per-row
+ * scale; built on first use, `dimension` bytes per row; also enabled by
+ * MVF_I8_SHADOW=1): the int8 MFMA runs at about twice the f16 kernel's rate
+ * under the part's power limit; every row whose approximate score is within a
+ * PROVEN bound of the k-th best (5-8 x k rows per query on uniform data; the
+ * f16 shadow keeps a handful) is re-scored from the stored rows and the f32
+ * query, so results are again those of the exact path.  Same as 0 on Int8 /
+ * UInt8 corpora.
  *
  * The f16 shadow: batched searches on a Float32 corpus select candidates with
  * the f16 MFMA kernel on a scaled-f16 copy of the rows (built on the first

@@ -98,6 +98,8 @@ struct mvfgpu_corpus {
     std::vector<uint64_t> h_ids;          // host copy of the ids ...
     mutable std::vector<std::pair<uint64_t, uint32_t>> id_index;  // ... and, built by the first gather, (id, row) sorted by id
     mutable int shadow_state = 0;         // 0 not built yet, 1 ready, -1 unavailable (no memory)
+    mutable DevBuf shadow8, xscale8, qs_stats;  // Float32 / Float16 corpora: int8 shadow rows, s_r per row, the 4 bound maxima
+    mutable int shadow8_state = 0;
     mutable bool xnorm_ready = false;
     mutable uint32_t bstate_slots = 0;    // queries the K2 state arrays are armed for
     mutable DevBuf h_q, h_s, h_i, h_r;    // device mirrors for the host-buffer API
@@ -376,6 +378,47 @@ hipError_t ensure_shadow(const mvfgpu_corpus* c, hipStream_t s, bool insist) {
     return e;
 }
 
+// ---- int8 shadow of a Float32 / Float16 corpus (selection only; shadow_i8.hip) --------------------------------------
+uint32_t shadow8_pitch(uint32_t dim) { return (dim + 15u) & ~15u; }
+constexpr uint32_t kBatchCapQS = 8192;  // candidate slots per query with int8 selection (5-8 x k rows ride in the margin)
+
+// scan path 5, or MVF_I8_SHADOW=1 with the automatic path: batched searches on Float32 / Float16 rows select on the int8
+// shadow (twice the MFMA rate of the f16 kernel under the same power limit; a 15 x wider proven margin)
+bool qs_wanted(const mvfgpu_corpus* c) {
+    if (is_int_dtype(c->dtype) || c->n == 0) return false;
+    if ((size_t)((c->dim + 7u) & ~7u) * 4 + kBatchCapQS * 4 > 64 * 1024) return false;  // re-scoring: query + candidates in LDS
+    if (c->scan_path == 5) return true;
+    const char* e = getenv("MVF_I8_SHADOW");
+    return c->scan_path == 0 && e && atoi(e) != 0;
+}
+
+hipError_t ensure_shadow8(const mvfgpu_corpus* c, hipStream_t s, bool insist) {
+    if (c->shadow8_state == -1 && insist) c->shadow8_state = 0;
+    if (c->shadow8_state != 0) return hipSuccess;
+    const size_t need = (size_t)std::max<uint64_t>(c->n, 1) * shadow8_pitch(c->dim);
+    if (!insist) {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < need + ((size_t)2 << 30)) {
+            c->shadow8_state = -1;
+            return hipSuccess;
+        }
+    }
+    if (c->shadow8.reserve(need) != hipSuccess || c->xscale8.reserve(((size_t)std::max<uint64_t>(c->n, 1) + 256) * 4) != hipSuccess ||
+        c->qs_stats.reserve(16) != hipSuccess) {
+        (void)hipGetLastError();
+        c->shadow8.release();
+        c->xscale8.release();
+        c->shadow8_state = -1;
+        return hipSuccess;
+    }
+    hipError_t e = hipMemsetAsync(c->qs_stats.p, 0, 16, s);
+    if (e == hipSuccess)
+        e = launch_shadow_i8(c->d_rows, c->dtype, (uint32_t)c->n, c->pitch, c->dim, static_cast<unsigned char*>(c->shadow8.p),
+                             shadow8_pitch(c->dim), static_cast<float*>(c->xscale8.p), static_cast<float*>(c->qs_stats.p), s);
+    if (e == hipSuccess) c->shadow8_state = 1;
+    return e;
+}
+
 // K2 per-query state (threshold key, candidate count, overflow flag), armed once and re-armed by the kernels that end
 // a search.
 int ensure_bstate(const mvfgpu_corpus* c, uint32_t nq_pad, hipStream_t s) {
@@ -511,16 +554,24 @@ int search_batched_path(const mvfgpu_corpus* c, uint8_t metric, const void* d_qu
     // Float32 rows: either the exact f32 MFMA kernel on the rows themselves, or -- 4x faster -- the f16 kernel on a
     // scaled-f16 SHADOW copy that only selects candidates (error bound below); the kept rows are re-scored from the
     // f32 rows and the f32 query either way, so results do not depend on which one ran.
-    bool use_shadow = false;
+    bool use_shadow = false, use_qs = false;
     const bool rescore_fits = (size_t)((c->dim + 7u) & ~7u) * 4 + kBatchCap * 4 <= 64 * 1024;  // query + candidates in LDS
-    if (c->dtype == MVF_DTYPE_FLOAT32 && c->scan_path != 2 && (c->scan_path == 3 || shadow_enabled()) && rescore_fits) {
+    if (qs_wanted(c)) {  // int8 shadow: selection at the int8 MFMA rate (Float32 and Float16 corpora)
+        int rc = ensure_norms(c, s);
+        if (rc != MVF_OK) return rc;
+        HIP_TRY(ensure_shadow8(c, s, c->scan_path == 5));
+        use_qs = c->shadow8_state == 1;
+    }
+    if (!use_qs && c->dtype == MVF_DTYPE_FLOAT32 && c->scan_path != 2 && (c->scan_path == 3 || shadow_enabled()) && rescore_fits) {
         HIP_TRY(ensure_shadow(c, s, c->scan_path == 3));
         use_shadow = c->shadow_state == 1;
     }
-    const bool wide = c->dtype == MVF_DTYPE_FLOAT32 && !use_shadow;  // f32 rows: 128x128x32-float tiles
-    const uint8_t kdtype = use_shadow ? (uint8_t)MVF_DTYPE_FLOAT16 : c->dtype;  // element type the scan kernel reads
-    const unsigned char* krows = use_shadow ? static_cast<const unsigned char*>(c->shadow.p) : c->d_rows;
-    const uint32_t kpitch = use_shadow ? shadow_pitch(c->dim) : c->pitch;
+    const bool wide = c->dtype == MVF_DTYPE_FLOAT32 && !use_shadow && !use_qs;  // f32 rows: 128x128x32-float tiles
+    const uint8_t kdtype = use_qs ? (uint8_t)MVF_DTYPE_INT8 : use_shadow ? (uint8_t)MVF_DTYPE_FLOAT16 : c->dtype;  // what the scan kernel reads
+    const unsigned char* krows = use_qs       ? static_cast<const unsigned char*>(c->shadow8.p)
+                                 : use_shadow ? static_cast<const unsigned char*>(c->shadow.p)
+                                              : c->d_rows;
+    const uint32_t kpitch = use_qs ? shadow8_pitch(c->dim) : use_shadow ? shadow_pitch(c->dim) : c->pitch;
     const bool dma = !wide && k2_dma_enabled();            // LDS-DMA kernel (default) or the register-staged one
     const uint32_t qpb = wide ? 128u : dma ? scan_mfma16_dma_queries_per_block(nq) : scan_mfma16_queries_per_block(kdtype);
     const uint32_t tile_rows = wide ? 128u : dma ? scan_mfma16_dma_tile_rows(qpb) : 256u;
@@ -529,14 +580,15 @@ int search_batched_path(const mvfgpu_corpus* c, uint8_t metric, const void* d_qu
     const uint32_t KT = wide ? (c->dim + 31u) / 32u : (c->dim * elem_size(kdtype) + ktb - 1u) / ktb;
     const uint32_t KPB = KT * ktb;                         // prepared query row, bytes
     const uint32_t planes = 1u;
-    const uint32_t cap = kBatchCap;
+    const uint32_t cap = use_qs ? kBatchCapQS : kBatchCap;
     const uint32_t n = (uint32_t)c->n;
 
-    HIP_TRY(c->bq.reserve((size_t)planes * nq_pad * KPB + (size_t)nq_pad * 8 + 64));
+    HIP_TRY(c->bq.reserve((size_t)planes * nq_pad * KPB + (size_t)nq_pad * 12 + 64));
     unsigned char* qprep = static_cast<unsigned char*>(c->bq.p);
     float* qaux0 = reinterpret_cast<float*>(qprep + (size_t)planes * nq_pad * KPB);
     float* qaux1 = qaux0 + nq_pad;
     unsigned char* zeros = reinterpret_cast<unsigned char*>(qaux1 + nq_pad);  // 64 zero bytes
+    float* qdelta = reinterpret_cast<float*>(zeros + 64);                       // [nq_pad] int8-shadow selection: bound per query
     HIP_TRY(hipMemsetAsync(zeros, 0, 64, s));
     {
         int rc = ensure_bstate(c, nq_pad, s);
@@ -549,7 +601,7 @@ int search_batched_path(const mvfgpu_corpus* c, uint8_t metric, const void* d_qu
     const bool is_float = !is_int_dtype(c->dtype);
     // approximate selection + exact re-scoring: float L2 (GEMM-form distances) and every metric on Float16 rows
     // (single f16 query plane); the other combinations carry final keys through the phases
-    const bool approx = is_float && (metric == MVF_METRIC_L2 || kdtype == MVF_DTYPE_FLOAT16);
+    const bool approx = is_float && (metric == MVF_METRIC_L2 || kdtype == MVF_DTYPE_FLOAT16 || use_qs);
     const bool need_norms = approx || metric != MVF_METRIC_INNER_PRODUCT || c->dtype == MVF_DTYPE_UINT8;
     const size_t nn = norm_stride(n);
     if (need_norms) {
@@ -558,7 +610,10 @@ int search_batched_path(const mvfgpu_corpus* c, uint8_t metric, const void* d_qu
     }
     const float* xx2 = is_float && c->xnorm.p ? static_cast<const float*>(c->xnorm.p) + nn : nullptr;
     const float* xxmax = is_float && c->xnorm.p ? static_cast<const float*>(c->xnorm.p) + norm_max_at(n) : nullptr;
-    if (wide)
+    if (use_qs)
+        HIP_TRY(launch_prep_queries_i8s(static_cast<const float*>(d_queries), nq, nq_pad, c->dim, KPB, metric,
+                                        static_cast<const float*>(c->qs_stats.p), xxmax, qprep, qaux0, qaux1, qdelta, s));
+    else if (wide)
         HIP_TRY(launch_prep_queries(static_cast<const float*>(d_queries), nq, nq_pad, c->dim, KPB / 4,
                                     reinterpret_cast<float*>(qprep), qaux0, s));
     else
@@ -588,7 +643,7 @@ int search_batched_path(const mvfgpu_corpus* c, uint8_t metric, const void* d_qu
     hp.qaux0 = qaux0;
     hp.qaux1 = qaux1;
     hp.rows = krows;
-    hp.xscale = use_shadow ? static_cast<const float*>(c->xscale.p) : nullptr;
+    hp.xscale = use_qs ? static_cast<const float*>(c->xscale8.p) : use_shadow ? static_cast<const float*>(c->xscale.p) : nullptr;
     hp.zeros = zeros;
     hp.xnorm_f = static_cast<const float*>(c->xnorm.p);
     hp.xnorm_i = static_cast<const int32_t*>(c->xnorm.p);
@@ -637,9 +692,10 @@ int search_batched_path(const mvfgpu_corpus* c, uint8_t metric, const void* d_qu
     cp.eps = (float)(std::max<uint32_t>(c->dim, 64) + 16) * 1.1920929e-7f;
     if (kdtype == MVF_DTYPE_FLOAT16) cp.eps += 4.8828125e-4f * 1.001f;
     if (use_shadow) cp.eps += 4.8828125e-4f * 1.001f;  // the shadow rows' own rounding (same bound, per element of x)
+    cp.delta = use_qs ? qdelta : nullptr;               // int8 selection: the per-query bound from the query preparation
 
     mvfgpu_timing tm{};
-    tm.scan_kernel = wide ? 2u : use_shadow ? 4u : 3u;
+    tm.scan_kernel = wide ? 2u : use_qs ? 6u : use_shadow ? 4u : 3u;
     mvfgpu_corpus::ProfSlot* ps = nullptr;
     if (c->profiling) {
         ps = &c->prof[c->prof_next % mvfgpu_corpus::kProfSlots];
@@ -812,7 +868,7 @@ bool use_batched_path(const mvfgpu_corpus* c, uint8_t metric, uint32_t nq) {
         (size_t)((c->dim + 7u) & ~7u) * 4 + kBatchCap * 4 > 64 * 1024)
         supported = false;  // the re-scoring kernel keeps the query in LDS
     if (!supported) return false;
-    if (c->scan_path == 2 || c->scan_path == 3) return true;
+    if (c->scan_path == 2 || c->scan_path == 3 || (c->scan_path == 5 && !is_int_dtype(c->dtype))) return true;
     // K1 takes 2..4 queries per HBM pass (5.7 / 6.3 / 7.4 ms on 10M x 768 f32 / 12.5M x 1024 f16 / 50M x 768 int8);
     // K2 costs a flat padded-tile time: with the 64-query tile 3.65 ms (f16 kernel on the f32 corpus' shadow), 4.9 ms
     // (f16 corpus), 7.6 ms (int8) up to 64 queries; the exact f32 kernel 15.3 ms up to 128 -- plus ~0.2 ms of phase
@@ -1127,6 +1183,9 @@ void mvfgpu_corpus_destroy(mvfgpu_corpus* c) {
         c->xscale.release();
         c->tomb.release();
         c->ids.release();
+        c->shadow8.release();
+        c->xscale8.release();
+        c->qs_stats.release();
         c->h_q.release();
         c->h_s.release();
         c->h_i.release();
@@ -1154,7 +1213,7 @@ int mvfgpu_corpus_get_info(const mvfgpu_corpus* c, mvfgpu_corpus_info* out) {
     out->deleted_rows = c->deleted;
     std::lock_guard<std::mutex> lk(c->mu);
     out->device_bytes = c->tomb.bytes + c->ids.bytes + c->rows_bytes + c->cand.bytes + c->bq.bytes + c->bstate.bytes + c->bcand.bytes + c->xnorm.bytes +
-                        c->repair.bytes + c->blk.bytes + c->shadow.bytes + c->xscale.bytes + c->h_q.bytes + c->h_s.bytes + c->h_i.bytes +
+                        c->repair.bytes + c->blk.bytes + c->shadow8.bytes + c->xscale8.bytes + c->shadow.bytes + c->xscale.bytes + c->h_q.bytes + c->h_s.bytes + c->h_i.bytes +
                         c->h_r.bytes;
     return MVF_OK;
 }
@@ -1519,7 +1578,7 @@ int mvfgpu_last_timing(const mvfgpu_corpus* c, mvfgpu_timing* out) {
 
 int mvfgpu_set_scan_path(mvfgpu_corpus* c, int path) {
     if (!c) return fail(MVF_ERR_INVALID_ARGUMENT, "corpus is NULL");
-    if (path < 0 || path > 4) return fail(MVF_ERR_INVALID_ARGUMENT, "path must be 0..4");
+    if (path < 0 || path > 5) return fail(MVF_ERR_INVALID_ARGUMENT, "path must be 0..5");
     std::lock_guard<std::mutex> lk(c->mu);
     c->scan_path = path;
     return MVF_OK;

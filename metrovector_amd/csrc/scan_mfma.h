@@ -64,7 +64,7 @@ struct Batch16Params {
 };
 
 constexpr uint32_t kBlkMaxBlocks = 512;  // grids this size or smaller use per-block candidate regions ...
-constexpr uint32_t kBlkCap = 8192;       // ... of this many 16-byte records each (64 MiB in all)
+constexpr uint32_t kBlkCap = 16384;      // ... of this many 16-byte records each (128 MiB in all)
 
 struct CompactParams {
     uint64_t* cand;
@@ -86,6 +86,9 @@ struct CompactParams {
     uint8_t l2_is_distance;
     float eps_acc;
     uint32_t truncated_at;
+    // int8-shadow selection (shadow_i8.hip): the proven bound of |approximate - exact score| per query, replacing the
+    // eps formulas above (the L2 entry bounds the squared GEMM-form distance)
+    const float* delta;   // [nq] or NULL
     // final stage only
     uint8_t metric, dtype;
     uint64_t index_base;
@@ -139,6 +142,12 @@ hipError_t launch_prep_queries16(const void* q, int dtype, uint32_t nq, uint32_t
                                  unsigned char* qprep, float* qaux0, float* qaux1, hipStream_t s);
 hipError_t launch_shadow_f16(const unsigned char* rows32, uint32_t n, uint32_t pitch32, uint32_t dim, unsigned char* rows16,
                              uint32_t pitch16, float* xscale, hipStream_t s);
+// int8 shadow of a Float32 / Float16 corpus + its queries (shadow_i8.hip); stats: 4 floats, zeroed by the caller
+hipError_t launch_shadow_i8(const unsigned char* rows, int src_dtype, uint32_t n, uint32_t pitch, uint32_t dim, unsigned char* rows8,
+                            uint32_t pitch8, float* xscale8, float* stats, hipStream_t s);
+hipError_t launch_prep_queries_i8s(const float* q, uint32_t nq, uint32_t nq_pad, uint32_t dim, uint32_t KPB, int metric,
+                                   const float* stats, const float* xxmax, unsigned char* qprep, float* qaux0, float* qaux1,
+                                   float* delta, hipStream_t s);
 hipError_t launch_row_norms16(const unsigned char* rows, int dtype, uint32_t n, uint32_t pitch, uint32_t dim, void* out,
                               float* xx2, float* xxmax, hipStream_t s);  // UInt8: xx2 receives the int32 bias array
 

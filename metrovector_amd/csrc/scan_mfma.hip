@@ -375,10 +375,48 @@ __global__ void __launch_bounds__(256) row_norms_f32_kernel(const unsigned char*
 
 // ---- candidate hand-off: per-block regions -> per-query lists ---------------------------------------------------
 // The narrow-type K2 kernels append {key, row, query} records to per-block regions with an LDS counter (scan_mfma.h);
-// this pass files them under their queries.  Here the returning atomics cost nothing: thousands of threads, nobody
-// waits for anybody.  grid (4, regions); block 256.
-__global__ void __launch_bounds__(256) scatter_cand_kernel(const uint4* blk_cand, const uint32_t* blk_cnt, uint32_t blk_cap,
-                                                            uint64_t* cand, uint32_t* cnt, uint32_t cap) {
+// this pass files them under their queries.  A record-per-thread version with one global atomicAdd(cnt[q]) each was
+// bound by same-address atomics (2 M records on 1024 counters: 150 us per call, 0.9 ms of a 12-ms search).  Here a block
+// owns a contiguous share of the regions and aggregates per query in LDS first: histogram with LDS atomics (which also
+// hand every record its rank), ONE global atomicAdd per (block, query) to reserve the range, then the stores.
+// grid (kScatterBlocks); block 1024; dynamic LDS 8 * nq_pad bytes (queries <= kScatterMaxQueries, else the simple form).
+constexpr uint32_t kScatterBlocks = 64, kScatterMaxQueries = 8192;
+
+__global__ void __launch_bounds__(1024) scatter_cand_kernel(const uint4* blk_cand, const uint32_t* blk_cnt, uint32_t blk_cap,
+                                                             uint32_t nregions, uint64_t* cand, uint32_t* cnt, uint32_t cap,
+                                                             uint32_t nq_pad) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32_t* hist = reinterpret_cast<uint32_t*>(smem);  // [nq_pad] records of this block per query, then their global base
+    const uint32_t per = (nregions + gridDim.x - 1) / gridDim.x;
+    const uint32_t r_lo = blockIdx.x * per, r_hi = min(nregions, r_lo + per);
+    for (uint32_t i = threadIdx.x; i < nq_pad; i += 1024) hist[i] = 0;
+    __syncthreads();
+    // pass 1: histogram (the returned value is the record's rank inside the block's share of its query; it is
+    // recomputed in pass 3 in the same order only if deterministic order mattered -- it does not: lists are unordered)
+    for (uint32_t b = r_lo; b < r_hi; b++) {
+        const uint32_t n = min(blk_cnt[b], blk_cap);
+        for (uint32_t e = threadIdx.x; e < n; e += 1024) atomicAdd(&hist[blk_cand[(size_t)b * blk_cap + e].z], 1u);
+    }
+    __syncthreads();
+    // pass 2: reserve the ranges
+    for (uint32_t i = threadIdx.x; i < nq_pad; i += 1024) {
+        const uint32_t h = hist[i];
+        hist[i] = h ? atomicAdd(&cnt[i], h) : 0u;
+    }
+    __syncthreads();
+    // pass 3: store (a query's records take consecutive slots from its base, in arrival order of the LDS atomics)
+    for (uint32_t b = r_lo; b < r_hi; b++) {
+        const uint32_t n = min(blk_cnt[b], blk_cap);
+        for (uint32_t e = threadIdx.x; e < n; e += 1024) {
+            const uint4 rec = blk_cand[(size_t)b * blk_cap + e];
+            const uint32_t slot = atomicAdd(&hist[rec.z], 1u);
+            if (slot < cap) cand[(size_t)rec.z * cap + slot] = ((uint64_t)rec.x << 32) | rec.y;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) scatter_cand_simple_kernel(const uint4* blk_cand, const uint32_t* blk_cnt, uint32_t blk_cap,
+                                                                   uint64_t* cand, uint32_t* cnt, uint32_t cap) {
     const uint32_t b = blockIdx.y;
     const uint32_t n = min(blk_cnt[b], blk_cap);
     for (uint32_t e = blockIdx.x * 256u + threadIdx.x; e < n; e += gridDim.x * 256u) {
@@ -460,48 +498,90 @@ __global__ void __launch_bounds__(1024) compact_kernel(CompactParams p) {
 // top-k row has s~ within 2 delta of v_k: keep all of those (not just k) and publish tau = ord(v_k -/+ 2 delta).
 // The kept rows are re-scored exactly at the end (rescore_kernel).
 __global__ void __launch_bounds__(1024) compact_margin_kernel(CompactParams p) {
+    // The kept rows are re-scored and sorted by rescore_kernel, so nothing here needs the candidates in order: what is
+    // needed is the k-th best approximate KEY (a radix select over the 32-bit keys: four 8-bit histogram passes in LDS)
+    // and a filter.  (Round 1 sorted all cap entries: 55 us at cap 4096, 118 us at 8192, per phase.)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint64_t* buf = reinterpret_cast<uint64_t*>(smem);
-    __shared__ uint32_t keep_s;
+    __shared__ uint32_t hist[256];
+    __shared__ uint32_t live_s, keep_s, sel_prefix, sel_remaining;
     const int tid = threadIdx.x;
     const uint32_t q = blockIdx.x;
-    __shared__ uint32_t live_s;
     const uint32_t raw_cnt = p.direct_cnt ? p.direct_cnt : p.cnt[q];  // direct phase: every row of it, no counter
-    uint32_t m = raw_cnt < p.cap ? raw_cnt : p.cap;
+    const uint32_t m = raw_cnt < p.cap ? raw_cnt : p.cap;
     uint64_t* c = p.cand + (size_t)q * p.cap;
-    const uint32_t P2 = next_pow2(m < 2 ? 2 : m);
-    for (uint32_t i = tid; i < P2; i += 1024) buf[i] = i < m ? c[i] : kPadComposite;
+    if (tid == 0) live_s = 0, keep_s = 0, sel_prefix = 0, sel_remaining = p.k;
     __syncthreads();
-    bitonic_sort_u64<1024>(buf, P2, tid);
-    m = live_prefix(buf, m, tid, &live_s);
-    if (tid == 0) keep_s = m;
+    uint32_t mylive = 0;
+    for (uint32_t i = tid; i < m; i += 1024) {
+        const uint64_t e = c[i];
+        buf[i] = e;
+        mylive += e != kPadComposite;  // padding = the direct phase's slots of deleted rows
+    }
+    for (int off = 32; off > 0; off >>= 1) mylive += __shfl_xor(mylive, off, 64);
+    if ((tid & 63) == 0 && mylive) atomicAdd(&live_s, mylive);
     __syncthreads();
+    const uint32_t live = live_s;
     uint32_t tkey = kNanKey;
-    if (m >= p.k) {
-        const float vk = score_from_key((uint32_t)(buf[p.k - 1] >> 32), p.metric);
+    if (live >= p.k) {
+        uint32_t mask = 0;
+        for (int shift = 24; shift >= 0; shift -= 8) {
+            if (tid < 256) hist[tid] = 0;
+            __syncthreads();
+            const uint32_t prefix = sel_prefix;
+            for (uint32_t i = tid; i < m; i += 1024) {
+                const uint64_t e = buf[i];
+                const uint32_t key = (uint32_t)(e >> 32);
+                if (e != kPadComposite && ((key ^ prefix) & mask) == 0) atomicAdd(&hist[(key >> shift) & 255u], 1u);
+            }
+            __syncthreads();
+            if (tid < 64) {  // one wave: bin of the k-th among the entries that share the prefix
+                const uint32_t h0 = hist[4 * tid], h1 = hist[4 * tid + 1], h2 = hist[4 * tid + 2], h3 = hist[4 * tid + 3];
+                uint32_t incl = h0 + h1 + h2 + h3;
+                for (int off = 1; off < 64; off <<= 1) {
+                    const uint32_t v = __shfl_up(incl, off, 64);
+                    if (tid >= off) incl += v;
+                }
+                const uint32_t excl = incl - (h0 + h1 + h2 + h3), rem = sel_remaining;
+                if (excl < rem && rem <= incl) {  // exactly one lane
+                    uint32_t r = rem - excl, bin = 4 * tid;
+                    if (r > h0) { r -= h0; bin++; if (r > h1) { r -= h1; bin++; if (r > h2) { r -= h2; bin++; } } }
+                    sel_prefix = prefix | (bin << shift);
+                    sel_remaining = r;
+                }
+            }
+            mask |= 255u << shift;
+            __syncthreads();
+        }
+        const float vk = score_from_key(sel_prefix, p.metric);  // the k-th best approximate score
         const float qn = p.qnorm[q];
         float thr;
-        if (p.metric == MVF_METRIC_L2 && p.l2_is_distance)
+        if (p.delta) thr = p.metric == MVF_METRIC_L2 ? vk + 2.0f * p.delta[q] : vk - 2.0f * p.delta[q];  // int8-shadow selection
+        else if (p.metric == MVF_METRIC_L2 && p.l2_is_distance)
             thr = vk + 2.0f * (p.eps * sqrtf(p.xxmax[0]) + p.eps_acc * (qn + sqrtf(p.xxmax[0])));
         else if (p.metric == MVF_METRIC_L2) thr = vk + 2.0f * p.eps * (qn * qn + p.xxmax[0]);
         else if (p.metric == MVF_METRIC_COSINE) thr = vk - 2.0f * p.eps;
         else thr = vk - 2.0f * p.eps * qn * sqrtf(p.xxmax[0]);
         tkey = key_from_score(thr, p.metric);
-        if (tkey != kNanKey)
-            for (uint32_t i = p.k - 1 + tid; i < m; i += 1024)
-                if ((uint32_t)(buf[i] >> 32) <= tkey && (i + 1 == m || (uint32_t)(buf[i + 1] >> 32) > tkey)) keep_s = i + 1;
+    }
+    // filter: every live entry whose key is within the margin (all of them while there is no threshold)
+    const uint32_t keep_cap = p.cap / 2;
+    for (uint32_t i = tid; i < m; i += 1024) {
+        const uint64_t e = buf[i];
+        if (e != kPadComposite && (tkey == kNanKey || (uint32_t)(e >> 32) <= tkey)) {
+            const uint32_t slot = atomicAdd(&keep_s, 1u);
+            if (slot < keep_cap) c[slot] = e;
+        }
     }
     __syncthreads();
-    uint32_t keep = keep_s;
-    const uint32_t keep_cap = p.cap / 2;
-    bool over = raw_cnt > p.cap;
-    if (keep > keep_cap) {  // too many near-ties to carry: the host redoes this query exactly with K1
-        keep = keep_cap;
-        over = true;
-    }
-    if (p.truncated_at && m >= p.truncated_at && keep_s >= m) over = true;  // the margin reaches past the cut
-    for (uint32_t i = tid; i < keep; i += 1024) c[i] = buf[i];
     if (tid == 0) {
+        uint32_t keep = keep_s;
+        bool over = raw_cnt > p.cap;
+        if (keep > keep_cap) {  // too many near-ties to carry: this query is redone exactly with K1
+            keep = keep_cap;
+            over = true;
+        }
+        if (p.truncated_at && m >= p.truncated_at && keep_s >= live) over = true;  // the margin reaches past the cut
         if (over) p.overflow[q] = 1u;
         p.cnt[q] = keep;
         p.tau[q] = tkey;
@@ -644,11 +724,28 @@ hipError_t launch_row_norms_f32(const unsigned char* rows, uint32_t n, uint32_t 
 
 hipError_t launch_scatter_cand(const Batch16Params& p, uint32_t nblocks, hipStream_t s) {
     if (!p.blk_cand || nblocks == 0) return hipSuccess;
-    hipLaunchKernelGGL(scatter_cand_kernel, dim3(4, nblocks), dim3(256), 0, s, p.blk_cand, p.blk_cnt, p.blk_cap, p.cand, p.cnt, p.cap);
+    if (p.nq_pad <= kScatterMaxQueries) {
+        const size_t lds = (size_t)p.nq_pad * 4;
+        if (lds > 48 * 1024) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&scatter_cand_kernel),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+        }
+        hipLaunchKernelGGL(scatter_cand_kernel, dim3(std::min(kScatterBlocks, nblocks)), dim3(1024), lds, s, p.blk_cand, p.blk_cnt,
+                           p.blk_cap, nblocks, p.cand, p.cnt, p.cap, p.nq_pad);
+    } else {
+        hipLaunchKernelGGL(scatter_cand_simple_kernel, dim3(4, nblocks), dim3(256), 0, s, p.blk_cand, p.blk_cnt, p.blk_cap, p.cand,
+                           p.cnt, p.cap);
+    }
     return hipGetLastError();
 }
 
 hipError_t launch_compact_margin(const CompactParams& p, uint32_t nq, hipStream_t s) {
+    if ((size_t)p.cap * 8 > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&compact_margin_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)((size_t)p.cap * 8));
+        if (e != hipSuccess) return e;
+    }
     hipLaunchKernelGGL(compact_margin_kernel, dim3(nq), dim3(1024), (size_t)p.cap * 8, s, p);
     return hipGetLastError();
 }

@@ -173,7 +173,7 @@ __global__ void __launch_bounds__(512, 2) scan_mfma16_dma_kernel(Batch16Params p
 
     uint32_t c_n = 0, c_kt = 0, c_nt, c_mt;  // compute cursor
     slot_tile(0, c_nt, c_mt);
-    load_query_consts16<DT, METRIC, BMQ>(p, c_mt * BMQ, tid, qa_s, qb_s, tau_s, thr_s);
+    load_query_consts16<DT, METRIC, BMQ, (DT == MVF_DTYPE_INT8 && XS)>(p, c_mt * BMQ, tid, qa_s, qb_s, tau_s, thr_s);
 
     set_dma_tile(0);
 #pragma unroll
@@ -234,7 +234,7 @@ __global__ void __launch_bounds__(512, 2) scan_mfma16_dma_kernel(Batch16Params p
                 slot_tile(c_n, c_nt, nmt);
                 if (nmt != c_mt) {  // block-uniform; rare
                     __syncthreads();
-                    load_query_consts16<DT, METRIC, BMQ>(p, nmt * BMQ, tid, qa_s, qb_s, tau_s, thr_s);
+                    load_query_consts16<DT, METRIC, BMQ, (DT == MVF_DTYPE_INT8 && XS)>(p, nmt * BMQ, tid, qa_s, qb_s, tau_s, thr_s);
                     c_mt = nmt;
                 }
             }
@@ -254,7 +254,7 @@ template <int DT, int METRIC, int BMQ>
 hipError_t launch_dtm(const Batch16Params& p, dim3 grid, hipStream_t s) {
     void (*fn)(Batch16Params) =
         p.direct ? &scan_mfma16_dma_kernel<DT, METRIC, true, false, BMQ> : &scan_mfma16_dma_kernel<DT, METRIC, false, false, BMQ>;
-    if constexpr (DT == MVF_DTYPE_FLOAT16)
+    if constexpr (DT == MVF_DTYPE_FLOAT16 || DT == MVF_DTYPE_INT8)  // rows are a scaled shadow (f16, or the int8 shadow)
         if (p.xscale)
             fn = p.direct ? &scan_mfma16_dma_kernel<DT, METRIC, true, true, BMQ> : &scan_mfma16_dma_kernel<DT, METRIC, false, true, BMQ>;
     // > 64 KiB of dynamic LDS needs the attribute; it is per device, and one process may drive several devices

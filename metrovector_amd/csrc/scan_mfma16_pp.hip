@@ -70,7 +70,9 @@ template <int DT, int METRIC, bool DIRECT, bool XS>
 __global__ void __launch_bounds__(512, 2) scan_mfma16_pp_kernel(Batch16Params p) {
     using AccT = typename std::conditional<DT == MVF_DTYPE_FLOAT16, f32x4, i32x4>::type;
     constexpr int NI = WQ / SH, NJ = WR / SH, NE = SH * SH / 64, HI = NI / 2;
-    constexpr bool U8 = DT == MVF_DTYPE_UINT8, F16 = DT == MVF_DTYPE_FLOAT16;
+    constexpr bool U8 = DT == MVF_DTYPE_UINT8;
+    constexpr bool QS = DT == MVF_DTYPE_INT8 && XS;             // int8 shadow of a float corpus: float scores (common.inc)
+    constexpr bool F16 = DT == MVF_DTYPE_FLOAT16 || QS;         // ... so the per-row constants are the float ones
     // per-row constants the epilogue needs (scan_mfma16_common.inc): array 0 = norms, array 1 = shadow scale / UInt8 bias
     constexpr bool NEED0 = METRIC != MVF_METRIC_INNER_PRODUCT;
     constexpr bool NEED1 = F16 ? XS : (U8 && METRIC != MVF_METRIC_L2);
@@ -156,7 +158,7 @@ __global__ void __launch_bounds__(512, 2) scan_mfma16_pp_kernel(Batch16Params p)
     };
     zero_acc();
 
-    load_query_consts16<DT, METRIC, BMQ>(p, mt * BMQ, tid, qa_s, qb_s, tau_s, thr_s);
+    load_query_consts16<DT, METRIC, BMQ, QS>(p, mt * BMQ, tid, qa_s, qb_s, tau_s, thr_s);
     if (tid == 0) *bc_s = 0;
     set_dma_tile(0);
     // prologue: A k-tiles 0, 1 (group 0) / B k-tiles 0 .. 3 (group 1)
@@ -265,7 +267,7 @@ static_assert(PPW * (NSB - 2) < 16 && PPW * (NSA - 3) < 16, "vmcnt low field");
 template <int DT, int METRIC>
 hipError_t launch_dtm(const Batch16Params& p, dim3 grid, hipStream_t s) {
     void (*fn)(Batch16Params) = p.direct ? &scan_mfma16_pp_kernel<DT, METRIC, true, false> : &scan_mfma16_pp_kernel<DT, METRIC, false, false>;
-    if constexpr (DT == MVF_DTYPE_FLOAT16)
+    if constexpr (DT == MVF_DTYPE_FLOAT16 || DT == MVF_DTYPE_INT8)  // rows are a scaled shadow (f16, or the int8 shadow: QS)
         if (p.xscale) fn = p.direct ? &scan_mfma16_pp_kernel<DT, METRIC, true, true> : &scan_mfma16_pp_kernel<DT, METRIC, false, true>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)PP_LDS);
     if (e != hipSuccess) return e;

@@ -25,10 +25,13 @@ CFGS = {
     "cfg4z": (50_000_000, 768, 2, 1, 256),
     "cfg5b": (12_500_000, 1024, 1, 0, 1024),  # bf16-compatible f16 bit patterns (MVF_DIAG_BF16 builds)
 }
-ALL_VARIANTS = {"lockstep": {"MVF_K2_PP": "0", "MVF_K2_GROWTH": "8"}, "pingpong": {"MVF_K2_PP": "1", "MVF_K2_GROWTH": "8"},
-                "default": {"MVF_K2_PP": None, "MVF_K2_GROWTH": None},
+ALL_VARIANTS = {"lockstep": {"MVF_K2_PP": "0", "MVF_K2_GROWTH": "8", "MVF_I8_SHADOW": None},
+                "pingpong": {"MVF_K2_PP": "1", "MVF_K2_GROWTH": "8", "MVF_I8_SHADOW": None},
+                "default": {"MVF_K2_PP": None, "MVF_K2_GROWTH": None, "MVF_I8_SHADOW": None},
                 "pp_g4": {"MVF_K2_PP": "1", "MVF_K2_GROWTH": "4"}, "pp_g3": {"MVF_K2_PP": "1", "MVF_K2_GROWTH": "3"},
                 "pp_g16": {"MVF_K2_PP": "1", "MVF_K2_GROWTH": "16"},
+                "i8s_ls": {"MVF_K2_PP": "0", "MVF_K2_GROWTH": None, "MVF_I8_SHADOW": "1"},
+                "i8s_pp": {"MVF_K2_PP": "1", "MVF_K2_GROWTH": None, "MVF_I8_SHADOW": "1"},
                 "ls_g4": {"MVF_K2_PP": "0", "MVF_K2_GROWTH": "4"}, "ls_g3": {"MVF_K2_PP": "0", "MVF_K2_GROWTH": "3"}}
 VARIANTS = [(v, ALL_VARIANTS[v]) for v in (sys.argv[3].split(",") if len(sys.argv) > 3 else ["lockstep", "pingpong"])]
 
