@@ -17,7 +17,7 @@ shard, one packed RCCL all-gather, merge; per-rank scan ms, exchange ms and the 
 are printed with it.
 
 N = 1 only: recall@k against an exact oracle top-k over all rows, the metric's second leg on the same corpus (1024
-batched queries: default path and exact f32 MFMA), `host_api` (the same search through the host-buffer entry point
+batched queries: default path = int8-shadow selection, f16-shadow selection, exact f32 MFMA), `host_api` (the same search through the host-buffer entry point
 mvfgpu_search: query H2D + kernels + results D2H), `cpu_baseline` (the oracle's faithful single-thread restatement of the
 reference loop) and `cpu_baseline_best_effort` (OpenMP over rows, all host cores, no per-row allocation).
 
@@ -50,10 +50,14 @@ def mfma_roofline(tm, dtype):
     """Roofline of the batched path from the live HIP-event timing: the dominant launch (the LAST, largest phase) and
     the WHOLE search (every phase, compactions, re-scoring and repair launches included).
     tm.scan_kernel: 2 = f32 MFMA kernel on Float32 rows, 3 = f16/int8 kernel on the stored rows, 4 = f16 kernel on
-    the scaled-f16 shadow of a Float32 corpus (selection; the kept rows are re-scored exactly)."""
+    the scaled-f16 shadow of a Float32 corpus, 6 = int8 kernel on the int8 shadow of a Float32 / Float16 corpus (4 and 6:
+    selection only; the kept rows are re-scored exactly from the stored rows).  The int8-shadow leg is priced against the
+    INT8 MFMA peak: that is the pipe the kernel runs on."""
     ach = tm.scan_flops / (tm.scan_ms_avg * 1e-3) / 1e12
     if tm.scan_kernel == 2:
         peak, unit, kernel = MFMA_F32_PEAK_TF, "TFLOP/s", "scan_mfma_f32_kernel (last phase)"
+    elif tm.scan_kernel == 6:
+        peak, unit, kernel = MFMA_I8_PEAK_TOPS, "TOP/s", "scan_mfma16 kernel <int8> (last phase) on the int8 shadow of the float rows"
     elif tm.scan_kernel == 3 and dtype in (2, 3):
         peak, unit, kernel = MFMA_I8_PEAK_TOPS, "TOP/s", "scan_mfma16 kernel <int8> (last phase)"
     else:
@@ -413,8 +417,9 @@ def main():
                 leg["recall_at_k"] = sum(len(set(a.tolist()) & set(b.tolist())) for a, b in zip(gi, oidx)) / oidx.size
             result["single_query_f16_shadow_stream"] = leg
         # ---- the metric's second leg: the same resident corpus, 1024 batched queries (MFMA path) ----------
-        # Two ways, same results: the default (f16 MFMA kernel selecting on the scaled-f16 shadow of the rows,
-        # kept rows re-scored exactly from the f32 rows) and the exact f32 MFMA kernel on the rows themselves.
+        # Three ways, same results: the default (int8 MFMA kernel selecting on the int8 shadow of the rows, every row inside
+        # a proven bound of the k-th best re-scored exactly from the f32 rows), the f16 MFMA kernel on the scaled-f16
+        # shadow (round 1's default), and the exact f32 MFMA kernel on the rows themselves.
         if args.queries == 1 and args.dtype == 0 and not args.no_batched:
             nqb, bsteps = 1024, 5
             dqb = torch.empty((nqb, args.dim), dtype=qdt, device=dev)
@@ -424,7 +429,7 @@ def main():
             oidx = None
             if not args.no_recall:
                 osc, oidx = oracle_topk_full(args, oracle, dqb.cpu().numpy()[sel])
-            for name, path in (("batched_q1024", 0), ("batched_q1024_f32_mfma", 2)):
+            for name, path in (("batched_q1024", 0), ("batched_q1024_f16_shadow", 3), ("batched_q1024_f32_mfma", 2)):
                 corpus.set_scan_path(path)
                 searcher.search(dqb, args.k, args.metric)  # warm-up (builds the row norms / the shadow once)
                 torch.cuda.synchronize()
@@ -437,14 +442,17 @@ def main():
                 tmb = corpus.last_timing()
                 corpus.set_profiling(False)
                 leg = {"workload": f"{args.rows // 1_000_000}M x {args.dim} {dtname} {mname}, {nqb} batched queries, top-{args.k}",
-                       "scan_path": "automatic" if path == 0 else "2 (exact f32 MFMA on the stored rows)",
+                       "scan_path": {0: "automatic (int8-shadow selection + exact re-scoring)",
+                                     3: "3 (f16-shadow selection + exact re-scoring; round 1's default)",
+                                     2: "2 (exact f32 MFMA on the stored rows)"}[path],
                        "value": float(nqb) * args.rows * bsteps / eb, "unit": "distance-ops/s", "steps": bsteps,
                        "ms_per_step": eb / bsteps * 1e3}
                 if tmb.samples and tmb.scan_ms_avg > 0 and tmb.scan_kernel >= 2:
                     leg["roofline"] = mfma_roofline(tmb, args.dtype)
                     # HBM bytes per launch from the committed PMC passes of this exact workload and kernel
                     tp = os.path.join(ROOT, "profiles", {2: "r01_bench_n1_q1024_hbm_traffic.json",
-                                                         4: "r01_bench_n1_q1024_shadow_hbm_traffic.json"}.get(tmb.scan_kernel, "-"))
+                                                         4: "r01_bench_n1_q1024_shadow_hbm_traffic.json",
+                                                         6: "r02_bench_n1_q1024_i8_shadow_hbm_traffic.json"}.get(tmb.scan_kernel, "-"))
                     if os.path.exists(tp):
                         leg["roofline"]["traffic"] = json.load(open(tp))["roofline_traffic_bytes_per_launch"]
                         leg["roofline"]["traffic_source"] = "profiles/" + os.path.basename(tp)

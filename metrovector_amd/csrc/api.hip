@@ -100,6 +100,15 @@ struct mvfgpu_corpus {
     mutable int shadow_state = 0;         // 0 not built yet, 1 ready, -1 unavailable (no memory)
     mutable DevBuf shadow8, xscale8, qs_stats;  // Float32 / Float16 corpora: int8 shadow rows, s_r per row, the 4 bound maxima
     mutable int shadow8_state = 0;
+    // feedback for the automatic choice: after a search that selected on the int8 shadow the number of queries the
+    // repair launches had to redo is copied to pinned host memory (no wait); a later search that finds it large
+    // (the data defeats the int8 bound: near-duplicates everywhere, heavy-tailed rows) switches this corpus back to the
+    // f16 selection for good
+    mutable uint32_t* qs_redo_host = nullptr;
+    mutable hipEvent_t qs_redo_ev = nullptr;
+    mutable bool qs_redo_pending = false, qs_disabled = false;
+    mutable uint32_t qs_redo_nq = 0;
+    mutable const uint32_t* last_redo_cnt = nullptr;  // device: the count the newest repair pass produced
     mutable bool xnorm_ready = false;
     mutable uint32_t bstate_slots = 0;    // queries the K2 state arrays are armed for
     mutable DevBuf h_q, h_s, h_i, h_r;    // device mirrors for the host-buffer API
@@ -382,14 +391,34 @@ hipError_t ensure_shadow(const mvfgpu_corpus* c, hipStream_t s, bool insist) {
 uint32_t shadow8_pitch(uint32_t dim) { return (dim + 15u) & ~15u; }
 constexpr uint32_t kBatchCapQS = 8192;  // candidate slots per query with int8 selection (5-8 x k rows ride in the margin)
 
-// scan path 5, or MVF_I8_SHADOW=1 with the automatic path: batched searches on Float32 / Float16 rows select on the int8
-// shadow (twice the MFMA rate of the f16 kernel under the same power limit; a 15 x wider proven margin)
+// Batched searches on Float32 / Float16 rows select on the int8 shadow by default (measured on cfg3 / cfg5 and on 2..512
+// queries: 1.3-1.6 x the f16 selection at every batch size, profiles/r02_k2_ab.txt, r02_small_batches_*.txt): twice the
+// MFMA rate of the f16 kernel under the same power limit, half (a quarter) of the bytes of Float16 (Float32) rows, a 15 x
+// wider proven margin.  MVF_I8_SHADOW=0, scan path 3 (f16 selection) and scan path 2 (stored rows) opt out; scan path 5
+// insists; a corpus whose data defeats the int8 bound switches itself back (qs_disabled).
 bool qs_wanted(const mvfgpu_corpus* c) {
     if (is_int_dtype(c->dtype) || c->n == 0) return false;
     if ((size_t)((c->dim + 7u) & ~7u) * 4 + kBatchCapQS * 4 > 64 * 1024) return false;  // re-scoring: query + candidates in LDS
     if (c->scan_path == 5) return true;
+    if (c->scan_path != 0 && c->scan_path != 4) return false;
+    if (c->qs_disabled || c->shadow8_state < 0) return false;
     const char* e = getenv("MVF_I8_SHADOW");
-    return c->scan_path == 0 && e && atoi(e) != 0;
+    return !e || atoi(e) != 0;
+}
+
+// Non-blocking look at what the previous int8-selected search had to repair.
+void qs_feedback_poll(const mvfgpu_corpus* c) {
+    if (!c->qs_redo_pending || hipEventQuery(c->qs_redo_ev) != hipSuccess) {
+        (void)hipGetLastError();
+        return;
+    }
+    c->qs_redo_pending = false;
+    if ((uint64_t)*c->qs_redo_host * 8 > c->qs_redo_nq && *c->qs_redo_host >= 4) {
+        c->qs_disabled = true;
+        if (getenv("MVF_DEBUG_REPAIR"))
+            fprintf(stderr, "[mvfgpu] int8-shadow selection switched off for this corpus: %u of %u queries needed the repair path\n",
+                    *c->qs_redo_host, c->qs_redo_nq);
+    }
 }
 
 hipError_t ensure_shadow8(const mvfgpu_corpus* c, hipStream_t s, bool insist) {
@@ -494,6 +523,7 @@ int repair_flagged_queries(const mvfgpu_corpus* c, uint8_t metric, const void* d
     uint32_t* redo_cnt = reinterpret_cast<uint32_t*>(static_cast<unsigned char*>(c->repair.p) + (size_t)R * per_query);
     uint32_t* redo_list = redo_cnt + 4;
     HIP_TRY(launch_flag_compact(overflow, nq, redo_list, redo_cnt, s));
+    c->last_redo_cnt = redo_cnt;
     for (uint32_t base = 0; base < nq; base += R) {
         ScanParams sp{};
         sp.rows = c->d_rows;
@@ -556,6 +586,7 @@ int search_batched_path(const mvfgpu_corpus* c, uint8_t metric, const void* d_qu
     // f32 rows and the f32 query either way, so results do not depend on which one ran.
     bool use_shadow = false, use_qs = false;
     const bool rescore_fits = (size_t)((c->dim + 7u) & ~7u) * 4 + kBatchCap * 4 <= 64 * 1024;  // query + candidates in LDS
+    qs_feedback_poll(c);
     if (qs_wanted(c)) {  // int8 shadow: selection at the int8 MFMA rate (Float32 and Float16 corpora)
         int rc = ensure_norms(c, s);
         if (rc != MVF_OK) return rc;
@@ -765,7 +796,18 @@ int search_batched_path(const mvfgpu_corpus* c, uint8_t metric, const void* d_qu
         c->prof_next++;
     }
 
-    return repair_flagged_queries(c, metric, d_queries, nq, nq_pad, k, overflow, d_scores, d_indices, d_raw, s);
+    int rc = repair_flagged_queries(c, metric, d_queries, nq, nq_pad, k, overflow, d_scores, d_indices, d_raw, s);
+    if (rc == MVF_OK && use_qs && c->scan_path != 5 && !c->qs_redo_pending && c->repair.p) {  // feedback, never waited for here
+        if (!c->qs_redo_host) {
+            HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&c->qs_redo_host), 64, hipHostMallocDefault));
+            HIP_TRY(hipEventCreateWithFlags(&c->qs_redo_ev, hipEventDisableTiming));
+        }
+        HIP_TRY(hipMemcpyAsync(c->qs_redo_host, c->last_redo_cnt, 4, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipEventRecord(c->qs_redo_ev, s));
+        c->qs_redo_pending = true;
+        c->qs_redo_nq = nq;
+    }
+    return rc;
 }
 
 // Scan path 4 (opt-in): one or two queries on a Float32 corpus STREAM ITS SCALED-F16 SHADOW -- half the bytes of the
@@ -875,8 +917,9 @@ bool use_batched_path(const mvfgpu_corpus* c, uint8_t metric, uint32_t nq) {
     // launches and the final flag read-back.  Measured crossovers on >= 1 GiB of rows; small corpora keep K1 until the
     // batch is MFMA-sized.
     const uint64_t bytes = c->n * (uint64_t)c->dim * elem_size(c->dtype);
-    const bool shadowed = c->dtype == MVF_DTYPE_FLOAT32 && (c->scan_path == 3 || shadow_enabled()) && c->shadow_state >= 0 &&  // runs as Float16
-                          (size_t)((c->dim + 7u) & ~7u) * 4 + kBatchCap * 4 <= 64 * 1024;
+    const bool shadowed = qs_wanted(c) ||  // int8 selection, else the f16 shadow (runs as Float16)
+                          (c->dtype == MVF_DTYPE_FLOAT32 && (c->scan_path == 3 || shadow_enabled()) && c->shadow_state >= 0 &&
+                           (size_t)((c->dim + 7u) & ~7u) * 4 + kBatchCap * 4 <= 64 * 1024);
     const uint32_t threshold = bytes < (1ull << 30)                           ? 32u
                                : c->dtype == MVF_DTYPE_FLOAT32 && !shadowed ? 9u
                                : is_int_dtype(c->dtype)                     ? 5u
@@ -953,7 +996,10 @@ int upload_rows(mvfgpu_corpus* c, const void* rows, uint64_t stride, const mvfgp
 
     // what the compute stream prepares per chunk
     bool want_norms = (o.flags & (MVFGPU_UPLOAD_EAGER_NORMS | MVFGPU_UPLOAD_EAGER_SHADOW)) != 0;
-    bool want_shadow = (o.flags & MVFGPU_UPLOAD_EAGER_SHADOW) != 0 && c->dtype == MVF_DTYPE_FLOAT32 && shadow_enabled();
+    // which selection copy the batched searches of this corpus will use: the int8 shadow (Float32 and Float16 rows; the
+    // default) or, with MVF_I8_SHADOW=0, the f16 shadow of Float32 rows
+    bool want_shadow8 = (o.flags & MVFGPU_UPLOAD_EAGER_SHADOW) != 0 && qs_wanted(c);
+    bool want_shadow = (o.flags & MVFGPU_UPLOAD_EAGER_SHADOW) != 0 && !want_shadow8 && c->dtype == MVF_DTYPE_FLOAT32 && shadow_enabled();
     float* xn = nullptr;
     const size_t nn = norm_stride(n);
     if (want_norms) {
@@ -970,6 +1016,21 @@ int upload_rows(mvfgpu_corpus* c, const void* rows, uint64_t stride, const mvfgp
             c->shadow.release();
             c->xscale.release();
             want_shadow = false;  // as ensure_shadow: the searches then use the exact f32 kernel
+        }
+    }
+
+    if (want_shadow8) {
+        const size_t need = (size_t)n * shadow8_pitch(c->dim);
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < need + ((size_t)2 << 30) ||
+            c->shadow8.reserve(need) != hipSuccess || c->xscale8.reserve(((size_t)n + 256) * 4) != hipSuccess ||
+            c->qs_stats.reserve(16) != hipSuccess) {
+            (void)hipGetLastError();
+            c->shadow8.release();
+            c->xscale8.release();
+            want_shadow8 = false;
+        } else {
+            HIP_TRY(hipMemsetAsync(c->qs_stats.p, 0, 16, s_comp));  // the four bound maxima accumulate over the chunks
         }
     }
 
@@ -1017,6 +1078,10 @@ int upload_rows(mvfgpu_corpus* c, const void* rows, uint64_t stride, const mvfgp
                 HIP_TRY(launch_row_norms16(place, c->dtype, (uint32_t)h, c->pitch, c->dim, xn + r0, xn + nn + r0,
                                            xn + norm_max_at(n), s_comp));
         }
+        if (want_shadow8)
+            HIP_TRY(launch_shadow_i8(place, c->dtype, (uint32_t)h, c->pitch, c->dim,
+                                     static_cast<unsigned char*>(c->shadow8.p) + r0 * shadow8_pitch(c->dim), shadow8_pitch(c->dim),
+                                     static_cast<float*>(c->xscale8.p) + r0, static_cast<float*>(c->qs_stats.p), s_comp));
         if (want_shadow)
             HIP_TRY(launch_shadow_f16(place, (uint32_t)h, c->pitch, c->dim,
                                       static_cast<unsigned char*>(c->shadow.p) + r0 * shadow_pitch(c->dim), shadow_pitch(c->dim),
@@ -1027,6 +1092,7 @@ int upload_rows(mvfgpu_corpus* c, const void* rows, uint64_t stride, const mvfgp
     HIP_TRY(hipStreamSynchronize(s_comp));
     if (want_norms) c->xnorm_ready = true;
     c->shadow_state = want_shadow ? 1 : c->shadow_state;
+    c->shadow8_state = want_shadow8 ? 1 : c->shadow8_state;
     return MVF_OK;
 }
 
@@ -1192,6 +1258,8 @@ void mvfgpu_corpus_destroy(mvfgpu_corpus* c) {
         c->h_r.release();
         if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
         if (c->up_stream) (void)hipStreamDestroy(c->up_stream);
+        if (c->qs_redo_ev) (void)hipEventDestroy(c->qs_redo_ev);
+        if (c->qs_redo_host) (void)hipHostFree(c->qs_redo_host);
         if (c->ev_done) (void)hipEventDestroy(c->ev_done);
         for (auto& ps : c->prof)
             for (auto& e : ps.e)

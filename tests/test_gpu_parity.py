@@ -536,7 +536,11 @@ def test_device_bytes_accounts_for_the_f16_shadow(oracle):
         c.set_scan_path(3)
         c.search(q, 10, G.COSINE)
         with_shadow = c.info().device_bytes
+        c.set_scan_path(5)
+        c.search(q, 10, G.COSINE)
+        with_shadow8 = c.info().device_bytes
     assert with_shadow - exact_only >= n * (208 + 4)      # pitch16 = 208 B for 100 halves
+    assert with_shadow8 - with_shadow >= n * (112 + 4)    # the int8 shadow: 112 B for 100 bytes
     assert exact_only > before                            # norms + K2 scratch
 
 
