@@ -735,10 +735,29 @@ int search_batched_path(const mvfgpu_corpus* c, uint8_t metric, const void* d_qu
         ps->scanned = false;
     }
 
-    // phase p scans rows [R_p, R_{p+1}); phase 0 passes everything (R_1 = cap rows), later phases grow by g:
-    // expected survivors per query k*(g-1) + k carried <= cap/2
+    // Phase p scans rows [R_p, R_{p+1}); phase 0 passes everything (no threshold yet: R_1 <= cap rows, stored by row
+    // offset), later phases grow by g: expected survivors per query k (g - 1) + k carried <= cap / 2.  The boundaries are
+    // laid out BACKWARDS from the corpus' end -- R_j = n / g^(P - j), P the fewest steps that bring R_1 under cap -- so every
+    // phase, the last one included, scans (g - 1) times what its threshold has seen, and the last phase is always the
+    // largest ((1 - 1/g) of the rows: the launch bench.py times and prices).  Round 1 grew forwards from cap rows, which
+    // left a small odd phase at the end (and the one before it carrying most of the corpus).
     const uint32_t g = std::min(k2_growth_cap(), std::max(2u, cap / (2u * k)));
-    uint64_t begin = 0, end = std::min<uint64_t>(n, cap);
+    std::vector<uint64_t> bounds;  // R_1 .. R_{P+1} = n
+    {
+        uint32_t P = 0;
+        for (uint64_t f = n; f > cap; f = (f + g - 1) / g) P++;
+        for (uint32_t j = 0; j <= P; j++) {
+            uint64_t div = 1;
+            for (uint32_t i = j; i < P; i++) div *= g;
+            uint64_t e = (n + div - 1) / div;
+            e = std::min<uint64_t>(n, (e + 255) / 256 * 256);
+            if (j == 0) e = std::min<uint64_t>(e, cap);  // the direct phase's slots are row offsets
+            if (bounds.empty() || e > bounds.back()) bounds.push_back(e);
+        }
+        if (bounds.empty() || bounds.back() < n) bounds.push_back(n);
+    }
+    size_t bi = 0;
+    uint64_t begin = 0, end = bounds[0];
     for (;;) {
         const bool last = end >= n;
         if (end > begin) {
@@ -769,7 +788,7 @@ int search_batched_path(const mvfgpu_corpus* c, uint8_t metric, const void* d_qu
         else HIP_TRY(launch_compact(cp, nq, last, s));
         if (last) break;
         begin = end;
-        end = std::min<uint64_t>(n, ((end * g + 255) / 256) * 256);
+        end = bounds[++bi];
     }
     if (approx) {  // exact scores of the kept candidates from the caller's f32 queries, final top-k
         RescoreParams rp{};

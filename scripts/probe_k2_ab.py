@@ -2,8 +2,8 @@
 
 For each BASELINE batched config the same resident corpus is searched with the variants interleaved, several
 rounds each; prints wall ms per search (device-resident queries and results) and the last phase's scan ms.
-Variants are environment switches libmvf_gpu reads per call:  MVF_K2_PP=0|1 (lockstep LDS-DMA kernel | ping-pong).
-usage: python scripts/probe_k2_ab.py [cfg4,cfg5,cfg3] [rounds]
+Variants are environment switches libmvf_gpu reads per call (MVF_K2_PP, MVF_K2_GROWTH, MVF_I8_SHADOW): see ALL_VARIANTS.
+usage: python scripts/probe_k2_ab.py [cfg4,cfg5,cfg3] [rounds] [variant,variant,...]
 """
 import os
 import sys
@@ -25,14 +25,17 @@ CFGS = {
     "cfg4z": (50_000_000, 768, 2, 1, 256),
     "cfg5b": (12_500_000, 1024, 1, 0, 1024),  # bf16-compatible f16 bit patterns (MVF_DIAG_BF16 builds)
 }
-ALL_VARIANTS = {"lockstep": {"MVF_K2_PP": "0", "MVF_K2_GROWTH": "8", "MVF_I8_SHADOW": None},
-                "pingpong": {"MVF_K2_PP": "1", "MVF_K2_GROWTH": "8", "MVF_I8_SHADOW": None},
+ALL_VARIANTS = {"lockstep": {"MVF_K2_PP": "0", "MVF_K2_GROWTH": None, "MVF_I8_SHADOW": "0"},   # f16 / native kernels, no int8 shadow
+                "pingpong": {"MVF_K2_PP": "1", "MVF_K2_GROWTH": None, "MVF_I8_SHADOW": "0"},
                 "default": {"MVF_K2_PP": None, "MVF_K2_GROWTH": None, "MVF_I8_SHADOW": None},
-                "pp_g4": {"MVF_K2_PP": "1", "MVF_K2_GROWTH": "4"}, "pp_g3": {"MVF_K2_PP": "1", "MVF_K2_GROWTH": "3"},
-                "pp_g16": {"MVF_K2_PP": "1", "MVF_K2_GROWTH": "16"},
+                "pp_g8": {"MVF_K2_PP": "1", "MVF_K2_GROWTH": "8", "MVF_I8_SHADOW": "0"},
+                "pp_g4": {"MVF_K2_PP": "1", "MVF_K2_GROWTH": "4", "MVF_I8_SHADOW": "0"},
+                "pp_g3": {"MVF_K2_PP": "1", "MVF_K2_GROWTH": "3", "MVF_I8_SHADOW": "0"},
+                "f16sel": {"MVF_K2_PP": None, "MVF_K2_GROWTH": None, "MVF_I8_SHADOW": "0"},
                 "i8s_ls": {"MVF_K2_PP": "0", "MVF_K2_GROWTH": None, "MVF_I8_SHADOW": "1"},
                 "i8s_pp": {"MVF_K2_PP": "1", "MVF_K2_GROWTH": None, "MVF_I8_SHADOW": "1"},
-                "ls_g4": {"MVF_K2_PP": "0", "MVF_K2_GROWTH": "4"}, "ls_g3": {"MVF_K2_PP": "0", "MVF_K2_GROWTH": "3"}}
+                "ls_g4": {"MVF_K2_PP": "0", "MVF_K2_GROWTH": "4", "MVF_I8_SHADOW": "0"},
+                "ls_g3": {"MVF_K2_PP": "0", "MVF_K2_GROWTH": "3", "MVF_I8_SHADOW": "0"}}
 VARIANTS = [(v, ALL_VARIANTS[v]) for v in (sys.argv[3].split(",") if len(sys.argv) > 3 else ["lockstep", "pingpong"])]
 
 

@@ -96,11 +96,67 @@ def traffic(fd, wd, out, rows, dim, dtype, metric, queries, k, comment):
                "roofline_traffic_bytes_per_launch": roof[0] if roof else None}, open(out, "w"), indent=1)
 
 
+def k2traffic(fd, wd, out, kname, alg_bytes, comment):
+    """HBM bytes of the LAST phase (largest FETCH_SIZE dispatch) of one K2 kernel: 2 x FETCH_SIZE + WRITE_SIZE of the same
+    dispatch ordinal in the separate WRITE_SIZE pass."""
+    def series(d, name):
+        out_ = defaultdict(list)
+        for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+            rows = sorted((r for r in csv.DictReader(open(f)) if r["Counter_Name"] == name), key=lambda r: int(r["Dispatch_Id"]))
+            per_disp = defaultdict(float)
+            order = []
+            for r in rows:
+                if kname in r["Kernel_Name"]:
+                    if r["Dispatch_Id"] not in per_disp:
+                        order.append(r["Dispatch_Id"])
+                    per_disp[r["Dispatch_Id"]] += float(r["Counter_Value"])
+            return [per_disp[dd] for dd in order]
+        return []
+    f, w = series(fd, "FETCH_SIZE"), series(wd, "WRITE_SIZE")
+    if not f:
+        return
+    i = max(range(len(f)), key=lambda j: f[j])
+    wv = w[i] if i < len(w) else 0.0
+    json.dump({"source": comment, "kernel_name_contains": kname, "dispatches_of_the_kernel": len(f), "last_phase_dispatch_ordinal": i,
+               "fetch_size_kib": f[i], "write_size_kib": wv,
+               "correction": "x2 on FETCH_SIZE (gfx950, 16-byte-per-lane streaming reads, global_load and global_load_lds alike; "
+                             "profiles/r02_fetch_size_calibration.json); WRITE_SIZE exact",
+               "algorithmic_bytes_per_launch": float(alg_bytes),
+               "roofline_traffic_bytes_per_launch": 2 * f[i] * 1024 + wv * 1024}, open(out, "w"), indent=1)
+
+
+def calibrate(d, log, out):
+    """Pairs the `expect <kernel> <bytes>` lines of scripts/calibrate_fetch_size.py with the largest FETCH_SIZE dispatch of
+    that kernel: known bytes / (FETCH_SIZE KiB x 1024) = the factor the counter has to be multiplied by."""
+    per = defaultdict(list)
+    for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] == "FETCH_SIZE":
+                per[r["Kernel_Name"]].append(float(r["Counter_Value"]))
+    rows = []
+    for line in open(log):
+        if not line.startswith("expect "):
+            continue
+        _, rest = line.split(" ", 1)
+        kname, want = rest.rsplit(" ", 1)
+        hits = [(k, max(v)) for k, v in per.items() if kname in k]
+        for k, v in hits:
+            rows.append({"kernel": k, "known_hbm_read_bytes_of_the_launch": int(want), "FETCH_SIZE_KiB": v,
+                         "FETCH_SIZE_bytes": v * 1024, "factor_known_over_counter": int(want) / (v * 1024)})
+    json.dump({"what": "FETCH_SIZE calibration on launches whose HBM read traffic is known (every block reads its rows once, "
+                       "no sharing between blocks); MI355X_MICROARCH.md says x2 for wide coalesced streaming reads on gfx950",
+               "rows": rows}, open(out, "w"), indent=1)
+
+
 if __name__ == "__main__":
     mode = sys.argv[1]
     if mode == "stats":
         stats(sys.argv[2], sys.argv[3], sys.argv[4])
     elif mode == "launches":
         launches(sys.argv[2], sys.argv[3], sys.argv[4], sys.argv[5])
+    elif mode == "calibrate":
+        calibrate(sys.argv[2], sys.argv[3], sys.argv[4])
+    elif mode == "k2traffic":
+        k2traffic(*sys.argv[2:])
     elif mode == "traffic":
         traffic(sys.argv[2], sys.argv[3], sys.argv[4], *[int(x) for x in sys.argv[5:11]], sys.argv[11])
