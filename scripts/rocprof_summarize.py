@@ -139,7 +139,7 @@ def calibrate(d, log, out):
             continue
         _, rest = line.split(" ", 1)
         kname, want = rest.rsplit(" ", 1)
-        hits = [(k, max(v)) for k, v in per.items() if kname in k]
+        hits = sorted(((k, max(v)) for k, v in per.items() if kname in k), key=lambda kv: -kv[1])[:1]  # the instantiation that ran the scan
         for k, v in hits:
             rows.append({"kernel": k, "known_hbm_read_bytes_of_the_launch": int(want), "FETCH_SIZE_KiB": v,
                          "FETCH_SIZE_bytes": v * 1024, "factor_known_over_counter": int(want) / (v * 1024)})
