@@ -225,6 +225,13 @@ __global__ void __launch_bounds__(512, 2) scan_mfma16_dma_kernel(Batch16Params p
         cs = cs + 1 == NSTAGE ? 0 : cs + 1;
         ds = ds + 1 == NSTAGE ? 0 : ds + 1;
         if (++c_kt == p.KT) {  // tile finished: its successor's first k-tiles are already in the ring
+#ifdef MVF_DIAG_NOEPI  // diagnostic build only: the k-loop alone (the sums are kept alive, nothing is selected)
+#pragma unroll
+            for (int i = 0; i < NI; i++)
+#pragma unroll
+                for (int j = 0; j < NJ; j++) asm volatile("" ::"v"(acc[i][j]));
+            if (false)
+#endif
             epilogue16<DT, METRIC, DIRECT, XS, BMQ, SH, WQ, WR, Cf::BR>(p, acc, c_nt, c_mt, wm, wn, lane, qa_s, qb_s, tau_s, thr_s,
                                                                         nullptr, nullptr, p.blk_cand ? bc_s : nullptr);
             zero_acc();
