@@ -385,37 +385,41 @@ def main():
             if cb:
                 result["cpu_baseline"] = cb
             result["cpu_baseline_best_effort"] = cpu_baseline_best_effort(args, oracle)
-        # ---- opt-in single-query path (scan path 4): K1 streams the scaled-f16 shadow of the rows (half the bytes),
-        # candidates within a proven margin are re-scored from the f32 rows -- same results, ~1.8x sooner.  Not the
-        # default: `value` above is the scan of the stored f32 rows.
+        # ---- opt-in single-query paths: K1 streams a SHADOW of the rows -- the scaled-f16 one (scan path 4, half the
+        # bytes) or the int8 one (scan path 6, a quarter) -- and every candidate within a proven margin is re-scored from
+        # the f32 rows: same results, 1.8x / 3x sooner.  Not the default (extra device memory, a shadow to build):
+        # `value` above is the scan of the stored f32 rows.
         if args.queries == 1 and args.dtype == 0 and not args.no_batched:
-            corpus.set_scan_path(4)
-            for _ in range(args.warmup):
-                step()
-            torch.cuda.synchronize()
-            corpus.set_profiling(True)
-            t0 = time.perf_counter()
-            for _ in range(args.steps):
-                outs = step()
-            torch.cuda.synchronize()
-            es_ = time.perf_counter() - t0
-            tms = corpus.last_timing()
-            corpus.set_profiling(False)
-            corpus.set_scan_path(0)
-            leg = {"workload": result["config"]["workload"], "scan_path": "4 (K1 streams the f16 shadow; exact re-score)",
-                   "value": float(args.rows) * args.steps / es_, "unit": "distance-ops/s", "steps": args.steps,
-                   "ms_per_step": es_ / args.steps * 1e3}
-            if tms.samples and tms.scan_ms_avg > 0 and tms.scan_kernel == 5:
-                achs = tms.scan_bytes / (tms.scan_ms_avg * 1e-3) / 1e9
-                leg["roofline"] = {"bound": "hbm", "achieved": achs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                   "frac": achs / HBM_PEAK_GBS, "traffic": None,
-                                   "kernel": "scan_stream_kernel (f16 shadow rows x per-row scale)",
-                                   "kernel_ms_avg": tms.scan_ms_avg, "launches_timed": tms.samples,
-                                   "algorithmic_bytes_per_launch": float(tms.scan_bytes)}
-            if not args.no_recall:
-                gi = outs[1].cpu().numpy().view(np.uint64)[sel]
-                leg["recall_at_k"] = sum(len(set(a.tolist()) & set(b.tolist())) for a, b in zip(gi, oidx)) / oidx.size
-            result["single_query_f16_shadow_stream"] = leg
+            for name, path, code, what in (("single_query_f16_shadow_stream", 4, 5, "f16 shadow rows x per-row scale"),
+                                           ("single_query_int8_shadow_stream", 6, 7, "int8 shadow rows x per-row scale")):
+                corpus.set_scan_path(path)
+                for _ in range(max(args.warmup, 1)):
+                    step()
+                torch.cuda.synchronize()
+                corpus.set_profiling(True)
+                t0 = time.perf_counter()
+                for _ in range(args.steps):
+                    outs = step()
+                torch.cuda.synchronize()
+                es_ = time.perf_counter() - t0
+                tms = corpus.last_timing()
+                corpus.set_profiling(False)
+                corpus.set_scan_path(0)
+                leg = {"workload": result["config"]["workload"],
+                       "scan_path": f"{path} (K1 streams the {'f16' if path == 4 else 'int8'} shadow; exact re-score)",
+                       "value": float(args.rows) * args.steps / es_, "unit": "distance-ops/s", "steps": args.steps,
+                       "ms_per_step": es_ / args.steps * 1e3}
+                if tms.samples and tms.scan_ms_avg > 0 and tms.scan_kernel == code:
+                    achs = tms.scan_bytes / (tms.scan_ms_avg * 1e-3) / 1e9
+                    leg["roofline"] = {"bound": "hbm", "achieved": achs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                       "frac": achs / HBM_PEAK_GBS, "traffic": None,
+                                       "kernel": f"scan_stream_kernel ({what})",
+                                       "kernel_ms_avg": tms.scan_ms_avg, "launches_timed": tms.samples,
+                                       "algorithmic_bytes_per_launch": float(tms.scan_bytes)}
+                if not args.no_recall:
+                    gi = outs[1].cpu().numpy().view(np.uint64)[sel]
+                    leg["recall_at_k"] = sum(len(set(a.tolist()) & set(b.tolist())) for a, b in zip(gi, oidx)) / oidx.size
+                result[name] = leg
         # ---- the metric's second leg: the same resident corpus, 1024 batched queries (MFMA path) ----------
         # Three ways, same results: the default (int8 MFMA kernel selecting on the int8 shadow of the rows, every row inside
         # a proven bound of the k-th best re-scored exactly from the f32 rows), the f16 MFMA kernel on the scaled-f16

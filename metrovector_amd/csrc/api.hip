@@ -108,6 +108,9 @@ struct mvfgpu_corpus {
     mutable hipEvent_t qs_redo_ev = nullptr;
     mutable bool qs_redo_pending = false, qs_disabled = false;
     mutable uint32_t qs_redo_nq = 0;
+    // the same feedback for the int8 shadow STREAMED for 2..4 queries: too few per search to judge one, so a running count
+    mutable bool qs_redo_streamed = false, qs_stream_disabled = false;
+    mutable uint32_t qs_stream_seen = 0, qs_stream_redo = 0;
     mutable const uint32_t* last_redo_cnt = nullptr;  // device: the count the newest repair pass produced
     mutable bool xnorm_ready = false;
     mutable uint32_t bstate_slots = 0;    // queries the K2 state arrays are armed for
@@ -204,6 +207,15 @@ const void* scan_kernel(uint8_t dtype, int metric, int G, int nqv, bool redo = f
 struct ShadowStream {
     const unsigned char* rows;
     const float* xscale;
+    // int8 shadow (dt2x unit) only: prepared int8 queries `qstride` bytes apart, their scale / norm, the rows' norm array
+    bool i8;
+    const unsigned char* qprep;
+    const float *qaux0, *qaux1, *xrow;
+    uint32_t qstride;
+    // ... and select_final's margin mode instead of the k best: every row within 2 delta[q] of the rank_k-th best
+    const float* delta;
+    uint32_t *tau, *overflow;
+    uint32_t rank_k;
     uint32_t pitch, V, J;
     int G;
     uint64_t* cand;   // [nq][cand_cap]
@@ -215,11 +227,12 @@ int search_stream_path(const mvfgpu_corpus* c, uint8_t metric, const void* d_que
                        float* d_scores, uint64_t* d_indices, int32_t* d_raw, hipStream_t s, bool profile = true,
                        const ShadowStream* alt = nullptr) {
     const uint32_t kcap = next_pow2(k);
-    const uint8_t kdtype = alt ? (uint8_t)MVF_DTYPE_FLOAT16 : c->dtype;
+    const bool alt8 = alt && alt->i8;
+    const uint8_t kdtype = alt8 ? (uint8_t)MVF_DTYPE_INT8 : alt ? (uint8_t)MVF_DTYPE_FLOAT16 : c->dtype;
     const uint32_t kV = alt ? alt->V : c->V;
 
     mvfgpu_timing tm{};
-    tm.scan_kernel = alt ? 5u : 1u;
+    tm.scan_kernel = alt8 ? 7u : alt ? 5u : 1u;
     bool first = true;
     mvfgpu_corpus::ProfSlot* ps = nullptr;
     if (c->profiling && profile) {
@@ -230,7 +243,7 @@ int search_stream_path(const mvfgpu_corpus* c, uint8_t metric, const void* d_que
     }
 
     for (uint32_t q0 = 0; q0 < nq;) {
-        int nqv = (nq - q0) >= 2 && !alt ? 4 : 1;
+        int nqv = (nq - q0) >= 2 && (!alt || alt8) ? 4 : 1;
         int G;
         uint32_t J;
         choose_group(kV, nqv, &G, &J);  // the lane-group width depends on the queries per pass
@@ -249,7 +262,9 @@ int search_stream_path(const mvfgpu_corpus* c, uint8_t metric, const void* d_que
 
         uint32_t nblocks = 0;
         if (nchunks > 0) {
-            const void* kfn = alt ? scan_stream_kernel_ptr_dt1x(metric, G, nqv) : scan_kernel(c->dtype, metric, G, nqv);
+            const void* kfn = alt8  ? scan_stream_kernel_ptr_dt2x(metric, G, nqv)
+                              : alt ? scan_stream_kernel_ptr_dt1x(metric, G, nqv)
+                                    : scan_kernel(c->dtype, metric, G, nqv);
             if (lds > 48 * 1024)
                 HIP_TRY(hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             int occ = 0;
@@ -261,7 +276,13 @@ int search_stream_path(const mvfgpu_corpus* c, uint8_t metric, const void* d_que
             ScanParams sp{};
             sp.rows = alt ? alt->rows : c->d_rows;
             sp.xscale = alt ? alt->xscale : nullptr;
-            sp.queries = d_queries;
+            sp.queries = alt8 ? static_cast<const void*>(alt->qprep) : d_queries;
+            if (alt8) {
+                sp.qaux0 = alt->qaux0;
+                sp.qaux1 = alt->qaux1;
+                sp.xrow = alt->xrow;
+                sp.qstride = alt->qstride;
+            }
             sp.tomb = static_cast<const uint32_t*>(c->tomb.p);
             sp.cand = static_cast<uint64_t*>(c->cand.p);
             sp.n = (uint32_t)c->n;
@@ -277,7 +298,8 @@ int search_stream_path(const mvfgpu_corpus* c, uint8_t metric, const void* d_que
             sp.chunk_rows = chunk_rows;
             sp.nchunks = nchunks;
             if (ps && first) HIP_TRY(hipEventRecord(ps->e[0], s));
-            if (alt) HIP_TRY(scan_stream_launch_dt1x(sp, metric, G, nqv, dim3(nblocks), lds, s));
+            if (alt8) HIP_TRY(scan_stream_launch_dt2x(sp, metric, G, nqv, dim3(nblocks), lds, s));
+            else if (alt) HIP_TRY(scan_stream_launch_dt1x(sp, metric, G, nqv, dim3(nblocks), lds, s));
             else HIP_TRY(scan_launch(c->dtype, sp, metric, G, nqv, dim3(nblocks), lds, s));
             if (ps && first) {
                 HIP_TRY(hipEventRecord(ps->e[1], s));
@@ -303,6 +325,13 @@ int search_stream_path(const mvfgpu_corpus* c, uint8_t metric, const void* d_que
                 fp.out_cand = alt->cand + (size_t)q0 * alt->cand_cap;
                 fp.out_cnt = alt->cnt + q0;
                 fp.cand_cap = alt->cand_cap;
+                if (alt8) {
+                    fp.delta = alt->delta + q0;
+                    fp.out_tau = alt->tau + q0;
+                    fp.out_overflow = alt->overflow + q0;
+                    fp.keep_cap = alt->cand_cap / 2;
+                    fp.margin_rank = alt->rank_k;
+                }
             } else {
                 fp.out_scores = d_scores + (size_t)q0 * k;
                 fp.out_indices = d_indices + (size_t)q0 * k;
@@ -399,7 +428,7 @@ constexpr uint32_t kBatchCapQS = 8192;  // candidate slots per query with int8 s
 bool qs_wanted(const mvfgpu_corpus* c) {
     if (is_int_dtype(c->dtype) || c->n == 0) return false;
     if ((size_t)((c->dim + 7u) & ~7u) * 4 + kBatchCapQS * 4 > 64 * 1024) return false;  // re-scoring: query + candidates in LDS
-    if (c->scan_path == 5) return true;
+    if (c->scan_path == 5 || c->scan_path == 6) return true;
     if (c->scan_path != 0 && c->scan_path != 4) return false;
     if (c->qs_disabled || c->shadow8_state < 0) return false;
     const char* e = getenv("MVF_I8_SHADOW");
@@ -413,12 +442,42 @@ void qs_feedback_poll(const mvfgpu_corpus* c) {
         return;
     }
     c->qs_redo_pending = false;
+    if (c->qs_redo_streamed) {
+        c->qs_stream_seen += c->qs_redo_nq;
+        c->qs_stream_redo += *c->qs_redo_host;
+        if (c->qs_stream_redo >= 3 && c->qs_stream_redo * 4 > c->qs_stream_seen) {
+            c->qs_stream_disabled = true;
+            if (getenv("MVF_DEBUG_REPAIR"))
+                fprintf(stderr, "[mvfgpu] int8-shadow streaming switched off for this corpus: %u of %u queries needed the repair path\n",
+                        c->qs_stream_redo, c->qs_stream_seen);
+        } else if (c->qs_stream_seen >= 1024) {
+            c->qs_stream_seen /= 2;
+            c->qs_stream_redo /= 2;
+        }
+        return;
+    }
     if ((uint64_t)*c->qs_redo_host * 8 > c->qs_redo_nq && *c->qs_redo_host >= 4) {
         c->qs_disabled = true;
         if (getenv("MVF_DEBUG_REPAIR"))
             fprintf(stderr, "[mvfgpu] int8-shadow selection switched off for this corpus: %u of %u queries needed the repair path\n",
                     *c->qs_redo_host, c->qs_redo_nq);
     }
+}
+
+// ... and the request for it: the repair count of the search just enqueued, copied to pinned memory behind an event
+// (never waited for).
+int qs_feedback_post(const mvfgpu_corpus* c, uint32_t nq, bool streamed, hipStream_t s) {
+    if (c->qs_redo_pending || !c->repair.p) return MVF_OK;
+    if (!c->qs_redo_host) {
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&c->qs_redo_host), 64, hipHostMallocDefault));
+        HIP_TRY(hipEventCreateWithFlags(&c->qs_redo_ev, hipEventDisableTiming));
+    }
+    HIP_TRY(hipMemcpyAsync(c->qs_redo_host, c->last_redo_cnt, 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipEventRecord(c->qs_redo_ev, s));
+    c->qs_redo_pending = true;
+    c->qs_redo_nq = nq;
+    c->qs_redo_streamed = streamed;
+    return MVF_OK;
 }
 
 hipError_t ensure_shadow8(const mvfgpu_corpus* c, hipStream_t s, bool insist) {
@@ -590,7 +649,7 @@ int search_batched_path(const mvfgpu_corpus* c, uint8_t metric, const void* d_qu
     if (qs_wanted(c)) {  // int8 shadow: selection at the int8 MFMA rate (Float32 and Float16 corpora)
         int rc = ensure_norms(c, s);
         if (rc != MVF_OK) return rc;
-        HIP_TRY(ensure_shadow8(c, s, c->scan_path == 5));
+        HIP_TRY(ensure_shadow8(c, s, c->scan_path == 5 || c->scan_path == 6));
         use_qs = c->shadow8_state == 1;
     }
     if (!use_qs && c->dtype == MVF_DTYPE_FLOAT32 && c->scan_path != 2 && (c->scan_path == 3 || shadow_enabled()) && rescore_fits) {
@@ -816,16 +875,7 @@ int search_batched_path(const mvfgpu_corpus* c, uint8_t metric, const void* d_qu
     }
 
     int rc = repair_flagged_queries(c, metric, d_queries, nq, nq_pad, k, overflow, d_scores, d_indices, d_raw, s);
-    if (rc == MVF_OK && use_qs && c->scan_path != 5 && !c->qs_redo_pending && c->repair.p) {  // feedback, never waited for here
-        if (!c->qs_redo_host) {
-            HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&c->qs_redo_host), 64, hipHostMallocDefault));
-            HIP_TRY(hipEventCreateWithFlags(&c->qs_redo_ev, hipEventDisableTiming));
-        }
-        HIP_TRY(hipMemcpyAsync(c->qs_redo_host, c->last_redo_cnt, 4, hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipEventRecord(c->qs_redo_ev, s));
-        c->qs_redo_pending = true;
-        c->qs_redo_nq = nq;
-    }
+    if (rc == MVF_OK && use_qs && c->scan_path != 5 && c->scan_path != 6) rc = qs_feedback_post(c, nq, false, s);
     return rc;
 }
 
@@ -912,6 +962,97 @@ int search_stream_shadow_path(const mvfgpu_corpus* c, uint8_t metric, const void
     return repair_flagged_queries(c, metric, d_queries, nq, nq_pad, k, overflow, d_scores, d_indices, d_raw, s);
 }
 
+// One to four queries on a Float32 / Float16 corpus STREAM ITS INT8 SHADOW (dim bytes per row: a quarter / half of the
+// stored rows) through K1's dt2x unit -- exact i32 dots, float keys -- with the int8 selection's proven per-query bound
+// (shadow_i8.hip).  The bound is ~0.25 sigma of the score distribution -- 6-10 x k rows on the benchmark's data, more
+// than K1's selection can carry as "the k' best" -- so the selection is by BLOCK: every K1 block keeps the max(k, 32)
+// best approximate scores of ITS rows (n / ~1000 of them), select_final's margin mode finds the k-th best of all lists
+// and gathers every entry within 2 delta of it; a list that was cut inside the bound (rows beyond the cut may be inside
+// too: clustered rows, tiny corpora) or more than 2048 rows inside it flag the query, which the exact K1 then redoes.
+// rescore_kernel re-scores what was gathered from the stored rows and the f32 query.
+uint32_t stream_qs_klist(uint32_t k) { return std::max(k, 32u); }
+
+int search_stream_qs_path(const mvfgpu_corpus* c, uint8_t metric, const void* d_queries, uint32_t nq, uint32_t k,
+                          float* d_scores, uint64_t* d_indices, int32_t* d_raw, hipStream_t s) {
+    const uint32_t cap = kBatchCap;
+    const uint32_t nq_pad = (nq + 255u) & ~255u;
+    const uint32_t n = (uint32_t)c->n;
+    int rc = ensure_bstate(c, nq_pad, s);
+    if (rc == MVF_OK) rc = ensure_norms(c, s);
+    if (rc != MVF_OK) return rc;
+    uint32_t* tau = static_cast<uint32_t*>(c->bstate.p);
+    uint32_t* cnt = tau + c->bstate_slots;
+    uint32_t* overflow = cnt + c->bstate_slots;
+    HIP_TRY(c->bcand.reserve((size_t)nq_pad * cap * 8));
+    const uint32_t KPB = shadow8_pitch(c->dim);
+    HIP_TRY(c->bq.reserve((size_t)nq_pad * KPB + (size_t)nq_pad * 12 + 64));
+    unsigned char* qprep = static_cast<unsigned char*>(c->bq.p);
+    float* qaux0 = reinterpret_cast<float*>(qprep + (size_t)nq_pad * KPB);
+    float* qaux1 = qaux0 + nq_pad;
+    float* qdelta = qaux1 + nq_pad;
+    const size_t nn = norm_stride(n);
+    const float* xn = static_cast<const float*>(c->xnorm.p);
+    const float* xxmax = xn + norm_max_at(n);
+    HIP_TRY(launch_prep_queries_i8s(static_cast<const float*>(d_queries), nq, nq, c->dim, KPB, metric,
+                                    static_cast<const float*>(c->qs_stats.p), xxmax, qprep, qaux0, qaux1, qdelta, s));
+
+    ShadowStream alt{};
+    alt.i8 = true;
+    alt.rows = static_cast<const unsigned char*>(c->shadow8.p);
+    alt.xscale = static_cast<const float*>(c->xscale8.p);
+    alt.qprep = qprep;
+    alt.qaux0 = qaux0;
+    alt.qaux1 = qaux1;
+    alt.xrow = metric == MVF_METRIC_L2 ? xn + nn : xn;  // sum x^2 | |x| of the stored rows
+    alt.qstride = KPB;
+    alt.pitch = KPB;
+    alt.V = KPB / 16;
+    alt.cand = static_cast<uint64_t*>(c->bcand.p);
+    alt.cnt = cnt;
+    alt.cand_cap = cap;
+    alt.delta = qdelta;
+    alt.tau = tau;
+    alt.overflow = overflow;
+    alt.rank_k = k;
+    rc = search_stream_path(c, metric, d_queries, nq, stream_qs_klist(k), nullptr, nullptr, nullptr, s, /*profile=*/true, &alt);
+    if (rc != MVF_OK) return rc;
+
+    RescoreParams rp{};
+    rp.cand = alt.cand;
+    rp.cnt = cnt;
+    rp.tau = tau;
+    rp.cap = cap;
+    rp.k = k;
+    rp.queries = static_cast<const float*>(d_queries);
+    rp.rows = c->d_rows;
+    rp.pitch = c->pitch;
+    rp.dim = c->dim;
+    rp.dtype = c->dtype;
+    rp.index_base = c->index_base;
+    rp.ids = static_cast<const uint64_t*>(c->ids.p);
+    rp.out_scores = d_scores;
+    rp.out_indices = d_indices;
+    rp.out_raw = d_raw;
+    HIP_TRY(launch_rescore(rp, metric, nq, s));
+    rc = repair_flagged_queries(c, metric, d_queries, nq, nq_pad, k, overflow, d_scores, d_indices, d_raw, s);
+    if (rc == MVF_OK && c->scan_path != 6) rc = qs_feedback_post(c, nq, true, s);
+    return rc;
+}
+
+// The int8 shadow is streamed by default for 2..4 queries (a batch this small pays a whole padded 64-query MFMA tile
+// otherwise: 2.6 ms against K1's ~1.4 on 10M x 768) once the corpus holds >= 1 GiB of rows, for one query on request
+// (scan path 6 -- the default for one query stays the exact scan of the stored rows: no extra memory, nothing to
+// build).  MVF_STREAM_I8=0 opts out.
+bool stream_qs_wanted(const mvfgpu_corpus* c, uint32_t nq, uint32_t k) {
+    if (nq == 0 || nq > 4 || !qs_wanted(c) || c->scan_path == 5) return false;
+    if (const char* e = getenv("MVF_STREAM_I8"))
+        if (atoi(e) == 0) return false;
+    if (c->scan_path == 6) return true;
+    if (c->scan_path != 0 || nq == 1 || c->qs_stream_disabled) return false;
+    const uint64_t bytes = c->n * (uint64_t)c->dim * elem_size(c->dtype);
+    return bytes >= (1ull << 30);
+}
+
 // Scan path 4 applies to one or two queries on a Float32 corpus whose shadow exists (or can be built now).
 bool stream_shadow_wanted(const mvfgpu_corpus* c, uint32_t nq) {
     if (c->dtype != MVF_DTYPE_FLOAT32 || nq > 2 || c->n == 0) return false;
@@ -930,6 +1071,7 @@ bool use_batched_path(const mvfgpu_corpus* c, uint8_t metric, uint32_t nq) {
         supported = false;  // the re-scoring kernel keeps the query in LDS
     if (!supported) return false;
     if (c->scan_path == 2 || c->scan_path == 3 || (c->scan_path == 5 && !is_int_dtype(c->dtype))) return true;
+    if (c->scan_path == 6 && !is_int_dtype(c->dtype)) return nq > 4;
     // K1 takes 2..4 queries per HBM pass (5.7 / 6.3 / 7.4 ms on 10M x 768 f32 / 12.5M x 1024 f16 / 50M x 768 int8);
     // K2 costs a flat padded-tile time: with the 64-query tile 3.65 ms (f16 kernel on the f32 corpus' shadow), 4.9 ms
     // (f16 corpus), 7.6 ms (int8) up to 64 queries; the exact f32 kernel 15.3 ms up to 128 -- plus ~0.2 ms of phase
@@ -1446,13 +1588,24 @@ int mvfgpu_search_device(const mvfgpu_corpus* c, uint8_t metric, const void* d_q
         wps->whole = false;
         HIP_TRY(hipEventRecord(wps->e[3], s));
     }
-    bool shadow_stream = false;
-    if (stream_shadow_wanted(c, nq)) {
+    bool shadow_stream = false, qs_stream = false;
+    if (stream_qs_wanted(c, nq, k)) {
+        qs_feedback_poll(c);
+        if (stream_qs_wanted(c, nq, k)) {  // still, after the look at the last search's repairs
+            rc = ensure_norms(c, s);
+            if (rc != MVF_OK) return rc;
+            hipError_t e = ensure_shadow8(c, s, c->scan_path == 6);
+            if (e != hipSuccess) return fail(MVF_ERR_DEVICE, std::string("int8 shadow build: ") + hipGetErrorString(e));
+            qs_stream = c->shadow8_state == 1;
+        }
+    }
+    if (!qs_stream && stream_shadow_wanted(c, nq)) {
         hipError_t e = ensure_shadow(c, s, c->scan_path == 4);
         if (e != hipSuccess) return fail(MVF_ERR_DEVICE, std::string("shadow build: ") + hipGetErrorString(e));
         shadow_stream = c->shadow_state == 1;
     }
-    rc = shadow_stream                       ? search_stream_shadow_path(c, metric, d_queries, nq, k, d_scores, d_indices, d_raw, s)
+    rc = qs_stream                           ? search_stream_qs_path(c, metric, d_queries, nq, k, d_scores, d_indices, d_raw, s)
+         : shadow_stream                     ? search_stream_shadow_path(c, metric, d_queries, nq, k, d_scores, d_indices, d_raw, s)
          : use_batched_path(c, metric, nq) ? search_batched_path(c, metric, d_queries, nq, k, d_scores, d_indices, d_raw, s)
                                            : search_stream_path(c, metric, d_queries, nq, k, d_scores, d_indices, d_raw, s);
     if (rc != MVF_OK) return rc;
@@ -1665,7 +1818,7 @@ int mvfgpu_last_timing(const mvfgpu_corpus* c, mvfgpu_timing* out) {
 
 int mvfgpu_set_scan_path(mvfgpu_corpus* c, int path) {
     if (!c) return fail(MVF_ERR_INVALID_ARGUMENT, "corpus is NULL");
-    if (path < 0 || path > 5) return fail(MVF_ERR_INVALID_ARGUMENT, "path must be 0..5");
+    if (path < 0 || path > 6) return fail(MVF_ERR_INVALID_ARGUMENT, "path must be 0..6");
     std::lock_guard<std::mutex> lk(c->mu);
     c->scan_path = path;
     return MVF_OK;

@@ -24,6 +24,15 @@ struct SelectParams {
     uint64_t* out_cand;     // nullable
     uint32_t* out_cnt;
     uint32_t cand_cap;
+    // margin mode (streaming over the int8 shadow; out_cand set): the lists are each block's k best APPROXIMATE scores;
+    // out_cand receives EVERY entry within 2 delta[q] of the k-th best of them all (at most keep_cap), out_tau[q] the
+    // key of that bound; out_overflow[q] is raised when more than keep_cap entries are inside it or when a block's
+    // list was cut inside it (rows beyond the cut may be inside too): the query is then redone exactly
+    const float* delta;     // nullable; [nq]
+    uint32_t* out_tau;
+    uint32_t* out_overflow;
+    uint32_t keep_cap;
+    uint32_t margin_rank;   // the caller's k (<= k, the length the lists were cut at)
     // repair launches: block b serves query redo_list[redo_base + b] (its lists are the b-th of the launch) and exits
     // at once when *redo_cnt <= redo_base + b
     const uint32_t* redo_list;  // nullable

@@ -107,6 +107,35 @@ __global__ void __launch_bounds__(1024) select_final_kernel(SelectParams p) {
         }
         m = kcur;
     }
+    if (p.delta) {  // margin mode: everything within 2 delta of the k-th best, from every list
+        __shared__ uint32_t cut_s;
+        uint32_t tkey = kNanKey;  // fewer than k rows in all: everything is a candidate
+        if (m >= p.margin_rank) {
+            const float vk = score_from_key((uint32_t)(buf[p.margin_rank - 1] >> 32), p.metric), d = 2.0f * p.delta[q];
+            tkey = key_from_score(p.metric == MVF_METRIC_L2 ? vk + d : vk - d, p.metric);
+        }
+        __syncthreads();
+        if (tid == 0) *cnt = 0, cut_s = 0;
+        __syncthreads();
+        for (uint32_t l = tid; l < p.nlists; l += 1024) {
+            const uint64_t* li = lists + (size_t)l * p.kcap;
+            for (uint32_t i = 0; i < p.k; i++) {
+                const uint64_t c = li[i];
+                if (c == kPadComposite || (tkey != kNanKey && (uint32_t)(c >> 32) > tkey)) break;
+                const uint32_t slot = atomicAdd(cnt, 1u);
+                if (slot < p.keep_cap) p.out_cand[(size_t)q * p.cand_cap + slot] = c;
+                if (i + 1 == p.k) cut_s = 1;  // the block kept k rows and the last of them is still inside the bound
+            }
+        }
+        __syncthreads();
+        if (tid == 0) {
+            const uint32_t inside = *cnt;
+            if (inside > p.keep_cap || cut_s) p.out_overflow[q] = 1u;
+            p.out_cnt[q] = inside < p.keep_cap ? inside : p.keep_cap;
+            p.out_tau[q] = tkey;
+        }
+        return;
+    }
     if (p.out_cand) {
         const uint32_t keep = m < p.k ? m : p.k;
         for (uint32_t i = tid; i < keep; i += 1024) p.out_cand[(size_t)q * p.cand_cap + i] = buf[i];

@@ -9,7 +9,13 @@ namespace mvf {
 struct ScanParams {
     const unsigned char* rows;  // device rows, `pitch` bytes apart, 16-B aligned
     const void* queries;        // device [nq_total][dim]: f32, or the space's int type
-    const float* xscale;        // dt1x only: the rows are the scaled-f16 shadow of a Float32 corpus, row r times xscale[r]
+    const float* xscale;        // dt1x / dt2x: the rows are a scaled shadow (f16 of a Float32 corpus / int8 of a float corpus), row r times xscale[r]
+    // dt2x (int8 shadow, float scores): the queries are the int8 rows the query preparation wrote, `qstride` bytes apart,
+    // with their scale qaux0[q] and norm qaux1[q] = |q|; xrow[r] = |x_r| (cosine) / sum x_r^2 (L2) of the STORED row
+    const float* xrow;
+    const float* qaux0;
+    const float* qaux1;
+    uint32_t qstride;
     const uint32_t* tomb;       // deletion bitmap, bit (r & 31) of word (r >> 5) = local row r is deleted; NULL = none
     uint64_t* cand;             // out: [launch queries][gridDim.x][kcap] sorted composites, ~0-padded
     uint32_t n;                 // rows in the shard
@@ -42,13 +48,14 @@ MVF_DECL_SCAN(1)
 MVF_DECL_SCAN(2)
 MVF_DECL_SCAN(3)
 MVF_DECL_SCAN(1x)  // Float16 rows of an f32 corpus' shadow, scaled back by ScanParams::xscale; nqv = 1 only
+MVF_DECL_SCAN(2x)  // Int8 shadow rows of a float corpus: exact i32 dot, float keys dot * xscale[r] * qaux0[q]; nqv = 1 or 4
 #undef MVF_DECL_SCAN
 
 // rows per chunk for a lane-group width G (multiple of the 16*64/G rows a block covers per step)
 inline uint32_t scan_chunk_rows(int G) { return G == 1 ? 1024u : 512u; }
 
 // bytes of dynamic LDS the kernel carves
-inline size_t scan_lds_bytes(int dtype, int G, uint32_t J, int nqv, uint32_t pmax) {
+inline size_t scan_lds_bytes(int dtype, int G, uint32_t J, int nqv, uint32_t pmax) {  // dtype: of the rows the kernel reads
     const uint32_t qb = (dtype == 0) ? 16u : (dtype == 1) ? 32u : 16u;
     size_t q = ((size_t)nqv * J * G * qb + 15u) & ~(size_t)15u;
     return q + (size_t)nqv * pmax * 8u + (size_t)nqv * 32u;
