@@ -110,7 +110,7 @@ hipError_t launch_compact(const CompactParams& p, uint32_t nq, bool final_stage,
 
 // approximate selection: margin-aware compaction + exact re-scoring of the kept candidates
 struct RescoreParams {
-    const uint64_t* cand;       // [nq][cap] sorted approximate composites, first cnt[q] valid
+    uint64_t* cand;             // [nq][cap] approximate composites, first cnt[q] valid; keys replaced by the exact ones
     uint32_t* cnt;              // re-armed to 0
     uint32_t* tau;              // re-armed to "none"
     uint32_t cap, k;

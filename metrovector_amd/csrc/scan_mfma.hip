@@ -589,19 +589,23 @@ __global__ void __launch_bounds__(1024) compact_margin_kernel(CompactParams p) {
 }
 
 // ---- exact re-scoring of the kept candidates, final top-k ------------------------------------------------------
-// One block per query, one wave per candidate row: the score is recomputed from the caller's f32 query and the
-// stored row with K1's formulas (sqrt(sum (q-x)^2); sum q x; sum q x / (sqrt(qq) sqrt(xx))).
+// Two kernels.  rescore_score_kernel: one WAVE per candidate row, four rows in flight per wave -- the score is
+// recomputed from the caller's f32 query and the stored row with K1's formulas (sqrt(sum (q-x)^2); sum q x;
+// sum q x / (sqrt(qq) sqrt(xx))) and the candidate's key is replaced in place.  grid (B, nq): block b of a query
+// takes the 16-candidate slices b, b + B, ... (round 2 had one block per query walk all of them, four at a time:
+// 0.46 ms for the ~700 candidates of an int8-selected query whatever the batch size -- a fifth of a 64-query search).
+// rescore_select_kernel: one block per query sorts the re-scored candidates and formats the k best.
 template <int METRIC>
-__global__ void __launch_bounds__(256) rescore_kernel(RescoreParams p) {
+__global__ void __launch_bounds__(256) rescore_score_kernel(RescoreParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t dim4 = (p.dim + 7u) & ~7u;  // zero-padded to a multiple of 8 (one f16 vector)
     float* qs = reinterpret_cast<float*>(smem);
-    uint64_t* buf = reinterpret_cast<uint64_t*>(qs + dim4);
     __shared__ float qq_part[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const uint32_t q = blockIdx.x;
+    const uint32_t q = blockIdx.y;
     const uint32_t keep_cap = p.cap / 2;
     const uint32_t m = min(p.cnt[q], keep_cap);
+    if (blockIdx.x * 16u >= m) return;  // block-uniform
     float qq = 0.f;
     for (uint32_t e = tid; e < dim4; e += 256) {
         const float v = e < p.dim ? p.queries[(size_t)q * p.dim + e] : 0.f;
@@ -614,59 +618,87 @@ __global__ void __launch_bounds__(256) rescore_kernel(RescoreParams p) {
     }
     __syncthreads();
     if (METRIC == MVF_METRIC_COSINE) qq = (qq_part[0] + qq_part[1]) + (qq_part[2] + qq_part[3]);
-    const uint64_t* c = p.cand + (size_t)q * p.cap;
+    uint64_t* c = p.cand + (size_t)q * p.cap;
     const uint32_t V = p.pitch / 16;
-    for (uint32_t ci = wave; ci < m; ci += 4) {
-        const uint32_t r = (uint32_t)c[ci];
-        const unsigned char* rp = p.rows + (size_t)r * p.pitch;
-        float s = 0.f, xx = 0.f;
-        auto term = [&](float qv, float xv) __attribute__((always_inline)) {
-            if (METRIC == MVF_METRIC_L2) {
-                const float t = qv - xv;
-                s = fmaf(t, t, s);
-            } else {
-                s = fmaf(qv, xv, s);
-                if (METRIC == MVF_METRIC_COSINE) xx = fmaf(xv, xv, xx);
-            }
-        };
+    for (uint32_t c0 = blockIdx.x * 16u; c0 < m; c0 += gridDim.x * 16u) {
+        // this wave's four candidates: c0 + wave * 4 + u (a row past the end repeats the slice's first; not written)
+        uint32_t r[4];
+        const unsigned char* rp[4];
+        float s[4], xx[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const uint32_t ci = c0 + (uint32_t)wave * 4u + u;
+            r[u] = (uint32_t)c[ci < m ? ci : c0];
+            rp[u] = p.rows + (size_t)r[u] * p.pitch;
+            s[u] = 0.f;
+            xx[u] = 0.f;
+        }
         for (uint32_t v = lane; v < V; v += 64) {
-            const u32x4 x = *reinterpret_cast<const u32x4*>(rp + (size_t)v * 16);
-            if (p.dtype == MVF_DTYPE_FLOAT32) {
-                const f32x4 qv = *reinterpret_cast<const f32x4*>(qs + v * 4);
+            u32x4 x[4];
 #pragma unroll
-                for (int w = 0; w < 4; w++) term(qv[w], __uint_as_float(x[w]));
-            } else {
+            for (int u = 0; u < 4; u++) x[u] = *reinterpret_cast<const u32x4*>(rp[u] + (size_t)v * 16);
 #pragma unroll
-                for (int w = 0; w < 4; w++) {
-                    term(qs[v * 8 + 2 * w], __half2float(__ushort_as_half((unsigned short)(x[w] & 0xFFFFu))));
-                    term(qs[v * 8 + 2 * w + 1], __half2float(__ushort_as_half((unsigned short)(x[w] >> 16))));
+            for (int u = 0; u < 4; u++) {
+                auto term = [&](float qv, float xv) __attribute__((always_inline)) {
+                    if (METRIC == MVF_METRIC_L2) {
+                        const float t = qv - xv;
+                        s[u] = fmaf(t, t, s[u]);
+                    } else {
+                        s[u] = fmaf(qv, xv, s[u]);
+                        if (METRIC == MVF_METRIC_COSINE) xx[u] = fmaf(xv, xv, xx[u]);
+                    }
+                };
+                if (p.dtype == MVF_DTYPE_FLOAT32) {
+                    const f32x4 qv = *reinterpret_cast<const f32x4*>(qs + v * 4);
+#pragma unroll
+                    for (int w = 0; w < 4; w++) term(qv[w], __uint_as_float(x[u][w]));
+                } else {
+#pragma unroll
+                    for (int w = 0; w < 4; w++) {
+                        term(qs[v * 8 + 2 * w], __half2float(__ushort_as_half((unsigned short)(x[u][w] & 0xFFFFu))));
+                        term(qs[v * 8 + 2 * w + 1], __half2float(__ushort_as_half((unsigned short)(x[u][w] >> 16))));
+                    }
                 }
             }
         }
-        for (int off = 32; off > 0; off >>= 1) {
-            s += __shfl_xor(s, off, 64);
-            if (METRIC == MVF_METRIC_COSINE) xx += __shfl_xor(xx, off, 64);
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            for (int off = 32; off > 0; off >>= 1) {
+                s[u] += __shfl_xor(s[u], off, 64);
+                if (METRIC == MVF_METRIC_COSINE) xx[u] += __shfl_xor(xx[u], off, 64);
+            }
+            float sc = s[u];
+            if (METRIC == MVF_METRIC_L2) sc = sqrtf(s[u]);
+            if (METRIC == MVF_METRIC_COSINE) {
+                const float den = sqrtf(qq) * sqrtf(xx[u]);
+                sc = den > 0.0f ? s[u] / den : 0.0f;
+            }
+            const uint32_t ci = c0 + (uint32_t)wave * 4u + u;
+            if (lane == 0 && ci < m) c[ci] = ((uint64_t)key_from_score(sc, METRIC) << 32) | r[u];
         }
-        float sc = s;
-        if (METRIC == MVF_METRIC_L2) sc = sqrtf(s);
-        if (METRIC == MVF_METRIC_COSINE) {
-            const float den = sqrtf(qq) * sqrtf(xx);
-            sc = den > 0.0f ? s / den : 0.0f;
-        }
-        if (lane == 0) buf[ci] = ((uint64_t)key_from_score(sc, METRIC) << 32) | r;
     }
+}
+
+__global__ void __launch_bounds__(1024) rescore_select_kernel(RescoreParams p, int metric) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint64_t* buf = reinterpret_cast<uint64_t*>(smem);
+    const int tid = threadIdx.x;
+    const uint32_t q = blockIdx.x;
+    const uint32_t keep_cap = p.cap / 2;
+    const uint32_t m = min(p.cnt[q], keep_cap);
+    const uint64_t* c = p.cand + (size_t)q * p.cap;
     const uint32_t P2 = next_pow2(m < 2 ? 2 : m);
-    for (uint32_t i = m + tid; i < P2; i += 256) buf[i] = kPadComposite;
+    for (uint32_t i = tid; i < P2; i += 1024) buf[i] = i < m ? c[i] : kPadComposite;
     __syncthreads();
-    bitonic_sort_u64<256>(buf, P2, tid);
-    for (uint32_t i = tid; i < p.k; i += 256) {
+    bitonic_sort_u64<1024>(buf, P2, tid);
+    for (uint32_t i = tid; i < p.k; i += 1024) {
         const uint32_t o = q * p.k + i;
         const uint64_t comp = i < m ? buf[i] : kPadComposite;
         if (comp == kPadComposite) {
-            p.out_scores[o] = pad_score(METRIC);
+            p.out_scores[o] = pad_score(metric);
             p.out_indices[o] = ~0ull;
         } else {
-            p.out_scores[o] = score_from_key((uint32_t)(comp >> 32), METRIC);
+            p.out_scores[o] = score_from_key((uint32_t)(comp >> 32), metric);
             p.out_indices[o] = p.ids ? p.ids[(uint32_t)comp] : p.index_base + (uint32_t)comp;
         }
         if (p.out_raw) p.out_raw[o] = 0;
@@ -751,10 +783,19 @@ hipError_t launch_compact_margin(const CompactParams& p, uint32_t nq, hipStream_
 }
 
 hipError_t launch_rescore(const RescoreParams& p, int metric, uint32_t nq, hipStream_t s) {
-    const size_t lds = (size_t)((p.dim + 7u) & ~7u) * 4 + (size_t)(p.cap / 2) * 8;
-    if (metric == MVF_METRIC_L2) hipLaunchKernelGGL(rescore_kernel<MVF_METRIC_L2>, dim3(nq), dim3(256), lds, s, p);
-    else if (metric == MVF_METRIC_COSINE) hipLaunchKernelGGL(rescore_kernel<MVF_METRIC_COSINE>, dim3(nq), dim3(256), lds, s, p);
-    else hipLaunchKernelGGL(rescore_kernel<MVF_METRIC_INNER_PRODUCT>, dim3(nq), dim3(256), lds, s, p);
+    if (nq == 0) return hipSuccess;
+    const size_t lds = (size_t)((p.dim + 7u) & ~7u) * 4;
+    // blocks per query: enough to fill the chip with a small batch, few enough that a block's staged query serves
+    // several 16-candidate slices with a large one
+    const uint32_t slices = (p.cap / 2 + 15u) / 16u;
+    const uint32_t B = std::min(slices, std::max(8u, std::min(64u, 2048u / nq)));
+    const dim3 grid(B, nq);
+    if (metric == MVF_METRIC_L2) hipLaunchKernelGGL(rescore_score_kernel<MVF_METRIC_L2>, grid, dim3(256), lds, s, p);
+    else if (metric == MVF_METRIC_COSINE) hipLaunchKernelGGL(rescore_score_kernel<MVF_METRIC_COSINE>, grid, dim3(256), lds, s, p);
+    else hipLaunchKernelGGL(rescore_score_kernel<MVF_METRIC_INNER_PRODUCT>, grid, dim3(256), lds, s, p);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(rescore_select_kernel, dim3(nq), dim3(1024), (size_t)(p.cap / 2) * 8, s, p, metric);
     return hipGetLastError();
 }
 
