@@ -379,24 +379,44 @@ __global__ void __launch_bounds__(256) row_norms_f32_kernel(const unsigned char*
 // bound by same-address atomics (2 M records on 1024 counters: 150 us per call, 0.9 ms of a 12-ms search).  Here a block
 // owns a contiguous share of the regions and aggregates per query in LDS first: histogram with LDS atomics (which also
 // hand every record its rank), ONE global atomicAdd per (block, query) to reserve the range, then the stores.
-// grid (kScatterBlocks); block 1024; dynamic LDS 8 * nq_pad bytes (queries <= kScatterMaxQueries, else the simple form).
-constexpr uint32_t kScatterBlocks = 64, kScatterMaxQueries = 8192;
+// grid (kScatterBlocks); block 1024; dynamic LDS 4 * nq_pad bytes (queries <= kScatterMaxQueries, else the simple form).
+// The block's regions are walked as ONE flat record range (their counts are prefix-summed first): the record loads of
+// a pass are independent of each other, where a region-by-region walk paid two dependent round trips per region and pass
+// (8 regions x 2 passes: 50-100 us per call, 0.4 ms of a 10.8-ms search).
+constexpr uint32_t kScatterBlocks = 128, kScatterMaxQueries = 8192, kScatterMaxPer = 64;
 
 __global__ void __launch_bounds__(1024) scatter_cand_kernel(const uint4* blk_cand, const uint32_t* blk_cnt, uint32_t blk_cap,
                                                              uint32_t nregions, uint64_t* cand, uint32_t* cnt, uint32_t cap,
                                                              uint32_t nq_pad) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t* hist = reinterpret_cast<uint32_t*>(smem);  // [nq_pad] records of this block per query, then their global base
-    const uint32_t per = (nregions + gridDim.x - 1) / gridDim.x;
+    __shared__ uint32_t start_s[kScatterMaxPer + 1];     // flat offset of each of the block's regions
+    const uint32_t per = (nregions + gridDim.x - 1) / gridDim.x;  // <= kScatterMaxPer (the launcher sizes the grid)
     const uint32_t r_lo = blockIdx.x * per, r_hi = min(nregions, r_lo + per);
     for (uint32_t i = threadIdx.x; i < nq_pad; i += 1024) hist[i] = 0;
-    __syncthreads();
-    // pass 1: histogram (the returned value is the record's rank inside the block's share of its query; it is
-    // recomputed in pass 3 in the same order only if deterministic order mattered -- it does not: lists are unordered)
-    for (uint32_t b = r_lo; b < r_hi; b++) {
-        const uint32_t n = min(blk_cnt[b], blk_cap);
-        for (uint32_t e = threadIdx.x; e < n; e += 1024) atomicAdd(&hist[blk_cand[(size_t)b * blk_cap + e].z], 1u);
+    if (threadIdx.x < 64) {  // one wave: inclusive scan of the region counts
+        const uint32_t b = r_lo + threadIdx.x;
+        uint32_t incl = b < r_hi ? min(blk_cnt[b], blk_cap) : 0u;
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t v = __shfl_up(incl, off, 64);
+            if ((int)threadIdx.x >= off) incl += v;
+        }
+        start_s[threadIdx.x + 1] = incl;
+        if (threadIdx.x == 0) start_s[0] = 0;
     }
+    __syncthreads();
+    const uint32_t nreg = r_hi > r_lo ? r_hi - r_lo : 0u, total = start_s[nreg];
+    auto record = [&](uint32_t e) __attribute__((always_inline)) -> uint4 {
+        uint32_t lo = 0, hi = nreg;  // the region with start_s[lo] <= e < start_s[lo + 1]
+        while (hi - lo > 1) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (start_s[mid] <= e) lo = mid;
+            else hi = mid;
+        }
+        return blk_cand[(size_t)(r_lo + lo) * blk_cap + (e - start_s[lo])];
+    };
+    // pass 1: histogram
+    for (uint32_t e = threadIdx.x; e < total; e += 1024) atomicAdd(&hist[record(e).z], 1u);
     __syncthreads();
     // pass 2: reserve the ranges
     for (uint32_t i = threadIdx.x; i < nq_pad; i += 1024) {
@@ -404,14 +424,12 @@ __global__ void __launch_bounds__(1024) scatter_cand_kernel(const uint4* blk_can
         hist[i] = h ? atomicAdd(&cnt[i], h) : 0u;
     }
     __syncthreads();
-    // pass 3: store (a query's records take consecutive slots from its base, in arrival order of the LDS atomics)
-    for (uint32_t b = r_lo; b < r_hi; b++) {
-        const uint32_t n = min(blk_cnt[b], blk_cap);
-        for (uint32_t e = threadIdx.x; e < n; e += 1024) {
-            const uint4 rec = blk_cand[(size_t)b * blk_cap + e];
-            const uint32_t slot = atomicAdd(&hist[rec.z], 1u);
-            if (slot < cap) cand[(size_t)rec.z * cap + slot] = ((uint64_t)rec.x << 32) | rec.y;
-        }
+    // pass 3: store (a query's records take consecutive slots from its base, in arrival order of the LDS atomics;
+    // the lists are unordered)
+    for (uint32_t e = threadIdx.x; e < total; e += 1024) {
+        const uint4 rec = record(e);
+        const uint32_t slot = atomicAdd(&hist[rec.z], 1u);
+        if (slot < cap) cand[(size_t)rec.z * cap + slot] = ((uint64_t)rec.x << 32) | rec.y;
     }
 }
 
@@ -763,8 +781,9 @@ hipError_t launch_scatter_cand(const Batch16Params& p, uint32_t nblocks, hipStre
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return e;
         }
-        hipLaunchKernelGGL(scatter_cand_kernel, dim3(std::min(kScatterBlocks, nblocks)), dim3(1024), lds, s, p.blk_cand, p.blk_cnt,
-                           p.blk_cap, nblocks, p.cand, p.cnt, p.cap, p.nq_pad);
+        const uint32_t grid = std::max(std::min(kScatterBlocks, nblocks), (nblocks + kScatterMaxPer - 1) / kScatterMaxPer);
+        hipLaunchKernelGGL(scatter_cand_kernel, dim3(grid), dim3(1024), lds, s, p.blk_cand, p.blk_cnt, p.blk_cap, nblocks, p.cand,
+                           p.cnt, p.cap, p.nq_pad);
     } else {
         hipLaunchKernelGGL(scatter_cand_simple_kernel, dim3(4, nblocks), dim3(256), 0, s, p.blk_cand, p.blk_cnt, p.blk_cap, p.cand,
                            p.cnt, p.cap);
