@@ -243,6 +243,30 @@ def cfg5_sharded_leg(args, rank, local_rank, world, backend, dist, torch, G, Sha
     return leg
 
 
+def vendor_gemm_reference(torch, dev):
+    """torch.matmul / torch._int_mm (hipBLASLt) on an 8192^3 GEMM: the rate a tuned library sustains on this box under
+    its power limit -- the MFMA legs' `roofline.peak` is the nominal dense peak, this is the practical one."""
+    out = {"shape": "8192 x 8192 x 8192", "what": "torch.matmul (f16) / torch._int_mm (int8), 3 warm-up + 10 timed calls"}
+    try:
+        n = 8192
+        a = torch.randn(n, n, device=dev, dtype=torch.float16)
+        b = torch.randn(n, n, device=dev, dtype=torch.float16)
+        a8 = torch.randint(-127, 127, (n, n), device=dev, dtype=torch.int8)
+        b8 = torch.randint(-127, 127, (n, n), device=dev, dtype=torch.int8)
+        for name, fn in (("f16_tflops", lambda: torch.matmul(a, b.t())), ("int8_tops", lambda: torch._int_mm(a8, b8.t()))):
+            for _ in range(3):
+                fn()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(10):
+                fn()
+            torch.cuda.synchronize()
+            out[name] = 2.0 * n ** 3 * 10 / (time.perf_counter() - t0) / 1e12
+    except Exception as e:  # a torch build without these ops: the reference is context, not a measurement of ours
+        out["error"] = str(e)[:200]
+    return out
+
+
 def main():
     args = parse_args()
     rank = int(os.environ.get("RANK", "0"))
@@ -476,6 +500,10 @@ def main():
         leg = cfg5_sharded_leg(args, rank, local_rank, world, backend, dist, torch, G, ShardedSearcher, _lib)
         if rank == 0:
             result["cfg5_sharded"] = leg
+
+    # ---- context for the MFMA fractions above: what the vendor GEMM library holds on THIS box (best case, 8192^3) --------
+    if rank == 0 and world == 1 and not args.no_batched:
+        result["vendor_gemm_reference"] = vendor_gemm_reference(torch, dev)
 
     if rank == 0:
         print(json.dumps(result), flush=True)

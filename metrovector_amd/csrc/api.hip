@@ -108,9 +108,6 @@ struct mvfgpu_corpus {
     mutable hipEvent_t qs_redo_ev = nullptr;
     mutable bool qs_redo_pending = false, qs_disabled = false;
     mutable uint32_t qs_redo_nq = 0;
-    // the same feedback for the int8 shadow STREAMED for 2..4 queries: too few per search to judge one, so a running count
-    mutable bool qs_redo_streamed = false, qs_stream_disabled = false;
-    mutable uint32_t qs_stream_seen = 0, qs_stream_redo = 0;
     mutable const uint32_t* last_redo_cnt = nullptr;  // device: the count the newest repair pass produced
     mutable bool xnorm_ready = false;
     mutable uint32_t bstate_slots = 0;    // queries the K2 state arrays are armed for
@@ -442,20 +439,6 @@ void qs_feedback_poll(const mvfgpu_corpus* c) {
         return;
     }
     c->qs_redo_pending = false;
-    if (c->qs_redo_streamed) {
-        c->qs_stream_seen += c->qs_redo_nq;
-        c->qs_stream_redo += *c->qs_redo_host;
-        if (c->qs_stream_redo >= 3 && c->qs_stream_redo * 4 > c->qs_stream_seen) {
-            c->qs_stream_disabled = true;
-            if (getenv("MVF_DEBUG_REPAIR"))
-                fprintf(stderr, "[mvfgpu] int8-shadow streaming switched off for this corpus: %u of %u queries needed the repair path\n",
-                        c->qs_stream_redo, c->qs_stream_seen);
-        } else if (c->qs_stream_seen >= 1024) {
-            c->qs_stream_seen /= 2;
-            c->qs_stream_redo /= 2;
-        }
-        return;
-    }
     if ((uint64_t)*c->qs_redo_host * 8 > c->qs_redo_nq && *c->qs_redo_host >= 4) {
         c->qs_disabled = true;
         if (getenv("MVF_DEBUG_REPAIR"))
@@ -466,7 +449,7 @@ void qs_feedback_poll(const mvfgpu_corpus* c) {
 
 // ... and the request for it: the repair count of the search just enqueued, copied to pinned memory behind an event
 // (never waited for).
-int qs_feedback_post(const mvfgpu_corpus* c, uint32_t nq, bool streamed, hipStream_t s) {
+int qs_feedback_post(const mvfgpu_corpus* c, uint32_t nq, hipStream_t s) {
     if (c->qs_redo_pending || !c->repair.p) return MVF_OK;
     if (!c->qs_redo_host) {
         HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&c->qs_redo_host), 64, hipHostMallocDefault));
@@ -476,7 +459,6 @@ int qs_feedback_post(const mvfgpu_corpus* c, uint32_t nq, bool streamed, hipStre
     HIP_TRY(hipEventRecord(c->qs_redo_ev, s));
     c->qs_redo_pending = true;
     c->qs_redo_nq = nq;
-    c->qs_redo_streamed = streamed;
     return MVF_OK;
 }
 
@@ -875,7 +857,7 @@ int search_batched_path(const mvfgpu_corpus* c, uint8_t metric, const void* d_qu
     }
 
     int rc = repair_flagged_queries(c, metric, d_queries, nq, nq_pad, k, overflow, d_scores, d_indices, d_raw, s);
-    if (rc == MVF_OK && use_qs && c->scan_path != 5 && c->scan_path != 6) rc = qs_feedback_post(c, nq, false, s);
+    if (rc == MVF_OK && use_qs && c->scan_path != 5 && c->scan_path != 6) rc = qs_feedback_post(c, nq, s);
     return rc;
 }
 
@@ -1034,24 +1016,14 @@ int search_stream_qs_path(const mvfgpu_corpus* c, uint8_t metric, const void* d_
     rp.out_indices = d_indices;
     rp.out_raw = d_raw;
     HIP_TRY(launch_rescore(rp, metric, nq, s));
-    rc = repair_flagged_queries(c, metric, d_queries, nq, nq_pad, k, overflow, d_scores, d_indices, d_raw, s);
-    if (rc == MVF_OK && c->scan_path != 6) rc = qs_feedback_post(c, nq, true, s);
-    return rc;
+    return repair_flagged_queries(c, metric, d_queries, nq, nq_pad, k, overflow, d_scores, d_indices, d_raw, s);
 }
 
-// The int8 shadow is streamed by default for 2..4 queries (a batch this small pays a whole padded 64-query MFMA tile
-// otherwise: 2.6 ms against K1's ~1.4 on 10M x 768) once the corpus holds >= 1 GiB of rows, for one query on request
-// (scan path 6 -- the default for one query stays the exact scan of the stored rows: no extra memory, nothing to
-// build).  MVF_STREAM_I8=0 opts out.
-bool stream_qs_wanted(const mvfgpu_corpus* c, uint32_t nq, uint32_t k) {
-    if (nq == 0 || nq > 4 || !qs_wanted(c) || c->scan_path == 5) return false;
-    if (const char* e = getenv("MVF_STREAM_I8"))
-        if (atoi(e) == 0) return false;
-    if (c->scan_path == 6) return true;
-    if (c->scan_path != 0 || nq == 1 || c->qs_stream_disabled) return false;
-    const uint64_t bytes = c->n * (uint64_t)c->dim * elem_size(c->dtype);
-    return bytes >= (1ull << 30);
-}
+// Scan path 6: one to four queries stream the int8 shadow.  Opt-in: two to four queries are served as fast by the
+// 64-query MFMA tile on the same shadow (1.55-1.65 ms against 1.53-1.72 on 10M x 768: profiles/
+// r02_stream_int8_shadow_1to4_queries.txt), and ONE query keeps reading the stored rows by default -- no extra memory,
+// nothing to build.
+bool stream_qs_wanted(const mvfgpu_corpus* c, uint32_t nq) { return c->scan_path == 6 && nq >= 1 && nq <= 4 && qs_wanted(c); }
 
 // Scan path 4 applies to one or two queries on a Float32 corpus whose shadow exists (or can be built now).
 bool stream_shadow_wanted(const mvfgpu_corpus* c, uint32_t nq) {
@@ -1589,15 +1561,12 @@ int mvfgpu_search_device(const mvfgpu_corpus* c, uint8_t metric, const void* d_q
         HIP_TRY(hipEventRecord(wps->e[3], s));
     }
     bool shadow_stream = false, qs_stream = false;
-    if (stream_qs_wanted(c, nq, k)) {
-        qs_feedback_poll(c);
-        if (stream_qs_wanted(c, nq, k)) {  // still, after the look at the last search's repairs
-            rc = ensure_norms(c, s);
-            if (rc != MVF_OK) return rc;
-            hipError_t e = ensure_shadow8(c, s, c->scan_path == 6);
-            if (e != hipSuccess) return fail(MVF_ERR_DEVICE, std::string("int8 shadow build: ") + hipGetErrorString(e));
-            qs_stream = c->shadow8_state == 1;
-        }
+    if (stream_qs_wanted(c, nq)) {
+        rc = ensure_norms(c, s);
+        if (rc != MVF_OK) return rc;
+        hipError_t e = ensure_shadow8(c, s, true);
+        if (e != hipSuccess) return fail(MVF_ERR_DEVICE, std::string("int8 shadow build: ") + hipGetErrorString(e));
+        qs_stream = c->shadow8_state == 1;
     }
     if (!qs_stream && stream_shadow_wanted(c, nq)) {
         hipError_t e = ensure_shadow(c, s, c->scan_path == 4);

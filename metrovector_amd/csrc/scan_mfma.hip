@@ -103,6 +103,12 @@ __global__ void __launch_bounds__(256, 2) scan_mfma_f32_kernel(BatchParams p) {
                 const float tq = METRIC == MVF_METRIC_COSINE ? ts * qn : ts;
                 tql_s[tid] = tq - fabsf(tq) * 2e-6f;
             }
+            // padding queries of the batch's last tile (zero vectors) never pass: without this their "no threshold yet"
+            // sent every 32 x 32 tile of their wave through the exact path
+            if (q0 + tid >= p.nq) {
+                tau_s[tid] = 0u;
+                tql_s[tid] = __builtin_inff();
+            }
         }
     };
 
