@@ -82,7 +82,7 @@ typedef struct mvfgpu_timing {
                              corpus (scan path 4); MFMA batched (K2): 2 = f32 kernel on Float32 rows,
                              3 = f16/int8 kernel on the stored rows, 4 = f16 kernel on the f16 shadow,
                              6 = int8 kernel on the int8 shadow of a Float32 / Float16 corpus (scan path 5);
-                             7 = K1 on the int8 shadow (scan path 6) */
+                             7 = K1 on the int8 shadow (scan path 6; one query once the shadow exists) */
     uint32_t scan_launches; /* scan launches of one search (timing covers the first) */
     uint64_t scan_bytes; /* algorithmic bytes one scan launch reads */
     uint64_t scan_flops; /* algorithmic flops of one scan launch (2*nq*rows*dim) */
@@ -340,8 +340,11 @@ int mvfgpu_last_timing(const mvfgpu_corpus* corpus, mvfgpu_timing* out);
  * 6 = as 5, and ONE TO FOUR queries STREAM THE INT8 SHADOW through K1
  * (`dimension` bytes per row instead of 4x / 2x that; same bound, same exact
  * re-scoring: 1.2-1.3 ms for one query instead of 4.5 on 10M x 768 f32).
- * Opt-in: one query reads the stored rows by default (no extra memory, nothing
- * to build), two to four are served as fast by the 64-query MFMA tile.
+ * Path 0 does this for ONE query by itself once the corpus holds an int8
+ * shadow anyway (a batched search or an eager upload built it: nothing more
+ * to store or build; MVF_STREAM_I8=0 opts out); a corpus without one reads the
+ * stored rows.  Two to four queries are served as fast by the 64-query MFMA
+ * tile.
  *
  * The f16 shadow: batched searches on a Float32 corpus select candidates with
  * the f16 MFMA kernel on a scaled-f16 copy of the rows (built on the first

@@ -108,6 +108,7 @@ struct mvfgpu_corpus {
     mutable hipEvent_t qs_redo_ev = nullptr;
     mutable bool qs_redo_pending = false, qs_disabled = false;
     mutable uint32_t qs_redo_nq = 0;
+    mutable uint32_t qs_seen = 0, qs_redone = 0;  // running totals of int8-selected queries / of those the repair pass redid
     mutable const uint32_t* last_redo_cnt = nullptr;  // device: the count the newest repair pass produced
     mutable bool xnorm_ready = false;
     mutable uint32_t bstate_slots = 0;    // queries the K2 state arrays are armed for
@@ -439,11 +440,17 @@ void qs_feedback_poll(const mvfgpu_corpus* c) {
         return;
     }
     c->qs_redo_pending = false;
-    if ((uint64_t)*c->qs_redo_host * 8 > c->qs_redo_nq && *c->qs_redo_host >= 4) {
+    // running totals (a single streamed query says little by itself), halved now and then so that old history fades
+    c->qs_seen += c->qs_redo_nq;
+    c->qs_redone += std::min(*c->qs_redo_host, c->qs_redo_nq);
+    if (c->qs_redone >= 4 && (uint64_t)c->qs_redone * 8 > c->qs_seen) {
         c->qs_disabled = true;
         if (getenv("MVF_DEBUG_REPAIR"))
             fprintf(stderr, "[mvfgpu] int8-shadow selection switched off for this corpus: %u of %u queries needed the repair path\n",
-                    *c->qs_redo_host, c->qs_redo_nq);
+                    c->qs_redone, c->qs_seen);
+    } else if (c->qs_seen >= 8192) {
+        c->qs_seen /= 2;
+        c->qs_redone /= 2;
     }
 }
 
@@ -1016,14 +1023,24 @@ int search_stream_qs_path(const mvfgpu_corpus* c, uint8_t metric, const void* d_
     rp.out_indices = d_indices;
     rp.out_raw = d_raw;
     HIP_TRY(launch_rescore(rp, metric, nq, s));
-    return repair_flagged_queries(c, metric, d_queries, nq, nq_pad, k, overflow, d_scores, d_indices, d_raw, s);
+    rc = repair_flagged_queries(c, metric, d_queries, nq, nq_pad, k, overflow, d_scores, d_indices, d_raw, s);
+    if (rc == MVF_OK && c->scan_path != 6) rc = qs_feedback_post(c, nq, s);
+    return rc;
 }
 
-// Scan path 6: one to four queries stream the int8 shadow.  Opt-in: two to four queries are served as fast by the
-// 64-query MFMA tile on the same shadow (1.55-1.65 ms against 1.53-1.72 on 10M x 768: profiles/
-// r02_stream_int8_shadow_1to4_queries.txt), and ONE query keeps reading the stored rows by default -- no extra memory,
-// nothing to build.
-bool stream_qs_wanted(const mvfgpu_corpus* c, uint32_t nq) { return c->scan_path == 6 && nq >= 1 && nq <= 4 && qs_wanted(c); }
+// One to four queries stream the int8 shadow on request (scan path 6), and ONE query does so by itself once the corpus
+// HOLDS an int8 shadow anyway (a batched search or an eager upload built it): nothing more to store or to build, 1.24
+// instead of 4.5 ms on 10M x 768, same results.  A corpus without one keeps reading the stored rows (the bench's
+// headline: no extra memory, no build).  Two to four queries are served as fast by the 64-query MFMA tile on the same
+// shadow (1.55-1.65 ms against 1.53-1.72: profiles/r02_stream_int8_shadow_1to4_queries.txt).  MVF_STREAM_I8=0 opts
+// out; a corpus whose queries keep needing the repair pass switches itself back (qs_disabled).
+bool stream_qs_wanted(const mvfgpu_corpus* c, uint32_t nq) {
+    if (nq < 1 || nq > 4 || !qs_wanted(c)) return false;
+    if (c->scan_path == 6) return true;
+    if (c->scan_path != 0 || nq != 1 || c->shadow8_state != 1) return false;
+    const char* e = getenv("MVF_STREAM_I8");
+    return !e || atoi(e) != 0;
+}
 
 // Scan path 4 applies to one or two queries on a Float32 corpus whose shadow exists (or can be built now).
 bool stream_shadow_wanted(const mvfgpu_corpus* c, uint32_t nq) {
@@ -1561,10 +1578,11 @@ int mvfgpu_search_device(const mvfgpu_corpus* c, uint8_t metric, const void* d_q
         HIP_TRY(hipEventRecord(wps->e[3], s));
     }
     bool shadow_stream = false, qs_stream = false;
+    if (stream_qs_wanted(c, nq)) qs_feedback_poll(c);  // may switch the int8 selection off
     if (stream_qs_wanted(c, nq)) {
         rc = ensure_norms(c, s);
         if (rc != MVF_OK) return rc;
-        hipError_t e = ensure_shadow8(c, s, true);
+        hipError_t e = ensure_shadow8(c, s, c->scan_path == 6);
         if (e != hipSuccess) return fail(MVF_ERR_DEVICE, std::string("int8 shadow build: ") + hipGetErrorString(e));
         qs_stream = c->shadow8_state == 1;
     }
