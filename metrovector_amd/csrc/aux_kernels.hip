@@ -39,18 +39,22 @@ __device__ __forceinline__ void write_result(uint64_t comp, uint32_t o, const Se
 
 // K3 final select.  grid (nq); block 1024; dynamic LDS P*8 + 16.
 // Input: nlists sorted lists per query (one per scan block).
-//   1. threshold: the k-th smallest of the lists' first `heads` entries is the
-//      k-th smallest of a subset of the corpus, hence >= the true k-th best.
-//      With the top-k spread over many lists it is almost exact.
-//   2. every list's prefix <= threshold is appended to LDS (one thread per
-//      list, usually 0-2 entries each);
-//   3. the survivors are bitonic-sorted and the first k formatted.
-// If the survivors overflow LDS (adversarial clustering) the lists are folded
-// group by group into a running top-k instead.
+//   1. threshold: the k-th smallest KEY among the lists' first `heads` entries is the k-th smallest of a subset of
+//      the corpus, hence >= the true k-th best.  With the top-k spread over many lists it is almost exact.  Found by a
+//      radix select over the 32-bit keys (four 8-bit histogram passes in LDS; round 1 sorted all heads: with the final
+//      sort below that was 30 of the kernel's 41 us, 1 % of a 10M x 768 scan and most of a small corpus' search);
+//   2. every list's prefix with a key <= that is appended to LDS (one thread per list, usually 0-2 entries each);
+//   3. the survivors are sorted -- up to 1024 of them by RANK COUNTING (one per thread: its rank is the number of
+//      smaller survivors, read as LDS broadcasts; composites are distinct), more by the bitonic network -- and the
+//      first k formatted.
+// If the survivors overflow LDS (adversarial clustering, mass ties) the lists are folded group by group into a running
+// top-k instead.
 __global__ void __launch_bounds__(1024) select_final_kernel(SelectParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint64_t* buf = reinterpret_cast<uint64_t*>(smem);
     uint32_t* cnt = reinterpret_cast<uint32_t*>(buf + p.P);
+    __shared__ uint32_t hist[256];
+    __shared__ uint32_t sel_prefix, sel_remaining;
     const int tid = threadIdx.x;
     const uint32_t q = blockIdx.x;
     uint32_t qout = q;  // the query whose result row this block writes
@@ -60,15 +64,69 @@ __global__ void __launch_bounds__(1024) select_final_kernel(SelectParams p) {
     }
     const uint64_t* lists = p.lists + (size_t)q * p.nlists * p.kcap;
 
-    // 1. threshold from the list heads
+    // 1. threshold from the list heads (H >= k by the choice of `heads`, padding entries included: they carry the
+    // largest key, and a threshold that lands on one means "everything")
     const uint32_t H = p.nlists * p.heads;
-    const uint32_t HP = next_pow2(H < 2 ? 2 : H);
-    for (uint32_t i = tid; i < HP; i += 1024)
-        buf[i] = i < H ? lists[(size_t)(i / p.heads) * p.kcap + (i % p.heads)] : kPadComposite;
-    if (tid == 0) *cnt = 0;
+    for (uint32_t i = tid; i < H; i += 1024) buf[i] = lists[(size_t)(i / p.heads) * p.kcap + (i % p.heads)];
+    if (tid == 0) *cnt = 0, sel_prefix = 0, sel_remaining = p.k;
     __syncthreads();
-    bitonic_sort_u64<1024>(buf, HP, tid);
-    const uint64_t tau = (H >= p.k) ? buf[p.k - 1] : kPadComposite;
+    uint64_t tau = kPadComposite;
+    if (H >= p.k) {
+        // the k-th smallest 64-bit composite of the heads: radix select over the key (high word), then -- only when
+        // several heads share that key -- over the row (low word) among those; a unique k-th key is simply looked up
+        __shared__ uint32_t sel_count;
+        __shared__ uint64_t sel_tau;
+        uint32_t key_k = 0;
+        for (int word = 1; word >= 0; word--) {
+            uint32_t mask = 0;
+            if (tid == 0) sel_prefix = 0;
+            __syncthreads();
+            for (int shift = 24; shift >= 0; shift -= 8) {
+                if (tid < 256) hist[tid] = 0;
+                __syncthreads();
+                const uint32_t prefix = sel_prefix;
+                for (uint32_t i = tid; i < H; i += 1024) {
+                    const uint64_t e = buf[i];
+                    const uint32_t w = word ? (uint32_t)(e >> 32) : (uint32_t)e;
+                    if ((word || (uint32_t)(e >> 32) == key_k) && ((w ^ prefix) & mask) == 0) atomicAdd(&hist[(w >> shift) & 255u], 1u);
+                }
+                __syncthreads();
+                if (tid < 64) {  // one wave: bin of the k-th among the entries that share the prefix
+                    const uint32_t h0 = hist[4 * tid], h1 = hist[4 * tid + 1], h2 = hist[4 * tid + 2], h3 = hist[4 * tid + 3];
+                    uint32_t incl = h0 + h1 + h2 + h3;
+                    for (int off = 1; off < 64; off <<= 1) {
+                        const uint32_t v = __shfl_up(incl, off, 64);
+                        if (tid >= off) incl += v;
+                    }
+                    const uint32_t excl = incl - (h0 + h1 + h2 + h3), rem = sel_remaining;
+                    if (excl < rem && rem <= incl) {  // exactly one lane
+                        uint32_t r = rem - excl, bin = 4 * tid, hb = h0;
+                        if (r > h0) { r -= h0; bin++; hb = h1; if (r > h1) { r -= h1; bin++; hb = h2; if (r > h2) { r -= h2; bin++; hb = h3; } } }
+                        sel_prefix = prefix | (bin << shift);
+                        sel_remaining = r;
+                        sel_count = hb;
+                    }
+                }
+                mask |= 255u << shift;
+                __syncthreads();
+            }
+            const uint32_t found = sel_prefix, found_count = sel_count;
+            __syncthreads();  // everyone has read the selection before the next word's passes reset it
+            if (word) {
+                key_k = found;
+                if (found_count == 1) {  // block-uniform: the k-th key is unique among the heads
+                    for (uint32_t i = tid; i < H; i += 1024)
+                        if ((uint32_t)(buf[i] >> 32) == key_k) sel_tau = buf[i];
+                    __syncthreads();
+                    break;
+                }
+            } else {
+                if (tid == 0) sel_tau = ((uint64_t)key_k << 32) | found;
+                __syncthreads();
+            }
+        }
+        tau = sel_tau;
+    }
     __syncthreads();
 
     // 2. gather every list's prefix <= tau
@@ -85,8 +143,15 @@ __global__ void __launch_bounds__(1024) select_final_kernel(SelectParams p) {
     uint32_t m = *cnt;
     __syncthreads();
 
-    if (m <= p.P) {
-        const uint32_t P2 = next_pow2(m < 2 ? 2 : m);
+    if (m <= 1024) {  // rank counting: one survivor per thread
+        const uint64_t mine = (uint32_t)tid < m ? buf[tid] : kPadComposite;
+        uint32_t rank = 0;
+        for (uint32_t i = 0; i < m; i++) rank += buf[i] < mine ? 1u : 0u;
+        __syncthreads();
+        if ((uint32_t)tid < m) buf[rank] = mine;
+        __syncthreads();
+    } else if (m <= p.P) {
+        const uint32_t P2 = next_pow2(m);
         for (uint32_t i = m + tid; i < P2; i += 1024) buf[i] = kPadComposite;
         __syncthreads();
         bitonic_sort_u64<1024>(buf, P2, tid);
