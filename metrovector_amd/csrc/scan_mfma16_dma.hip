@@ -67,7 +67,14 @@ template <int BMQ_> struct CfT {
     static constexpr int BPW = BR / 16 / NW;                    //                                      B
     static constexpr int PIECES = APW + BPW;
     static constexpr int INFLIGHT = PIECES * (NSTAGE - 2);      // pieces left in flight across the barrier
-    static constexpr size_t LDS = (size_t)NSTAGE * STAGE_B + 4 * BMQ * 4 + 16;  // ring + qaux0 + tau + qaux1 + prefilter + candidate counter
+    // The tile's per-row constants (norms, shadow scale, UInt8 bias) ride along as 1-KB DMA pieces into LDS, NRC buffers
+    // of two arrays x BR entries (tile ordinal mod NRC: the DMA cursor runs up to NSTAGE k-tiles = tiles ahead).  An
+    // ordinary global load in the epilogue waits a full HBM round trip with the matrix pipe idle AND drains the ring
+    // (s_waitcnt vmcnt(0)): that was 20 % of the int8-selection scan.  The 64-query shape has no LDS left
+    // for them (4 x 36 KB of ring) and keeps the loads.
+    static constexpr bool RC_LDS = BMQ == 256;
+    static constexpr int NRC = 8;                               // >= NSTAGE + 1 (one k-tile per tile) with room for waves that lag inside the epilogue
+    static constexpr size_t LDS = (size_t)NSTAGE * STAGE_B + 4 * BMQ * 4 + (RC_LDS ? NRC * 2 * BR * 4 : 0) + 16;  // ring + qaux0 + tau + qaux1 + prefilter [+ row constants] + candidate counter
 };
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -93,7 +100,15 @@ __global__ void __launch_bounds__(512, 2) scan_mfma16_dma_kernel(Batch16Params p
     uint32_t* tau_s = reinterpret_cast<uint32_t*>(qa_s + BMQ);        // [BMQ]
     float* qb_s = reinterpret_cast<float*>(tau_s + BMQ);              // [BMQ] f16: |q|
     float* thr_s = qb_s + BMQ;                                        // [BMQ] pre-filter threshold
-    uint32_t* bc_s = reinterpret_cast<uint32_t*>(thr_s + BMQ);        // records in the block's candidate region
+    uint32_t* rc_s = reinterpret_cast<uint32_t*>(thr_s + BMQ);        // [NRC][2][BR] per-row constants (RC_LDS)
+    uint32_t* bc_s = rc_s + (Cf::RC_LDS ? Cf::NRC * 2 * Cf::BR : 0);  // records in the block's candidate region
+    // per-row constants the epilogue needs (scan_mfma16_common.inc): array 0 = norms, array 1 = shadow scale / UInt8 bias
+    constexpr bool QSF = DT == MVF_DTYPE_FLOAT16 || (DT == MVF_DTYPE_INT8 && XS);  // float scores
+    constexpr bool NEED0 = METRIC != MVF_METRIC_INNER_PRODUCT;
+    constexpr bool NEED1 = QSF ? XS : (U8 && METRIC != MVF_METRIC_L2);
+    const uint32_t* arr0 = QSF ? reinterpret_cast<const uint32_t*>(METRIC == MVF_METRIC_COSINE ? p.xnorm_f : p.xx2)
+                               : reinterpret_cast<const uint32_t*>(p.xnorm_i);
+    const uint32_t* arr1 = QSF ? reinterpret_cast<const uint32_t*>(p.xscale) : reinterpret_cast<const uint32_t*>(p.xbias_i);
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -132,6 +147,12 @@ __global__ void __launch_bounds__(512, 2) scan_mfma16_dma_kernel(Batch16Params p
         for (int j = 0; j < Cf::BPW; j++) {
             const uint32_t r = r0 + ((uint32_t)wave * Cf::BPW + j) * 16u + rl;
             b_src[j] = p.rows + (size_t)(r < p.row_end ? r : r0) * p.pitch;
+        }
+        if constexpr (Cf::RC_LDS) {  // BR = 256: one 1-KB piece per array (entries r0 .. r0 + 255; beyond row_end: unused)
+            uint32_t* dst = rc_s + (n & (Cf::NRC - 1)) * 2 * Cf::BR;
+            const uint32_t e = min(r0 + 4u * (uint32_t)lane, (p.row_end - 1u) & ~3u);
+            if (NEED0 && wave == 0) __builtin_amdgcn_global_load_lds((glb_ptr_t)(arr0 + e), (lds_ptr_t)dst, 16, 0, 0);
+            if (NEED1 && wave == 1) __builtin_amdgcn_global_load_lds((glb_ptr_t)(arr1 + e), (lds_ptr_t)(dst + Cf::BR), 16, 0, 0);
         }
     };
     // In the k-loop the pieces are issued after the groups of four MFMAs, so the address path works underneath the
@@ -232,8 +253,11 @@ __global__ void __launch_bounds__(512, 2) scan_mfma16_dma_kernel(Batch16Params p
                 for (int j = 0; j < NJ; j++) asm volatile("" ::"v"(acc[i][j]));
             if (false)
 #endif
-            epilogue16<DT, METRIC, DIRECT, XS, BMQ, SH, WQ, WR, Cf::BR>(p, acc, c_nt, c_mt, wm, wn, lane, qa_s, qb_s, tau_s, thr_s,
-                                                                        nullptr, nullptr, p.blk_cand ? bc_s : nullptr);
+            {
+                const uint32_t* rc = rc_s + (c_n & (Cf::NRC - 1)) * 2 * Cf::BR;
+                epilogue16<DT, METRIC, DIRECT, XS, BMQ, SH, WQ, WR, Cf::BR, Cf::RC_LDS>(p, acc, c_nt, c_mt, wm, wn, lane, qa_s, qb_s, tau_s,
+                                                                                       thr_s, rc, rc + Cf::BR, p.blk_cand ? bc_s : nullptr);
+            }
             zero_acc();
             c_kt = 0;
             if (++c_n < my_tiles) {
