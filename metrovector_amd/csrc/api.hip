@@ -496,13 +496,22 @@ hipError_t ensure_shadow8(const mvfgpu_corpus* c, hipStream_t s, bool insist) {
     return e;
 }
 
-// K2 per-query state (threshold key, candidate count, overflow flag), armed once and re-armed by the kernels that end
-// a search.
+// Threshold refinement of the int8 selection (scan_mfma.h: launch_refine_tau) in front of the LAST phase -- (g - 1) / g of
+// the corpus -- when that is at least this many rows (in front of the second largest phase too it cost what it saved);
+// MVF_QS_REFINE=0 switches it off (A/B runs).
+constexpr uint64_t kRefineMinRows = 200000;
+bool qs_refine_enabled() {
+    const char* e = getenv("MVF_QS_REFINE");
+    return !e || atoi(e) != 0;
+}
+
+// K2 per-query state (threshold key, candidate count, overflow flag; for the refinement the number of best candidates
+// at the head of the list and the worst exact key among them), armed once and re-armed by the kernels that end a search.
 int ensure_bstate(const mvfgpu_corpus* c, uint32_t nq_pad, hipStream_t s) {
     if (c->bstate_slots >= nq_pad) return MVF_OK;
-    HIP_TRY(c->bstate.reserve((size_t)nq_pad * 12));
-    HIP_TRY(hipMemsetAsync(c->bstate.p, 0xFF, (size_t)nq_pad * 4, s));                                                    // tau
-    HIP_TRY(hipMemsetAsync(static_cast<unsigned char*>(c->bstate.p) + (size_t)nq_pad * 4, 0, (size_t)nq_pad * 8, s));  // cnt, overflow
+    HIP_TRY(c->bstate.reserve((size_t)nq_pad * 20));
+    HIP_TRY(hipMemsetAsync(c->bstate.p, 0xFF, (size_t)nq_pad * 4, s));                                                     // tau
+    HIP_TRY(hipMemsetAsync(static_cast<unsigned char*>(c->bstate.p) + (size_t)nq_pad * 4, 0, (size_t)nq_pad * 16, s));  // cnt, overflow, ntop, lkey
     c->bstate_slots = nq_pad;
     return MVF_OK;
 }
@@ -772,6 +781,11 @@ int search_batched_path(const mvfgpu_corpus* c, uint8_t metric, const void* d_qu
     if (kdtype == MVF_DTYPE_FLOAT16) cp.eps += 4.8828125e-4f * 1.001f;
     if (use_shadow) cp.eps += 4.8828125e-4f * 1.001f;  // the shadow rows' own rounding (same bound, per element of x)
     cp.delta = use_qs ? qdelta : nullptr;               // int8 selection: the per-query bound from the query preparation
+    // int8 selection: between the large phases the threshold is refined with exact scores of the k best (scan_mfma.h)
+    uint32_t* ntop = overflow + c->bstate_slots;
+    uint32_t* lkey = ntop + c->bstate_slots;
+    const bool refine = use_qs && qs_refine_enabled();
+    cp.ntop = refine ? ntop : nullptr;
 
     mvfgpu_timing tm{};
     tm.scan_kernel = wide ? 2u : use_qs ? 6u : use_shadow ? 4u : 3u;
@@ -835,6 +849,20 @@ int search_batched_path(const mvfgpu_corpus* c, uint8_t metric, const void* d_qu
         if (approx) HIP_TRY(launch_compact_margin(cp, nq, s));
         else HIP_TRY(launch_compact(cp, nq, last, s));
         if (last) break;
+        if (refine && bounds[bi + 1] >= n && n - end >= kRefineMinRows) {  // worth its ~0.1 ms in front of the last (largest) phase
+            RescoreParams rp{};
+            rp.cand = bp.cand;
+            rp.cnt = cnt;
+            rp.tau = tau;
+            rp.cap = cap;
+            rp.k = k;
+            rp.queries = static_cast<const float*>(d_queries);
+            rp.rows = c->d_rows;
+            rp.pitch = c->pitch;
+            rp.dim = c->dim;
+            rp.dtype = c->dtype;
+            HIP_TRY(launch_refine_tau(rp, metric, nq, ntop, lkey, qdelta, s));
+        }
         begin = end;
         end = bounds[++bi];
     }

@@ -89,6 +89,9 @@ struct CompactParams {
     // int8-shadow selection (shadow_i8.hip): the proven bound of |approximate - exact score| per query, replacing the
     // eps formulas above (the L2 entry bounds the squared GEMM-form distance)
     const float* delta;   // [nq] or NULL
+    // threshold refinement (int8-shadow selection): the kept list is written with its `ntop[q]` best approximate entries
+    // (key <= the k-th best key) FIRST, for refine (below) to score them exactly; NULL = any order, nothing reported
+    uint32_t* ntop;       // [nq] or NULL
     // final stage only
     uint8_t metric, dtype;
     uint64_t index_base;
@@ -126,6 +129,13 @@ struct RescoreParams {
 };
 hipError_t launch_compact_margin(const CompactParams& p, uint32_t nq, hipStream_t s);
 hipError_t launch_rescore(const RescoreParams& p, int metric, uint32_t nq, hipStream_t s);
+// Threshold refinement between two phases of an int8-shadow selection: the ntop[q] >= k best approximate candidates of
+// every query are scored EXACTLY (rescore's arithmetic; L2 as the squared distance the selection works on); the worst of
+// those exact scores, L, is a lower bound of the final k-th best score, so a row of the final top-k has an approximate
+// score >= L - delta: tau[q] tightens from ord(v_k - 2 delta) to ord(L - delta) -- 2.7 x fewer scores get through the
+// next phase's pre-filter, the candidate lists and the final re-scoring.  lkey: [nq] scratch, zero on entry and exit.
+hipError_t launch_refine_tau(const RescoreParams& p, int metric, uint32_t nq, const uint32_t* ntop, uint32_t* lkey,
+                             const float* delta, hipStream_t s);
 
 uint32_t scan_mfma16_queries_per_block(int dtype);
 hipError_t launch_scan_mfma16(const Batch16Params& p, int dtype, int metric, int num_cus, hipStream_t s);

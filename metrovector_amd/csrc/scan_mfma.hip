@@ -587,14 +587,39 @@ __global__ void __launch_bounds__(1024) compact_margin_kernel(CompactParams p) {
         else if (p.metric == MVF_METRIC_COSINE) thr = vk - 2.0f * p.eps;
         else thr = vk - 2.0f * p.eps * qn * sqrtf(p.xxmax[0]);
         tkey = key_from_score(thr, p.metric);
+        // a threshold refined after an earlier phase (launch_refine_tau) may be tighter than this list's own: both hold
+        const uint32_t prev = p.tau[q];
+        if (prev < tkey) tkey = prev;
     }
     // filter: every live entry whose key is within the margin (all of them while there is no threshold)
     const uint32_t keep_cap = p.cap / 2;
-    for (uint32_t i = tid; i < m; i += 1024) {
-        const uint64_t e = buf[i];
-        if (e != kPadComposite && (tkey == kNanKey || (uint32_t)(e >> 32) <= tkey)) {
-            const uint32_t slot = atomicAdd(&keep_s, 1u);
-            if (slot < keep_cap) c[slot] = e;
+    const bool ordered = p.ntop != nullptr && live >= p.k;  // the k best (and their ties) first: refine scores those
+    if (ordered) {
+        const uint32_t kth = sel_prefix;
+        for (uint32_t i = tid; i < m; i += 1024) {
+            const uint64_t e = buf[i];
+            if (e != kPadComposite && (uint32_t)(e >> 32) <= kth && (uint32_t)(e >> 32) <= tkey) {
+                const uint32_t slot = atomicAdd(&keep_s, 1u);
+                if (slot < keep_cap) c[slot] = e;
+            }
+        }
+        __syncthreads();
+        if (tid == 0) live_s = keep_s;  // (live is in a register already) the number of top entries
+        __syncthreads();
+        for (uint32_t i = tid; i < m; i += 1024) {
+            const uint64_t e = buf[i];
+            if (e != kPadComposite && (uint32_t)(e >> 32) > kth && (uint32_t)(e >> 32) <= tkey) {
+                const uint32_t slot = atomicAdd(&keep_s, 1u);
+                if (slot < keep_cap) c[slot] = e;
+            }
+        }
+    } else {
+        for (uint32_t i = tid; i < m; i += 1024) {
+            const uint64_t e = buf[i];
+            if (e != kPadComposite && (tkey == kNanKey || (uint32_t)(e >> 32) <= tkey)) {
+                const uint32_t slot = atomicAdd(&keep_s, 1u);
+                if (slot < keep_cap) c[slot] = e;
+            }
         }
     }
     __syncthreads();
@@ -609,6 +634,7 @@ __global__ void __launch_bounds__(1024) compact_margin_kernel(CompactParams p) {
         if (over) p.overflow[q] = 1u;
         p.cnt[q] = keep;
         p.tau[q] = tkey;
+        if (p.ntop) p.ntop[q] = ordered ? min(live_s, keep) : 0u;
     }
 }
 
@@ -619,8 +645,8 @@ __global__ void __launch_bounds__(1024) compact_margin_kernel(CompactParams p) {
 // takes the 16-candidate slices b, b + B, ... (round 2 had one block per query walk all of them, four at a time:
 // 0.46 ms for the ~700 candidates of an int8-selected query whatever the batch size -- a fifth of a 64-query search).
 // rescore_select_kernel: one block per query sorts the re-scored candidates and formats the k best.
-template <int METRIC>
-__global__ void __launch_bounds__(256) rescore_score_kernel(RescoreParams p) {
+template <int METRIC, bool REFINE = false>
+__global__ void __launch_bounds__(256) rescore_score_kernel(RescoreParams p, const uint32_t* ntop = nullptr, uint32_t* lkey = nullptr) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t dim4 = (p.dim + 7u) & ~7u;  // zero-padded to a multiple of 8 (one f16 vector)
     float* qs = reinterpret_cast<float*>(smem);
@@ -628,7 +654,7 @@ __global__ void __launch_bounds__(256) rescore_score_kernel(RescoreParams p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t q = blockIdx.y;
     const uint32_t keep_cap = p.cap / 2;
-    const uint32_t m = min(p.cnt[q], keep_cap);
+    const uint32_t m = REFINE ? (ntop[q] >= p.k ? min(ntop[q], keep_cap) : 0u) : min(p.cnt[q], keep_cap);  // REFINE: the best k (+ ties) only
     if (blockIdx.x * 16u >= m) return;  // block-uniform
     float qq = 0.f;
     for (uint32_t e = tid; e < dim4; e += 256) {
@@ -692,15 +718,34 @@ __global__ void __launch_bounds__(256) rescore_score_kernel(RescoreParams p) {
                 if (METRIC == MVF_METRIC_COSINE) xx[u] += __shfl_xor(xx[u], off, 64);
             }
             float sc = s[u];
-            if (METRIC == MVF_METRIC_L2) sc = sqrtf(s[u]);
+            if (METRIC == MVF_METRIC_L2 && !REFINE) sc = sqrtf(s[u]);  // REFINE: the squared distance the selection works on
             if (METRIC == MVF_METRIC_COSINE) {
                 const float den = sqrtf(qq) * sqrtf(xx[u]);
                 sc = den > 0.0f ? s[u] / den : 0.0f;
             }
             const uint32_t ci = c0 + (uint32_t)wave * 4u + u;
-            if (lane == 0 && ci < m) c[ci] = ((uint64_t)key_from_score(sc, METRIC) << 32) | r[u];
+            if (REFINE) {
+                if (lane == 0 && ci < m) atomicMax(&lkey[q], key_from_score(sc, METRIC));  // the worst of the exact scores
+            } else if (lane == 0 && ci < m) {
+                c[ci] = ((uint64_t)key_from_score(sc, METRIC) << 32) | r[u];
+            }
         }
     }
+}
+
+// One thread per query: tau[q] = the tighter of itself and ord(L -/+ delta), L = the worst exact score of its k best
+// approximate candidates (rescore_score_kernel<., true>); re-arms lkey.  The 2 % on delta covers the f32 rounding of the
+// exact scores themselves (the final ranking is by those f32 values).
+__global__ void __launch_bounds__(256) refine_tau_kernel(uint32_t* tau, const uint32_t* ntop, uint32_t* lkey, const float* delta,
+                                                        int metric, uint32_t k, uint32_t nq) {
+    const uint32_t q = blockIdx.x * 256u + threadIdx.x;
+    if (q >= nq) return;
+    if (ntop[q] >= k) {
+        const float L = score_from_key(lkey[q], metric), d = delta[q] * 1.02f;
+        const uint32_t key = key_from_score(metric == MVF_METRIC_L2 ? L + d : L - d, metric);
+        if (key < tau[q]) tau[q] = key;
+    }
+    lkey[q] = 0u;
 }
 
 __global__ void __launch_bounds__(1024) rescore_select_kernel(RescoreParams p, int metric) {
@@ -821,6 +866,22 @@ hipError_t launch_rescore(const RescoreParams& p, int metric, uint32_t nq, hipSt
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(rescore_select_kernel, dim3(nq), dim3(1024), (size_t)(p.cap / 2) * 8, s, p, metric);
+    return hipGetLastError();
+}
+
+hipError_t launch_refine_tau(const RescoreParams& p, int metric, uint32_t nq, const uint32_t* ntop, uint32_t* lkey,
+                             const float* delta, hipStream_t s) {
+    if (nq == 0) return hipSuccess;
+    const size_t lds = (size_t)((p.dim + 7u) & ~7u) * 4;
+    const uint32_t slices = (p.k + 15u) / 16u + 1u;  // k best + a few ties
+    const dim3 grid(std::min(slices, 64u), nq);
+    if (metric == MVF_METRIC_L2) hipLaunchKernelGGL((rescore_score_kernel<MVF_METRIC_L2, true>), grid, dim3(256), lds, s, p, ntop, lkey);
+    else if (metric == MVF_METRIC_COSINE)
+        hipLaunchKernelGGL((rescore_score_kernel<MVF_METRIC_COSINE, true>), grid, dim3(256), lds, s, p, ntop, lkey);
+    else hipLaunchKernelGGL((rescore_score_kernel<MVF_METRIC_INNER_PRODUCT, true>), grid, dim3(256), lds, s, p, ntop, lkey);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(refine_tau_kernel, dim3((nq + 255u) / 256u), dim3(256), 0, s, p.tau, ntop, lkey, delta, metric, p.k, nq);
     return hipGetLastError();
 }
 
