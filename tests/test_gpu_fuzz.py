@@ -74,3 +74,56 @@ def test_random_case_against_the_oracle(oracle, case):
                     assert_float_topk(metric, res.scores[qi], padded, sc, rf, q[qi], k)
                 if dim >= 16:  # tiny dimensions: crowds of scores within the tolerance of each other (checked above)
                     assert recall_at_k(res.indices, want) >= 0.99, tag
+
+
+@pytest.mark.parametrize("case", range(24))
+def test_random_shard_splits_merge_to_the_unsharded_answer(oracle, case):
+    """Row-range shards (random cut points, empty-ish and one-row shards included), per-shard deletions and ids, through
+    the single-process shard set: the merged top-k equals the unsharded corpus' (ties by global position)."""
+    rng = np.random.default_rng(5000 + case)
+    dtype = int(rng.integers(0, 4))
+    metric = int(rng.integers(0, 3))
+    dim = int(rng.choice([8, 33, 64, 200]))
+    n = int(rng.choice([300, 5000, 40000]))
+    nshards = int(rng.integers(2, 6))
+    cuts = [0] + sorted(int(x) for x in rng.choice(np.arange(1, n), nshards - 1, replace=False)) + [n]
+    rows = oracle.synth_rows(SEED + 99 + case, 0, n, dim, dtype)
+    if dtype >= 2:
+        rows[rng.choice(n, n // 10, replace=False)] = rows[0]  # integer ties across shard boundaries
+    dead = rng.random(n) < 0.2 if rng.random() < 0.5 else None
+    ids = rng.permutation(np.arange(7_000_000, 7_000_000 + n)).astype(np.uint64) if rng.random() < 0.4 else None
+    nq = int(rng.choice([1, 3, 40, 130]))
+    k = int(rng.choice([1, 10, 100, 400]))
+    q = oracle.synth_queries(SEED + 3 * case, nq, dim, dtype)
+
+    def prepare(c, a, b):
+        if dead is not None:
+            c.set_tombstones(np.packbits(dead[a:b], bitorder="little"))
+        if ids is not None:
+            c.set_vector_ids(ids[a:b])
+
+    shards = []
+    try:
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            c = G.GpuCorpus.from_array(rows[a:b], index_base=a)
+            prepare(c, a, b)
+            shards.append(c)
+        with G.ShardSet(shards) as ss:
+            got = ss.search(q, k, metric)
+        with G.GpuCorpus.from_array(rows) as whole:
+            prepare(whole, 0, n)
+            want = whole.search(q, k, metric)
+    finally:
+        for s in shards:
+            s.close()
+    tag = f"case {case}: dtype {dtype} metric {metric} n {n} dim {dim} cuts {cuts} nq {nq} k {k}"
+    if dtype >= 2:
+        assert (got.indices == want.indices).all(), tag
+        assert (got.raw == want.raw).all(), tag
+    else:
+        assert recall_at_k(got.indices, want.indices) >= 0.995, tag
+        assert ((got.indices == PAD) == (want.indices == PAD)).all(), tag
+        live = want.indices != PAD
+        gs, ws = np.where(live, got.scores, 0.0), np.where(live, want.scores, 0.0)
+        scale = max(1.0, float(np.abs(ws).max(initial=1.0)))
+        assert np.abs(np.sort(gs, axis=1) - np.sort(ws, axis=1)).max() <= 2e-5 * scale, tag
