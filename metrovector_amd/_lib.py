@@ -14,7 +14,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 GPU_LIB_PATH = os.environ.get("MVF_GPU_LIB_PATH") or os.path.join(_HERE, "libmvf_gpu.so")  # override: diagnostic builds
-HOST_LIB_PATH = os.path.join(_HERE, "libmvf_host.so")
+HOST_LIB_PATH = os.environ.get("MVF_HOST_LIB_PATH") or os.path.join(_HERE, "libmvf_host.so")  # override: another build (sanitizers)
 
 _gpu = None
 _host = None
