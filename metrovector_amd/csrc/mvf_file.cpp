@@ -311,7 +311,7 @@ class FbBuilder {
         if (head_ >= need) return;
         size_t old = buf_.size(), grow = std::max<size_t>(need - head_, old ? old : 1024);
         std::vector<uint8_t> nb(old + grow, 0);
-        std::memcpy(nb.data() + grow + head_, buf_.data() + head_, old - head_);
+        if (old > head_) std::memcpy(nb.data() + grow + head_, buf_.data() + head_, old - head_);  // (memcpy from an empty vector's null data() is undefined, even for 0 bytes)
         buf_.swap(nb);
         head_ += grow;
     }

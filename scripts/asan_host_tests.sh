@@ -9,4 +9,4 @@ mkdir -p "$O"
 g++ -O1 -g -std=c++17 -fPIC -shared -fsanitize=address,undefined -fno-omit-frame-pointer -Iinclude \
     metrovector_amd/csrc/mvf_file.cpp -o "$O/libmvf_host.so"
 LD_PRELOAD="$(gcc -print-file-name=libasan.so)" ASAN_OPTIONS=detect_leaks=0 UBSAN_OPTIONS=halt_on_error=1 \
-    MVF_HOST_LIB_PATH="$O/libmvf_host.so" python -m pytest tests/test_host_mvf.py -q -x -m "not gpu" -p no:cacheprovider
+    MVF_HOST_LIB_PATH="$O/libmvf_host.so" python -m pytest tests/test_host_mvf.py -q -x -s -m "not gpu" -p no:cacheprovider
