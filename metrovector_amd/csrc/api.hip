@@ -425,6 +425,7 @@ constexpr uint32_t kBatchCapQS = 8192;  // candidate slots per query with int8 s
 // insists; a corpus whose data defeats the int8 bound switches itself back (qs_disabled).
 bool qs_wanted(const mvfgpu_corpus* c) {
     if (is_int_dtype(c->dtype) || c->n == 0) return false;
+    if (!k2_dma_enabled()) return false;  // the register-staged A/B kernel (MVF_K2_DMA=0) has no int8-shadow flavour
     if ((size_t)((c->dim + 7u) & ~7u) * 4 + kBatchCapQS * 4 > 64 * 1024) return false;  // re-scoring: query + candidates in LDS
     if (c->scan_path == 5 || c->scan_path == 6) return true;
     if (c->scan_path != 0 && c->scan_path != 4) return false;
