@@ -127,3 +127,35 @@ def test_random_shard_splits_merge_to_the_unsharded_answer(oracle, case):
         gs, ws = np.where(live, got.scores, 0.0), np.where(live, want.scores, 0.0)
         scale = max(1.0, float(np.abs(ws).max(initial=1.0)))
         assert np.abs(np.sort(gs, axis=1) - np.sort(ws, axis=1)).max() <= 2e-5 * scale, tag
+
+
+@pytest.mark.parametrize("dtype", [0, 1, 2, 3])
+def test_every_combination_of_the_tuning_switches_returns_the_same_rows(oracle, dtype):
+    """The environment switches choose kernels, tiles, shadows and schedules -- never results."""
+    import itertools
+    import os
+    switches = {"MVF_K2_PP": ("0", "1"), "MVF_K2_DMA": ("0", "1"), "MVF_I8_SHADOW": ("0", "1"), "MVF_F16_SHADOW": ("0", "1"),
+                "MVF_K2_TILE": ("64", "256"), "MVF_K2_GROWTH": ("2", "8"), "MVF_QS_REFINE": ("0", "1"),
+                "MVF_K2_PERSISTENT16": ("0", "1")}
+    n, dim, nq, k = 90_000, 72, 140, 25
+    metric = dtype % 3
+    rows = oracle.synth_rows(SEED + dtype, 0, n, dim, dtype)
+    q = oracle.synth_queries(SEED + 50 + dtype, nq, dim, dtype)
+    rng = np.random.default_rng(77 + dtype)
+    combos = list(itertools.product(*switches.values()))
+    picks = [combos[i] for i in rng.choice(len(combos), 48, replace=False)]
+    with G.GpuCorpus.from_array(rows) as c:
+        want = c.search(q, k, metric)
+        for combo in picks:
+            env = dict(zip(switches.keys(), combo))
+            os.environ.update(env)
+            try:
+                got = c.search(q, k, metric)
+            finally:
+                for name in env:
+                    os.environ.pop(name, None)
+            if dtype >= 2:
+                assert (got.indices == want.indices).all() and (got.raw == want.raw).all(), env
+            else:  # exact f32 MFMA selection (both shadows off) sums in another order: rows within 1e-5 may swap
+                assert recall_at_k(got.indices, want.indices) >= 0.999, env
+                assert np.abs(np.sort(got.scores, axis=1) - np.sort(want.scores, axis=1)).max() <= 2e-5 * max(1.0, float(np.abs(want.scores).max())), env
