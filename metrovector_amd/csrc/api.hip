@@ -356,6 +356,13 @@ bool k2_dma_enabled() {
     return !e || atoi(e) != 0;
 }
 
+// One tile of at most 64 queries: the streaming MFMA kernel (scan_mfma16_sb.hip) instead of the 64-query shape of the
+// LDS-DMA tile kernel; MVF_K2_SB=0 goes back (A/B runs).
+bool k2_sb_enabled() {
+    const char* e = getenv("MVF_K2_SB");
+    return !e || atoi(e) != 0;
+}
+
 // 256-query tile: the ping-pong schedule (scan_mfma16_pp.hip) or the lockstep LDS-DMA kernel.  Measured (MI355X,
 // profiles/r02_k2_ab.txt): Float16 rows / the f16 shadow 5 % faster on the ping-pong kernel once a block walks several
 // tiles (cfg5 last phase 20.7 -> 19.7 ms), short phases and Int8 rows a few percent slower (its longer prologue; cfg4
@@ -835,6 +842,8 @@ int search_batched_path(const mvfgpu_corpus* c, uint8_t metric, const void* d_qu
             else if (dma && qpb == 256u && k2_pp_wanted(kdtype, hp.ntiles, hp.mtiles, c->num_cus) &&
                      scan_mfma16_pp_usable(hp.mtiles, c->num_cus, KT))
                 HIP_TRY(launch_scan_mfma16_pp(hp, kdtype, metric, c->num_cus, s));
+            else if (dma && qpb == 64u && k2_sb_enabled() && scan_mfma16_sb_usable(nq_pad, KT, nq))
+                HIP_TRY(launch_scan_mfma16_sb(hp, kdtype, metric, c->num_cus, s));
             else if (dma) HIP_TRY(launch_scan_mfma16_dma(hp, kdtype, metric, c->num_cus, qpb, k2_dma_persistent(kdtype), s));
             else HIP_TRY(launch_scan_mfma16(hp, kdtype, metric, c->num_cus, s));
             if (ps && last) {

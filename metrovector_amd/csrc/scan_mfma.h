@@ -139,6 +139,9 @@ hipError_t launch_refine_tau(const RescoreParams& p, int metric, uint32_t nq, co
 
 uint32_t scan_mfma16_queries_per_block(int dtype);
 hipError_t launch_scan_mfma16(const Batch16Params& p, int dtype, int metric, int num_cus, hipStream_t s);
+// small batches (one tile of <= 64 queries): streaming kernel with MFMA dots (scan_mfma16_sb.hip)
+bool scan_mfma16_sb_usable(uint32_t nq_pad, uint32_t KT, uint32_t nq);
+hipError_t launch_scan_mfma16_sb(const Batch16Params& p, int dtype, int metric, int num_cus, hipStream_t s);
 uint32_t scan_mfma16_dma_queries_per_block(uint32_t nq);
 uint32_t scan_mfma16_dma_tile_rows(uint32_t bmq);
 hipError_t launch_scan_mfma16_dma(const Batch16Params& p, int dtype, int metric, int num_cus, uint32_t bmq, bool persistent,

@@ -21,6 +21,12 @@ __global__ void __launch_bounds__(256) read_kernel(const unsigned char* rows, ui
             const unsigned char* rp = rows + (size_t)(g * 16 + (lane & 15)) * pitch + (lane >> 4) * 16;
 #pragma unroll
             for (int j = 0; j < KT; j++) x[j] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(rp + j * 64));
+        } else if (SHAPE == 2) {  // 4 rows x 256 B per instruction, COLUMN-BLOCK-major over 16 rows (scan_mfma16_sb.hip's stages)
+#pragma unroll
+            for (int j = 0; j < KT; j++) {
+                const int seg = j / 4, rr = (j % 4) * 4 + (lane >> 4);
+                x[j] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(rows + (size_t)(g * 16 + rr) * pitch + seg * 256 + (lane & 15) * 16));
+            }
         } else {           // 4 rows x 256 B per instruction (K1's G = 16 shape), KT / 4 instructions per 4 rows
 #pragma unroll
             for (int j = 0; j < KT; j++) {
@@ -34,31 +40,40 @@ __global__ void __launch_bounds__(256) read_kernel(const unsigned char* rows, ui
     if (acc == 0x12345678u) out[0] = acc;
 }
 
+template <int KT>
+void run(const unsigned char* d, uint32_t n, uint32_t pitch, uint32_t* o, hipEvent_t e0, hipEvent_t e1) {
+    for (int shape = 0; shape < 3; shape++) {
+        float best = 1e9f;
+        for (int it = 0; it < 6; it++) {
+            hipEventRecord(e0);
+            if (shape == 0) hipLaunchKernelGGL((read_kernel<KT, 0>), dim3(1024), dim3(256), 0, 0, d, n, pitch, o);
+            else if (shape == 1) hipLaunchKernelGGL((read_kernel<KT, 1>), dim3(1024), dim3(256), 0, 0, d, n, pitch, o);
+            else hipLaunchKernelGGL((read_kernel<KT, 2>), dim3(1024), dim3(256), 0, 0, d, n, pitch, o);
+            hipEventRecord(e1);
+            hipEventSynchronize(e1);
+            float ms;
+            hipEventElapsedTime(&ms, e0, e1);
+            if (ms < best) best = ms;
+        }
+        printf("pitch %4u rows %8u shape %d (%s): %.3f ms  %.2f TB/s\n", pitch, n, shape,
+               shape == 0 ? "16 rows x 64 B" : shape == 1 ? "4 rows x 256 B, row-major" : "4 rows x 256 B, column-block-major over 16 rows", best,
+               (double)n * (KT * 64) / best / 1e9);
+    }
+}
+
 int main() {
-    const uint32_t n = 10000000, pitch = 768;
     unsigned char* d;
     uint32_t* o;
-    hipMalloc(&d, (size_t)n * pitch);
+    const size_t bytes = (size_t)12500000 * 1040;
+    hipMalloc(&d, bytes);
     hipMalloc(&o, 4);
-    hipMemset(d, 1, (size_t)n * pitch);
+    hipMemset(d, 1, bytes);
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
     hipEventCreate(&e1);
-    for (int shape = 0; shape < 2; shape++)
-        for (int blocks : {256 * 2, 256 * 4, 256 * 8}) {
-            float best = 1e9f;
-            for (int it = 0; it < 6; it++) {
-                hipEventRecord(e0);
-                if (shape == 0) hipLaunchKernelGGL((read_kernel<12, 0>), dim3(blocks), dim3(256), 0, 0, d, n, pitch, o);
-                else hipLaunchKernelGGL((read_kernel<12, 1>), dim3(blocks), dim3(256), 0, 0, d, n, pitch, o);
-                hipEventRecord(e1);
-                hipEventSynchronize(e1);
-                float ms;
-                hipEventElapsedTime(&ms, e0, e1);
-                if (ms < best) best = ms;
-            }
-            printf("shape %d (%s) blocks %4d: %.3f ms  %.2f TB/s\n", shape, shape == 0 ? "16 rows x 64 B" : "4 rows x 256 B", blocks, best,
-                   (double)n * pitch / best / 1e9);
-        }
+    run<12>(d, 10000000, 768, o, e0, e1);
+    run<16>(d, 12500000, 1024, o, e0, e1);
+    run<16>(d, 12500000, 1040, o, e0, e1);   // the same row bytes, rows 16 bytes further apart
+    run<8>(d, 20000000, 512, o, e0, e1);
     return 0;
 }
