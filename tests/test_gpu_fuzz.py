@@ -136,7 +136,7 @@ def test_every_combination_of_the_tuning_switches_returns_the_same_rows(oracle, 
     import os
     switches = {"MVF_K2_PP": ("0", "1"), "MVF_K2_DMA": ("0", "1"), "MVF_I8_SHADOW": ("0", "1"), "MVF_F16_SHADOW": ("0", "1"),
                 "MVF_K2_TILE": ("64", "256"), "MVF_K2_GROWTH": ("2", "8"), "MVF_QS_REFINE": ("0", "1"),
-                "MVF_K2_PERSISTENT16": ("0", "1")}
+                "MVF_K2_PERSISTENT16": ("0", "1"), "MVF_K2_SB": ("0", "1")}
     n, dim, nq, k = 90_000, 72, 140, 25
     metric = dtype % 3
     rows = oracle.synth_rows(SEED + dtype, 0, n, dim, dtype)
@@ -146,16 +146,20 @@ def test_every_combination_of_the_tuning_switches_returns_the_same_rows(oracle, 
     picks = [combos[i] for i in rng.choice(len(combos), 48, replace=False)]
     with G.GpuCorpus.from_array(rows) as c:
         want = c.search(q, k, metric)
+        want_small = c.search(q[:40], k, metric)   # one tile of <= 64 queries: the streaming MFMA kernel's range
         for combo in picks:
             env = dict(zip(switches.keys(), combo))
             os.environ.update(env)
             try:
                 got = c.search(q, k, metric)
+                got_small = c.search(q[:40], k, metric)
             finally:
                 for name in env:
                     os.environ.pop(name, None)
             if dtype >= 2:
                 assert (got.indices == want.indices).all() and (got.raw == want.raw).all(), env
+                assert (got_small.indices == want_small.indices).all() and (got_small.raw == want_small.raw).all(), env
             else:  # exact f32 MFMA selection (both shadows off) sums in another order: rows within 1e-5 may swap
                 assert recall_at_k(got.indices, want.indices) >= 0.999, env
+                assert recall_at_k(got_small.indices, want_small.indices) >= 0.999, env
                 assert np.abs(np.sort(got.scores, axis=1) - np.sort(want.scores, axis=1)).max() <= 2e-5 * max(1.0, float(np.abs(want.scores).max())), env
