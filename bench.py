@@ -490,6 +490,24 @@ def main():
                     leg["recall_queries_checked"] = len(sel)
                 result[name] = leg
             corpus.set_scan_path(0)
+            # ---- small batches on the same corpus: one tile of queries, HBM-bound (the streaming MFMA kernel on the int8
+            # shadow; every candidate inside the proven bound re-scored exactly) -- wall time per search, default path
+            small = {}
+            for nqs in (4, 16, 64):
+                for _ in range(3):
+                    searcher.search(dqb[:nqs], args.k, args.metric)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(20):
+                    outs = searcher.search(dqb[:nqs], args.k, args.metric)
+                torch.cuda.synchronize()
+                es_ = (time.perf_counter() - t0) / 20
+                small[f"q{nqs}"] = {"ms_per_step": es_ * 1e3, "value": float(nqs) * args.rows / es_, "unit": "distance-ops/s"}
+            # the first rows of the 1024-query result (exact f32 MFMA leg) are these queries' answers
+            a, b = outs[1][:4].cpu().numpy(), outb[1][:4].cpu().numpy()
+            small["overlap_with_batched_q1024_f32_mfma_first_4_queries"] = float(
+                sum(len(set(x.tolist()) & set(y.tolist())) for x, y in zip(a, b)) / b.size)
+            result["small_batches"] = small
 
     corpus.close()
     del searcher
