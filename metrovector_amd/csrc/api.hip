@@ -580,9 +580,12 @@ int repair_flagged_queries(const mvfgpu_corpus* c, uint8_t metric, const void* d
     int occ = 0;
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kfn, 256, lds));
     if (occ < 1) occ = 1;
-    const uint32_t nblocks = std::min<uint32_t>(nchunks, (uint32_t)occ * (uint32_t)c->num_cus);
+    // Two blocks per CU at most: the repair is rare, and every block's list costs scratch for EVERY query a launch pair may
+    // serve -- with fewer lists a pair serves up to 256 queries, and a 1024-query search enqueues 4 (empty) pairs
+    // instead of 16 (0.14 ms of launches on a 10-ms search).
+    const uint32_t nblocks = std::min<uint32_t>(nchunks, (uint32_t)std::min(occ, 2) * (uint32_t)c->num_cus);
     const size_t per_query = (size_t)nblocks * kcap * 8;
-    const uint32_t R = (uint32_t)std::min<size_t>(64, std::max<size_t>(4, ((size_t)256 << 20) / per_query));
+    const uint32_t R = (uint32_t)std::min<size_t>(256, std::max<size_t>(4, ((size_t)256 << 20) / per_query));
     HIP_TRY(c->repair.reserve((size_t)R * per_query + (size_t)nq * 4 + 16));
     uint64_t* lists = static_cast<uint64_t*>(c->repair.p);
     uint32_t* redo_cnt = reinterpret_cast<uint32_t*>(static_cast<unsigned char*>(c->repair.p) + (size_t)R * per_query);
