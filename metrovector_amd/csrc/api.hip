@@ -831,6 +831,7 @@ int search_batched_path(const mvfgpu_corpus* c, uint8_t metric, const void* d_qu
     }
     size_t bi = 0;
     uint64_t begin = 0, end = bounds[0];
+    bool regions_armed = false;
     for (;;) {
         const bool last = end >= n;
         if (end > begin) {
@@ -839,7 +840,11 @@ int search_batched_path(const mvfgpu_corpus* c, uint8_t metric, const void* d_qu
             bp.ntiles = hp.ntiles = (uint32_t)((end - begin + tile_rows - 1) / tile_rows);
             bp.direct = hp.direct = (begin == 0 && end - begin <= cap) ? 1u : 0u;
             const bool regions = hp.blk_cand && !hp.direct;
-            if (regions) HIP_TRY(hipMemsetAsync(hp.blk_cnt, 0, (size_t)kBlkMaxBlocks * 4, s));
+            // the region counters: zeroed once, re-armed by every scatter after it has read them
+            if (regions && (!regions_armed || nq_pad > scatter_rearm_max_queries())) {
+                HIP_TRY(hipMemsetAsync(hp.blk_cnt, 0, (size_t)kBlkMaxBlocks * 4, s));
+                regions_armed = true;
+            }
             if (ps && last) HIP_TRY(hipEventRecord(ps->e[0], s));
             if (wide) HIP_TRY(launch_scan_mfma_f32(bp, metric, c->num_cus, s));
             else if (dma && qpb == 256u && k2_pp_wanted(kdtype, hp.ntiles, hp.mtiles, c->num_cus) &&
@@ -880,6 +885,20 @@ int search_batched_path(const mvfgpu_corpus* c, uint8_t metric, const void* d_qu
         end = bounds[++bi];
     }
     if (approx) {  // exact scores of the kept candidates from the caller's f32 queries, final top-k
+        if (refine && n >= kRefineMinRows) {  // once more on the final lists: the re-scoring skips what falls outside
+            RescoreParams fp{};
+            fp.cand = bp.cand;
+            fp.cnt = cnt;
+            fp.tau = tau;
+            fp.cap = cap;
+            fp.k = k;
+            fp.queries = static_cast<const float*>(d_queries);
+            fp.rows = c->d_rows;
+            fp.pitch = c->pitch;
+            fp.dim = c->dim;
+            fp.dtype = c->dtype;
+            HIP_TRY(launch_refine_tau(fp, metric, nq, ntop, lkey, qdelta, s));
+        }
         RescoreParams rp{};
         rp.cand = bp.cand;
         rp.cnt = cnt;

@@ -150,7 +150,9 @@ hipError_t launch_scan_mfma16_dma(const Batch16Params& p, int dtype, int metric,
 bool scan_mfma16_pp_usable(uint32_t mtiles, int num_cus, uint32_t KT);
 hipError_t launch_scan_mfma16_pp(const Batch16Params& p, int dtype, int metric, int num_cus, hipStream_t s);
 // files the per-block candidate records of one K2 launch into the per-query lists (p.cand / p.cnt)
+// (re-arms blk_cnt[] to zero for the next phase, unless more than `scatter_rearm_max_queries()` queries take the simple form)
 hipError_t launch_scatter_cand(const Batch16Params& p, uint32_t nblocks, hipStream_t s);
+uint32_t scatter_rearm_max_queries();
 hipError_t launch_prep_queries16(const void* q, int dtype, uint32_t nq, uint32_t nq_pad, uint32_t dim, uint32_t KPB,
                                  unsigned char* qprep, float* qaux0, float* qaux1, hipStream_t s);
 hipError_t launch_shadow_f16(const unsigned char* rows32, uint32_t n, uint32_t pitch32, uint32_t dim, unsigned char* rows16,

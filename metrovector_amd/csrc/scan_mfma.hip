@@ -391,7 +391,7 @@ __global__ void __launch_bounds__(256) row_norms_f32_kernel(const unsigned char*
 // (8 regions x 2 passes: 50-100 us per call, 0.4 ms of a 10.8-ms search).
 constexpr uint32_t kScatterBlocks = 128, kScatterMaxQueries = 8192, kScatterMaxPer = 64;
 
-__global__ void __launch_bounds__(1024) scatter_cand_kernel(const uint4* blk_cand, const uint32_t* blk_cnt, uint32_t blk_cap,
+__global__ void __launch_bounds__(1024) scatter_cand_kernel(const uint4* blk_cand, uint32_t* blk_cnt, uint32_t blk_cap,
                                                              uint32_t nregions, uint64_t* cand, uint32_t* cnt, uint32_t cap,
                                                              uint32_t nq_pad) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -437,6 +437,8 @@ __global__ void __launch_bounds__(1024) scatter_cand_kernel(const uint4* blk_can
         const uint32_t slot = atomicAdd(&hist[rec.z], 1u);
         if (slot < cap) cand[(size_t)rec.z * cap + slot] = ((uint64_t)rec.x << 32) | rec.y;
     }
+    // re-arm the counters of this block's regions for the next phase (a scan block without work does not write its own)
+    if (threadIdx.x < nreg) blk_cnt[r_lo + threadIdx.x] = 0u;
 }
 
 __global__ void __launch_bounds__(256) scatter_cand_simple_kernel(const uint4* blk_cand, const uint32_t* blk_cnt, uint32_t blk_cap,
@@ -670,15 +672,20 @@ __global__ void __launch_bounds__(256) rescore_score_kernel(RescoreParams p, con
     if (METRIC == MVF_METRIC_COSINE) qq = (qq_part[0] + qq_part[1]) + (qq_part[2] + qq_part[3]);
     uint64_t* c = p.cand + (size_t)q * p.cap;
     const uint32_t V = p.pitch / 16;
+    const uint32_t tau_q = p.tau[q];
     for (uint32_t c0 = blockIdx.x * 16u; c0 < m; c0 += gridDim.x * 16u) {
         // this wave's four candidates: c0 + wave * 4 + u (a row past the end repeats the slice's first; not written)
         uint32_t r[4];
         const unsigned char* rp[4];
         float s[4], xx[4];
+        bool skip[4];
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             const uint32_t ci = c0 + (uint32_t)wave * 4u + u;
-            r[u] = (uint32_t)c[ci < m ? ci : c0];
+            const uint64_t ce = c[ci < m ? ci : c0];
+            r[u] = (uint32_t)ce;
+            // outside the (possibly refined) threshold: cannot be in the top-k; not fetched, not scored
+            skip[u] = !REFINE && tau_q != kNanKey && (uint32_t)(ce >> 32) > tau_q;
             rp[u] = p.rows + (size_t)r[u] * p.pitch;
             s[u] = 0.f;
             xx[u] = 0.f;
@@ -686,7 +693,7 @@ __global__ void __launch_bounds__(256) rescore_score_kernel(RescoreParams p, con
         for (uint32_t v = lane; v < V; v += 64) {
             u32x4 x[4];
 #pragma unroll
-            for (int u = 0; u < 4; u++) x[u] = *reinterpret_cast<const u32x4*>(rp[u] + (size_t)v * 16);
+            for (int u = 0; u < 4; u++) x[u] = skip[u] ? u32x4{0, 0, 0, 0} : *reinterpret_cast<const u32x4*>(rp[u] + (size_t)v * 16);
 #pragma unroll
             for (int u = 0; u < 4; u++) {
                 auto term = [&](float qv, float xv) __attribute__((always_inline)) {
@@ -727,7 +734,7 @@ __global__ void __launch_bounds__(256) rescore_score_kernel(RescoreParams p, con
             if (REFINE) {
                 if (lane == 0 && ci < m) atomicMax(&lkey[q], key_from_score(sc, METRIC));  // the worst of the exact scores
             } else if (lane == 0 && ci < m) {
-                c[ci] = ((uint64_t)key_from_score(sc, METRIC) << 32) | r[u];
+                c[ci] = skip[u] ? kPadComposite : ((uint64_t)key_from_score(sc, METRIC) << 32) | r[u];
             }
         }
     }
@@ -822,6 +829,8 @@ hipError_t launch_row_norms_f32(const unsigned char* rows, uint32_t n, uint32_t 
     hipLaunchKernelGGL(row_norms_f32_kernel, dim3(blocks), dim3(256), 0, s, rows, n, pitch, pitch / 16, xnorm, xx2, xxmax);
     return hipGetLastError();
 }
+
+uint32_t scatter_rearm_max_queries() { return kScatterMaxQueries; }
 
 hipError_t launch_scatter_cand(const Batch16Params& p, uint32_t nblocks, hipStream_t s) {
     if (!p.blk_cand || nblocks == 0) return hipSuccess;
