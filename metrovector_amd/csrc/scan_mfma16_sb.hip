@@ -53,6 +53,11 @@ constexpr int SB_RCSLOTS = 8;       // per wave: row-constant buffers of the gro
 constexpr int SB_RC = SB_NW * SB_RCSLOTS * 2 * 16 * 4;  // two arrays x 16 dwords each
 constexpr int SB_AUX = 4 * SB_Q * 4 + SB_RC + 16;
 constexpr size_t SB_LDS_MAX = 156 * 1024;  // of the CU's 160 KB
+// cache policy of the corpus-row DMA: nontemporal (aux bit 1) -- the rows are read once; with the default policy they
+// wash through L2 and the same kernel is 7-12 % slower (1.51 vs 1.35 ms per 8-query search of 10M x 768).  (The tile
+// kernels must NOT do this: their 64-byte pieces fetch a 128-byte line in two halves, one k-tile apart, and the second
+// half then comes from HBM again: cfg4 11.5 -> 13.2 ms.)
+constexpr int SB_AUX_POLICY = 2;
 
 // vmcnt(n) only (lgkmcnt / expcnt untouched), n a multiple of 4 up to 20
 __device__ __forceinline__ void wait_vmcnt(uint32_t n) {
@@ -139,7 +144,7 @@ __global__ void __launch_bounds__(512, 1) scan_mfma16_sb_kernel(Batch16Params p,
             const uint32_t rl = 4u * t + lrow, r = r0 + rl;
             const uint32_t v = dc.s4 * 16u + (lslot ^ rl);  // 16-byte vector of the row
             const unsigned char* src = v < p.V ? p.rows + (size_t)(r < p.row_end ? r : r0) * p.pitch + (size_t)v * 16u : p.zeros;
-            __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)(st + t * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)(st + t * 1024), 16, 0, SB_AUX_POLICY);
         }
         if (dc.s4 == 0u) {  // the group's row constants (entry lane % 16; rows past row_end repeat the last valid one)
             uint32_t* dst = rc_s + (((uint32_t)wave * SB_RCSLOTS + dc.rcs) * 2u) * 16u;
