@@ -47,11 +47,23 @@ typedef const __attribute__((address_space(1))) void* glb_ptr_t;
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int SB_NW = 8;            // waves per block
-constexpr int SB_Q = 64;            // queries per launch tile (NI = 4 MFMA sub-tiles of 16)
-constexpr int SB_STAGE = 16 * 256;  // bytes of one ring stage: 16 rows x 256 B = 4 k-steps
-constexpr int SB_RCSLOTS = 8;       // per wave: row-constant buffers of the groups in flight (group ordinal mod 8 >= the 6 stages a ring holds)
+// Two tile widths.  NQT = 64 queries (NI = 4 MFMA sub-tiles): ring stages of 16 rows x 256 B (four k-steps, four DMA
+// instructions of 4 rows x 256 B).  NQT = 128 queries (NI = 8): the query tile takes up to 96 KB of LDS, so the stages
+// are 16 rows x 128 B (two k-steps, two instructions of 8 rows x 128 B -- still whole 128-byte lines).
+template <int NQT> struct SbT {
+    static constexpr int Q = NQT;
+    static constexpr int NI = NQT / 16;
+    static constexpr int SRB = NQT == 64 ? 256 : 128;  // stage bytes per row
+    static constexpr int CPR = SRB / 16;               // 16-byte chunks per row and stage
+    static constexpr int RPI = 64 / CPR;               // rows per DMA instruction
+    static constexpr int IPS = 16 / RPI;               // DMA instructions per stage
+    static constexpr int KPS = SRB / 64;               // k-steps per stage
+    static constexpr int STAGE = 16 * SRB;             // bytes of one ring stage
+    static constexpr int MAXST = NQT == 64 ? 6 : 8;    // ring stages per wave at most
+};
+constexpr int SB_RCSLOTS = 8;       // per wave: row-constant buffers of the groups in flight (group ordinal mod 8 >= the stages a ring holds)
 constexpr int SB_RC = SB_NW * SB_RCSLOTS * 2 * 16 * 4;  // two arrays x 16 dwords each
-constexpr int SB_AUX = 4 * SB_Q * 4 + SB_RC + 16;
+constexpr int sb_aux(int nqt) { return 4 * nqt * 4 + SB_RC + 16; }
 constexpr size_t SB_LDS_MAX = 156 * 1024;  // of the CU's 160 KB
 // cache policy of the corpus-row DMA: nontemporal (aux bit 1) -- the rows are read once; with the default policy they
 // wash through L2 and the same kernel is 7-12 % slower (1.51 vs 1.35 ms per 8-query search of 10M x 768).  (The tile
@@ -59,26 +71,32 @@ constexpr size_t SB_LDS_MAX = 156 * 1024;  // of the CU's 160 KB
 // half then comes from HBM again: cfg4 11.5 -> 13.2 ms.)
 constexpr int SB_AUX_POLICY = 2;
 
-// vmcnt(n) only (lgkmcnt / expcnt untouched), n a multiple of 4 up to 20
+// vmcnt(n) only (lgkmcnt / expcnt untouched), n even, up to 20 (larger: 20 -- stricter, still correct)
 __device__ __forceinline__ void wait_vmcnt(uint32_t n) {
     switch (n) {
     case 0: __builtin_amdgcn_s_waitcnt(0x0F70); break;
+    case 2: __builtin_amdgcn_s_waitcnt(0x0F72); break;
     case 4: __builtin_amdgcn_s_waitcnt(0x0F74); break;
+    case 6: __builtin_amdgcn_s_waitcnt(0x0F76); break;
     case 8: __builtin_amdgcn_s_waitcnt(0x0F78); break;
+    case 10: __builtin_amdgcn_s_waitcnt(0x0F7A); break;
     case 12: __builtin_amdgcn_s_waitcnt(0x0F7C); break;
+    case 14: __builtin_amdgcn_s_waitcnt(0x0F7E); break;
     case 16: __builtin_amdgcn_s_waitcnt(0x4F70); break;
+    case 18: __builtin_amdgcn_s_waitcnt(0x4F72); break;
     default: __builtin_amdgcn_s_waitcnt(0x4F74); break;  // 20
     }
 }
 
-template <int DT, int METRIC, bool DIRECT, bool XS>
+template <int DT, int METRIC, bool DIRECT, bool XS, int NQT>
 __global__ void __launch_bounds__(512, 1) scan_mfma16_sb_kernel(Batch16Params p, uint32_t nst, uint32_t ni) {
     using AccT = typename std::conditional<DT == MVF_DTYPE_FLOAT16, f32x4, i32x4>::type;
-    constexpr int NI = SB_Q / 16, SH = 16;
+    using Sb = SbT<NQT>;
+    constexpr int NI = Sb::NI, SH = 16, SB_Q = NQT, SB_STAGE = Sb::STAGE;
     constexpr bool U8 = DT == MVF_DTYPE_UINT8;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t KT = p.KT;                        // 64-byte k-steps of a (padded) query row
-    const uint32_t S4 = (KT + 3u) / 4u;              // ring stages per 16-row group
+    const uint32_t S4 = (KT + Sb::KPS - 1u) / Sb::KPS;  // ring stages per 16-row group
     unsigned char* a_s = smem;                       // [KT][ni][1 KB] query fragments
     unsigned char* ring0 = a_s + (size_t)KT * ni * 1024u;
     float* qa_s = reinterpret_cast<float*>(ring0 + (size_t)SB_NW * nst * SB_STAGE);
@@ -134,21 +152,25 @@ __global__ void __launch_bounds__(512, 1) scan_mfma16_sb_kernel(Batch16Params p,
             c.rcs = (c.rcs + 1u) & (SB_RCSLOTS - 1u);
         }
     };
-    // DMA of the cursor's item: four instructions, lane L -> row 4 t + L / 16, source chunk (L % 16) ^ row
-    const uint32_t lrow = (uint32_t)lane >> 4, lslot = (uint32_t)lane & 15u;
+    // DMA of the cursor's item: IPS instructions, lane L -> row RPI t + L / CPR, source chunk (L % CPR) ^ swz(row).
+    // swz: the fragment reads below take 16 rows of ONE chunk at a time; in the 256-byte image a row is one pass over the
+    // banks, so the chunk moves by the row (slot = chunk ^ row); in the 128-byte image two rows share a pass (slot =
+    // chunk ^ (row >> 1), the row's parity picks the half).
+    const uint32_t lrow = (uint32_t)lane / Sb::CPR, lslot = (uint32_t)lane % Sb::CPR;
+    auto swz = [](uint32_t row) __attribute__((always_inline)) -> uint32_t { return Sb::CPR == 16 ? (row & 15u) : ((row >> 1) & 7u); };
     auto issue = [&]() __attribute__((always_inline)) {
         const uint32_t r0 = p.row_begin + dc.g * 16u;
         unsigned char* st = ring + (size_t)dc.slot * SB_STAGE;
 #pragma unroll
-        for (int t = 0; t < 4; t++) {
-            const uint32_t rl = 4u * t + lrow, r = r0 + rl;
-            const uint32_t v = dc.s4 * 16u + (lslot ^ rl);  // 16-byte vector of the row
+        for (int t = 0; t < Sb::IPS; t++) {
+            const uint32_t rl = (uint32_t)Sb::RPI * t + lrow, r = r0 + rl;
+            const uint32_t v = dc.s4 * Sb::CPR + (lslot ^ swz(rl));  // 16-byte vector of the row
             const unsigned char* src = v < p.V ? p.rows + (size_t)(r < p.row_end ? r : r0) * p.pitch + (size_t)v * 16u : p.zeros;
             __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)(st + t * 1024), 16, 0, SB_AUX_POLICY);
         }
         if (dc.s4 == 0u) {  // the group's row constants (entry lane % 16; rows past row_end repeat the last valid one)
             uint32_t* dst = rc_s + (((uint32_t)wave * SB_RCSLOTS + dc.rcs) * 2u) * 16u;
-            const uint32_t e = min(r0 + lslot, p.row_end - 1u);
+            const uint32_t e = min(r0 + ((uint32_t)lane & 15u), p.row_end - 1u);
             if (lane < 16) {  // sixteen lanes, one dword each
                 if (NEED0) __builtin_amdgcn_global_load_lds((glb_ptr_t)(arr0 + e), (lds_ptr_t)dst, 4, 0, 0);
                 if (NEED1) __builtin_amdgcn_global_load_lds((glb_ptr_t)(arr1 + e), (lds_ptr_t)(dst + 16), 4, 0, 0);
@@ -181,15 +203,15 @@ __global__ void __launch_bounds__(512, 1) scan_mfma16_sb_kernel(Batch16Params p,
         asm volatile("" ::: "memory");
         if (it + ahead < items) issue();
         const uint32_t younger = min(ahead, items - 1u - it);  // stages issued after this one (their row constants, if
-        wait_vmcnt(4u * younger);                               // any, only make the wait stricter)
+        wait_vmcnt((uint32_t)Sb::IPS * younger);                // any, only make the wait stricter)
         asm volatile("" ::: "memory");
 
         const unsigned char* st = ring + (size_t)cc.slot * SB_STAGE;
 #pragma unroll
-        for (int k4 = 0; k4 < 4; k4++) {
-            const uint32_t ks = cc.s4 * 4u + k4;
+        for (int k4 = 0; k4 < Sb::KPS; k4++) {
+            const uint32_t ks = cc.s4 * Sb::KPS + k4;
             if (ks < KT) {  // wave-uniform
-                u32x4 fb = *reinterpret_cast<const u32x4*>(st + frow * 256u + (((uint32_t)k4 * 4u + fq) ^ frow) * 16u);
+                u32x4 fb = *reinterpret_cast<const u32x4*>(st + frow * (uint32_t)Sb::SRB + (((uint32_t)k4 * 4u + fq) ^ swz(frow)) * 16u);
                 if (U8) fb ^= u32x4{0x80808080u, 0x80808080u, 0x80808080u, 0x80808080u};  // x_u -> x_s
                 const unsigned char* af = a_s + (size_t)ks * ni * 1024u + (uint32_t)lane * 16u;
 #pragma unroll
@@ -210,57 +232,74 @@ __global__ void __launch_bounds__(512, 1) scan_mfma16_sb_kernel(Batch16Params p,
     if (tid == 0 && p.blk_cnt) p.blk_cnt[blockIdx.x] = min(*bc_s, p.blk_cap);
 }
 
-template <int DT, int METRIC>
+template <int DT, int METRIC, int NQT>
 hipError_t launch_dtm(const Batch16Params& p, dim3 grid, size_t lds, uint32_t nst, uint32_t ni, hipStream_t s) {
     void (*fn)(Batch16Params, uint32_t, uint32_t) =
-        p.direct ? &scan_mfma16_sb_kernel<DT, METRIC, true, false> : &scan_mfma16_sb_kernel<DT, METRIC, false, false>;
+        p.direct ? &scan_mfma16_sb_kernel<DT, METRIC, true, false, NQT> : &scan_mfma16_sb_kernel<DT, METRIC, false, false, NQT>;
     if constexpr (DT == MVF_DTYPE_FLOAT16 || DT == MVF_DTYPE_INT8)  // rows are a scaled shadow (f16, or the int8 shadow)
-        if (p.xscale) fn = p.direct ? &scan_mfma16_sb_kernel<DT, METRIC, true, true> : &scan_mfma16_sb_kernel<DT, METRIC, false, true>;
+        if (p.xscale)
+            fn = p.direct ? &scan_mfma16_sb_kernel<DT, METRIC, true, true, NQT> : &scan_mfma16_sb_kernel<DT, METRIC, false, true, NQT>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(fn, grid, dim3(512), lds, s, p, nst, ni);
     return hipGetLastError();
 }
 
-template <int DT>
+template <int DT, int NQT>
 hipError_t launch_dt(const Batch16Params& p, int metric, dim3 grid, size_t lds, uint32_t nst, uint32_t ni, hipStream_t s) {
     switch (metric) {
-    case MVF_METRIC_L2: return launch_dtm<DT, MVF_METRIC_L2>(p, grid, lds, nst, ni, s);
-    case MVF_METRIC_INNER_PRODUCT: return launch_dtm<DT, MVF_METRIC_INNER_PRODUCT>(p, grid, lds, nst, ni, s);
-    default: return launch_dtm<DT, MVF_METRIC_COSINE>(p, grid, lds, nst, ni, s);
+    case MVF_METRIC_L2: return launch_dtm<DT, MVF_METRIC_L2, NQT>(p, grid, lds, nst, ni, s);
+    case MVF_METRIC_INNER_PRODUCT: return launch_dtm<DT, MVF_METRIC_INNER_PRODUCT, NQT>(p, grid, lds, nst, ni, s);
+    default: return launch_dtm<DT, MVF_METRIC_COSINE, NQT>(p, grid, lds, nst, ni, s);
     }
 }
 
-// ring stages per wave that fit beside `ni` query sub-tiles of KT k-steps (0: does not fit)
-uint32_t sb_stages(uint32_t KT, uint32_t ni) {
-    const size_t fixed = (size_t)KT * ni * 1024u + SB_AUX;
-    if (fixed + (size_t)SB_NW * 2u * SB_STAGE > SB_LDS_MAX) return 0u;
-    return (uint32_t)std::min<size_t>(6u, (SB_LDS_MAX - fixed) / ((size_t)SB_NW * SB_STAGE));
+template <int NQT>
+hipError_t launch_nqt(const Batch16Params& p, int dtype, int metric, dim3 grid, size_t lds, uint32_t nst, uint32_t ni, hipStream_t s) {
+    if (dtype == MVF_DTYPE_FLOAT16) return launch_dt<MVF_DTYPE_FLOAT16, NQT>(p, metric, grid, lds, nst, ni, s);
+    if (dtype == MVF_DTYPE_UINT8) return launch_dt<MVF_DTYPE_UINT8, NQT>(p, metric, grid, lds, nst, ni, s);
+    return launch_dt<MVF_DTYPE_INT8, NQT>(p, metric, grid, lds, nst, ni, s);
+}
+
+// the tile width for nq queries, the 16-query sub-tiles that hold real queries, and the ring stages per wave that fit
+// beside them (0: the query fragments do not leave room for two)
+struct SbShape {
+    uint32_t nqt, ni, nst;
+    size_t lds;
+};
+SbShape sb_shape(uint32_t KT, uint32_t nq) {
+    SbShape sh{};
+    sh.nqt = nq <= 64u ? 64u : 128u;
+    sh.ni = nq <= 16u ? 1u : nq <= 32u ? 2u : (nq + 15u) / 16u;
+    if (sh.nqt == 64u && sh.ni == 3u) sh.ni = 4u;
+    const size_t stage = sh.nqt == 64u ? SbT<64>::STAGE : SbT<128>::STAGE;
+    const uint32_t maxst = sh.nqt == 64u ? SbT<64>::MAXST : SbT<128>::MAXST;
+    const size_t fixed = (size_t)KT * sh.ni * 1024u + sb_aux((int)sh.nqt);
+    if (nq > 128u || KT == 0 || fixed + (size_t)SB_NW * 2u * stage > SB_LDS_MAX) return sh;  // nst = 0
+    sh.nst = (uint32_t)std::min<size_t>(maxst, (SB_LDS_MAX - fixed) / ((size_t)SB_NW * stage));
+    sh.lds = fixed + (size_t)SB_NW * sh.nst * stage;
+    return sh;
 }
 
 }  // namespace
 
-// One query tile of at most 64 queries (p.nq_pad == 64, p.mtiles == 1) whose fragments fit in LDS beside two ring stages
-// per wave; p.KT / p.KPB in 64-byte k-steps as for the LDS-DMA kernel.
+// One query tile of at most 128 queries (p.nq_pad <= 128: the prepared queries are one [nq_pad][KPB] array) whose
+// fragments fit in LDS beside two ring stages per wave; p.KT / p.KPB in 64-byte k-steps as for the LDS-DMA kernel.
 bool scan_mfma16_sb_usable(uint32_t nq_pad, uint32_t KT, uint32_t nq) {
-    if (nq_pad != (uint32_t)SB_Q || KT == 0) return false;
-    const uint32_t ni = nq <= 16 ? 1u : nq <= 32 ? 2u : 4u;
-    return sb_stages(KT, ni) >= 2u;
+    if (nq_pad > 128u || nq > nq_pad) return false;
+    return sb_shape(KT, nq).nst >= 2u;
 }
 
 hipError_t launch_scan_mfma16_sb(const Batch16Params& p, int dtype, int metric, int num_cus, hipStream_t s) {
-    const uint32_t ni = p.nq <= 16 ? 1u : p.nq <= 32 ? 2u : 4u;  // 16-query sub-tiles that hold real queries
-    const uint32_t nst = sb_stages(p.KT, ni);
-    if (nst < 2u) return hipErrorInvalidValue;
-    const size_t lds = (size_t)p.KT * ni * 1024u + (size_t)SB_NW * nst * SB_STAGE + SB_AUX;
+    const SbShape sh = sb_shape(p.KT, p.nq);
+    if (sh.nst < 2u) return hipErrorInvalidValue;
     const uint32_t ngroups = (p.row_end - p.row_begin + 15u) / 16u;
     const uint32_t blocks = std::max(1u, std::min<uint32_t>((uint32_t)num_cus, (ngroups + SB_NW - 1u) / SB_NW));
     Batch16Params q = p;
     if (blocks > kBlkMaxBlocks) q.blk_cand = nullptr, q.blk_cnt = nullptr;
     const dim3 grid(blocks);
-    if (dtype == MVF_DTYPE_FLOAT16) return launch_dt<MVF_DTYPE_FLOAT16>(q, metric, grid, lds, nst, ni, s);
-    if (dtype == MVF_DTYPE_UINT8) return launch_dt<MVF_DTYPE_UINT8>(q, metric, grid, lds, nst, ni, s);
-    return launch_dt<MVF_DTYPE_INT8>(q, metric, grid, lds, nst, ni, s);
+    return sh.nqt == 64u ? launch_nqt<64>(q, dtype, metric, grid, sh.lds, sh.nst, sh.ni, s)
+                         : launch_nqt<128>(q, dtype, metric, grid, sh.lds, sh.nst, sh.ni, s);
 }
 
 }  // namespace mvf
