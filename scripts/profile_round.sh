@@ -10,7 +10,8 @@ mkdir -p $O
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
 S=scripts/rocprof_summarize.py
 echo "== bench (unprofiled)"; timeout -k 10 900 python3 bench.py > $O/${R}_bench_n1.json 2> $O/bench.err || { tail -5 $O/bench.err; exit 1; }
-echo "== kernel trace of the default bench"
+echo "== kernel trace of the default bench (after a pause: straight behind the MFMA-heavy legs of the run above the HBM-bound kernel measured 3-4 % slower)"
+sleep 60
 timeout -k 10 900 rocprofv3 --kernel-trace --output-format csv -d $O/kt_bench -- python3 bench.py --no-cpu-baseline --no-recall > $O/kt_bench.log 2>&1 || { tail -5 $O/kt_bench.log; exit 1; }
 python3 $S stats $O/kt_bench $O/${R}_bench_n1_kernel_stats.csv "rocprofv3 --kernel-trace -- python3 bench.py --no-cpu-baseline --no-recall (q=1 leg 5+50 searches, host-API leg 5+50, f16-shadow and int8-shadow stream legs 5+50 each, three batched legs 1+5 each, cfg5 shard leg 2+10, two 8192^3 library GEMMs); durations in us"
 python3 $S launches $O/kt_bench $O/${R}_cfg3_shadow_q1024_scan_launches.csv "scan_mfma16" "per-launch durations of the K2 kernels for the narrow types in the default bench run: cfg3 (10M x 768 f32 cosine, 1024 queries) through the int8 shadow (scan_mfma16_dma_kernel<2, 2, ., true, 256>) and through the f16 shadow (<1, 2, ., true>), and the cfg5 shard leg (12.5M x 1024 f16 L2) through the int8 shadow (<2, 0, ., true, 256>)"
