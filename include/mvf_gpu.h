@@ -336,7 +336,9 @@ int mvfgpu_last_timing(const mvfgpu_corpus* corpus, mvfgpu_timing* out);
  * PROVEN bound of the k-th best (5-8 x k rows per query on uniform data; the
  * f16 shadow keeps a handful) is re-scored from the stored rows and the f32
  * query, so results are again those of the exact path.  Same as 0 on Int8 /
- * UInt8 corpora.
+ * UInt8 corpora, and for k > 409 (path 6's streaming: k > 204): the margin
+ * would not fit the candidate budget, such requests take the f16 shadow / the
+ * stored rows.
  * 6 = as 5, and ONE TO FOUR queries STREAM THE INT8 SHADOW through K1
  * (`dimension` bytes per row instead of 4x / 2x that; same bound, same exact
  * re-scoring: 1.2-1.3 ms for one query instead of 4.5 on 10M x 768 f32).

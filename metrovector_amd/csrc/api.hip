@@ -430,8 +430,16 @@ constexpr uint32_t kBatchCapQS = 8192;  // candidate slots per query with int8 s
 // MFMA rate of the f16 kernel under the same power limit, half (a quarter) of the bytes of Float16 (Float32) rows, a 15 x
 // wider proven margin.  MVF_I8_SHADOW=0, scan path 3 (f16 selection) and scan path 2 (stored rows) opt out; scan path 5
 // insists; a corpus whose data defeats the int8 bound switches itself back (qs_disabled).
-bool qs_wanted(const mvfgpu_corpus* c) {
+// The int8 bound lets ~7-10 x k rows per query through to the re-scoring (0.23 sigma of the score distribution on the
+// benchmark's rows), and a query whose margin holds more than half its candidate slots is redone by K1: beyond these k
+// the selection is left to the f16 shadow / the stored rows, whose margins hold a handful of rows beyond k (k = 1000 on
+// 10M x 768, 16 queries: 42 ms with every query repaired, 3 ms without).
+constexpr uint32_t kQsMaxK = kBatchCapQS / 2 / 10;        // batched: 4096 kept candidates per query
+constexpr uint32_t kQsStreamMaxK = kBatchCap / 2 / 10;    // streamed (select_final's margin mode): 2048
+
+bool qs_wanted(const mvfgpu_corpus* c, uint32_t k = 0) {
     if (is_int_dtype(c->dtype) || c->n == 0) return false;
+    if (k > kQsMaxK) return false;
     if (!k2_dma_enabled()) return false;  // the register-staged A/B kernel (MVF_K2_DMA=0) has no int8-shadow flavour
     if ((size_t)((c->dim + 7u) & ~7u) * 4 + kBatchCapQS * 4 > 64 * 1024) return false;  // re-scoring: query + candidates in LDS
     if (c->scan_path == 5 || c->scan_path == 6) return true;
@@ -655,7 +663,7 @@ int search_batched_path(const mvfgpu_corpus* c, uint8_t metric, const void* d_qu
     bool use_shadow = false, use_qs = false;
     const bool rescore_fits = (size_t)((c->dim + 7u) & ~7u) * 4 + kBatchCap * 4 <= 64 * 1024;  // query + candidates in LDS
     qs_feedback_poll(c);
-    if (qs_wanted(c)) {  // int8 shadow: selection at the int8 MFMA rate (Float32 and Float16 corpora)
+    if (qs_wanted(c, k)) {  // int8 shadow: selection at the int8 MFMA rate (Float32 and Float16 corpora)
         int rc = ensure_norms(c, s);
         if (rc != MVF_OK) return rc;
         HIP_TRY(ensure_shadow8(c, s, c->scan_path == 5 || c->scan_path == 6));
@@ -1094,8 +1102,8 @@ int search_stream_qs_path(const mvfgpu_corpus* c, uint8_t metric, const void* d_
 // headline: no extra memory, no build).  Two to four queries are served as fast by the 64-query MFMA tile on the same
 // shadow (1.55-1.65 ms against 1.53-1.72: profiles/r02_stream_int8_shadow_1to4_queries.txt).  MVF_STREAM_I8=0 opts
 // out; a corpus whose queries keep needing the repair pass switches itself back (qs_disabled).
-bool stream_qs_wanted(const mvfgpu_corpus* c, uint32_t nq) {
-    if (nq < 1 || nq > 4 || !qs_wanted(c)) return false;
+bool stream_qs_wanted(const mvfgpu_corpus* c, uint32_t nq, uint32_t k) {
+    if (nq < 1 || nq > 4 || k > kQsStreamMaxK || !qs_wanted(c, k)) return false;
     if (c->scan_path == 6) return true;
     if (c->scan_path != 0 || nq != 1 || c->shadow8_state != 1) return false;
     const char* e = getenv("MVF_STREAM_I8");
@@ -1638,8 +1646,8 @@ int mvfgpu_search_device(const mvfgpu_corpus* c, uint8_t metric, const void* d_q
         HIP_TRY(hipEventRecord(wps->e[3], s));
     }
     bool shadow_stream = false, qs_stream = false;
-    if (stream_qs_wanted(c, nq)) qs_feedback_poll(c);  // may switch the int8 selection off
-    if (stream_qs_wanted(c, nq)) {
+    if (stream_qs_wanted(c, nq, k)) qs_feedback_poll(c);  // may switch the int8 selection off
+    if (stream_qs_wanted(c, nq, k)) {
         rc = ensure_norms(c, s);
         if (rc != MVF_OK) return rc;
         hipError_t e = ensure_shadow8(c, s, c->scan_path == 6);
