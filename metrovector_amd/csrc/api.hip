@@ -1129,17 +1129,20 @@ bool use_batched_path(const mvfgpu_corpus* c, uint8_t metric, uint32_t nq) {
     if (!supported) return false;
     if (c->scan_path == 2 || c->scan_path == 3 || (c->scan_path == 5 && !is_int_dtype(c->dtype))) return true;
     if (c->scan_path == 6 && !is_int_dtype(c->dtype)) return nq > 4;
-    // K1 takes 2..4 queries per HBM pass (5.7 / 6.3 / 7.4 ms on 10M x 768 f32 / 12.5M x 1024 f16 / 50M x 768 int8);
-    // K2 costs a flat padded-tile time: with the 64-query tile 3.65 ms (f16 kernel on the f32 corpus' shadow), 4.9 ms
-    // (f16 corpus), 7.6 ms (int8) up to 64 queries; the exact f32 kernel 15.3 ms up to 128 -- plus ~0.2 ms of phase
-    // launches and the final flag read-back.  Measured crossovers on >= 1 GiB of rows; small corpora keep K1 until the
-    // batch is MFMA-sized.
+    // K1 takes up to 4 queries per pass over the rows; K2 costs a flat padded-tile time -- since the streaming MFMA kernel
+    // (scan_mfma16_sb.hip) about ONE pass over the int8 shadow / the Int8 rows for up to 64 queries, plus ~0.1 ms of phase
+    // launches.  Measured crossovers (scripts/probe_small_corpora.py, profiles/r02_small_corpora_crossover.txt): Float32 /
+    // Float16 rows with a shadow from 2 queries up at every size measured (1M x 768 f32, 16 queries: 0.25 ms against K1's
+    // 2.4 -- until round 2 corpora under 1 GiB kept K1 up to 31 queries), Int8 / UInt8 rows from 5, Float32 rows without
+    // a shadow (exact f32 MFMA kernel, 128-query tiles) from 9 on >= 1 GiB and from 32 below.  Corpora under 16 MiB keep K1
+    // until the batch is MFMA-sized: their searches take tens of microseconds either way, and the batched path's scratch
+    // (128 MiB of candidate regions per handle) would dwarf them.
     const uint64_t bytes = c->n * (uint64_t)c->dim * elem_size(c->dtype);
     const bool shadowed = qs_wanted(c) ||  // int8 selection, else the f16 shadow (runs as Float16)
                           (c->dtype == MVF_DTYPE_FLOAT32 && (c->scan_path == 3 || shadow_enabled()) && c->shadow_state >= 0 &&
                            (size_t)((c->dim + 7u) & ~7u) * 4 + kBatchCap * 4 <= 64 * 1024);
-    const uint32_t threshold = bytes < (1ull << 30)                           ? 32u
-                               : c->dtype == MVF_DTYPE_FLOAT32 && !shadowed ? 9u
+    const uint32_t threshold = bytes < (16ull << 20)                          ? 32u
+                               : c->dtype == MVF_DTYPE_FLOAT32 && !shadowed ? (bytes < (1ull << 30) ? 32u : 9u)
                                : is_int_dtype(c->dtype)                     ? 5u
                                                                             : 2u;
     return nq >= threshold;
