@@ -254,7 +254,7 @@ int search_stream_path(const mvfgpu_corpus* c, uint8_t metric, const void* d_que
             pmax = next_pow2(k + chunk_rows);
             lds = scan_lds_bytes(kdtype, G, J, nqv, pmax);
         }
-        const uint32_t nchunks = (uint32_t)((c->n + chunk_rows - 1) / chunk_rows);
+        uint32_t nchunks = (uint32_t)((c->n + chunk_rows - 1) / chunk_rows);
         if (lds > 160 * 1024) return fail(MVF_ERR_BUILD, "dimension too large for the streaming kernel's LDS query tile");
         const uint32_t nq_here = std::min<uint32_t>(nqv, nq - q0);
 
@@ -268,6 +268,20 @@ int search_stream_path(const mvfgpu_corpus* c, uint8_t metric, const void* d_que
             int occ = 0;
             HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kfn, 256, lds));
             if (occ < 1) occ = 1;
+            {  // A corpus of fewer 512-row chunks than the GPU holds blocks (n < ~650K rows) would leave most of them idle:
+               // smaller chunks, one per resident block -- n / blocks rounded up to the kernel's step (100K x 128 f32: 196
+               // blocks -> 782, 52 -> 31 us per search).  Larger corpora keep the 512-row chunks (the headline's 496-row
+               // "balanced" chunks measured 1.4 % slower than 512).
+                const uint32_t slots = (uint32_t)occ * (uint32_t)c->num_cus, step = 16u * 64u / (uint32_t)G;
+                if (nchunks < slots) {
+                    const uint64_t per = (c->n + slots - 1) / slots;
+                    const uint32_t cr = (uint32_t)((per + step - 1) / step * step);
+                    if (cr >= step && cr < chunk_rows) {
+                        chunk_rows = cr;
+                        nchunks = (uint32_t)((c->n + chunk_rows - 1) / chunk_rows);
+                    }
+                }
+            }
             nblocks = std::min<uint32_t>(nchunks, (uint32_t)occ * (uint32_t)c->num_cus);
             HIP_TRY(c->cand.reserve((size_t)nq_here * nblocks * kcap * 8));
 
