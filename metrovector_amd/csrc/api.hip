@@ -270,9 +270,20 @@ int search_stream_path(const mvfgpu_corpus* c, uint8_t metric, const void* d_que
             if (occ < 1) occ = 1;
             {  // A corpus of fewer 512-row chunks than the GPU holds blocks (n < ~650K rows) would leave most of them idle:
                // smaller chunks, one per resident block -- n / blocks rounded up to the kernel's step (100K x 128 f32: 196
-               // blocks -> 782, 52 -> 31 us per search).  Larger corpora keep the 512-row chunks (the headline's 496-row
-               // "balanced" chunks measured 1.4 % slower than 512).
+               // blocks -> 782, 52 -> 31 us per search).  Up to four chunks per block the last round is uneven (700K x 256:
+               // 1368 chunks on 1280 blocks, i.e. two rounds for 7 % of the blocks): P = ceil(chunks / blocks) rounds of
+               // equal, smaller chunks instead (181 -> 144 us; 1M..3M rows: 1-5 %).  Larger corpora keep the 512-row chunks
+               // (the headline's 496-row "balanced" chunks measured 1.4 % slower than 512).
                 const uint32_t slots = (uint32_t)occ * (uint32_t)c->num_cus, step = 16u * 64u / (uint32_t)G;
+                if (nchunks >= slots && nchunks < 4u * slots) {
+                    const uint32_t P = (nchunks + slots - 1) / slots;
+                    const uint64_t per = (c->n + (uint64_t)P * slots - 1) / ((uint64_t)P * slots);
+                    const uint32_t cr = (uint32_t)((per + step - 1) / step * step);
+                    if (cr >= step && cr < chunk_rows) {
+                        chunk_rows = cr;
+                        nchunks = (uint32_t)((c->n + chunk_rows - 1) / chunk_rows);
+                    }
+                }
                 if (nchunks < slots) {
                     const uint64_t per = (c->n + slots - 1) / slots;
                     const uint32_t cr = (uint32_t)((per + step - 1) / step * step);
