@@ -41,6 +41,7 @@
 #define MVF_GPU_H
 
 #include <stddef.h>
+#include <string.h>
 #include <stdint.h>
 
 #include "mvf_status.h"
@@ -54,20 +55,36 @@ typedef struct mvfgpu_corpus mvfgpu_corpus;
 #define MVFGPU_MAX_K 1024u        /* largest k a search accepts */
 #define MVFGPU_MAX_INT_DIM 33025u /* d*255^2 < 2^31 */
 
+/*
+ * OUT-STRUCTS GROW.  Every struct a getter fills starts with `struct_size`: the CALLER sets it to sizeof(its struct)
+ * before the call, the library writes at most that many bytes (fields a newer library knows and the caller does not are
+ * dropped; fields a newer caller knows and an older library does not stay as the caller initialised them) and stores
+ * the number of bytes it filled back into struct_size.  struct_size < 8 -> MVF_ERR_INVALID_ARGUMENT ("struct_size not
+ * set").  MVFGPU_INIT(s) zeroes a struct and sets the field.
+ */
+#define MVFGPU_INIT(s) (memset(&(s), 0, sizeof(s)), (s).struct_size = (uint32_t)sizeof(s))
+
 typedef struct mvfgpu_corpus_info {
+    uint32_t struct_size; /* in: sizeof(mvfgpu_corpus_info); out: bytes filled */
+    int32_t device;
     uint64_t rows;        /* rows in this shard */
     uint64_t index_base;  /* global index of the shard's first row */
     uint32_t dimension;
     uint32_t pitch_bytes; /* device row pitch: dimension*elem_size rounded up to 16 */
     uint8_t data_type;    /* enum mvf_data_type */
-    uint8_t reserved[3];  /* [0]: 1 when vector ids are attached (searches then report ids, not positions) */
-    int32_t device;
-    uint64_t device_bytes; /* HBM held by the handle: rows, norms, scratch and, once a batched search has built
-                              it, the f16 shadow of a Float32 corpus */
+    uint8_t has_vector_ids; /* 1 when vector ids are attached (searches then report ids, not positions) */
+    uint8_t shadows;      /* bit 0: the int8 selection shadow is resident, bit 1: the scaled-f16 one */
+    uint8_t reserved;
+    uint32_t reserved2;
+    uint64_t device_bytes; /* HBM held by the handle: rows, deletion bitmap, ids, norms, every scratch buffer and the
+                              selection shadows (int8: +dimension bytes per row; scaled f16: +2*dimension) with their
+                              per-row scales and bound statistics, once built */
     uint64_t deleted_rows; /* rows masked by the tombstone bitmap */
 } mvfgpu_corpus_info;
 
 typedef struct mvfgpu_timing {
+    uint32_t struct_size; /* in: sizeof(mvfgpu_timing); out: bytes filled */
+    uint32_t samples;    /* searches averaged */
     /* HIP-event times of searches on the handle, milliseconds.  Events are
      * recorded (never waited for) on the search's own stream while
      * mvfgpu_set_profiling(corpus, 1) is in effect; mvfgpu_last_timing waits
@@ -77,7 +94,6 @@ typedef struct mvfgpu_timing {
     float total_ms;    /* newest search: scan_ms + select_ms */
     float scan_ms_avg;   /* mean over the (up to 64) newest profiled searches */
     float select_ms_avg;
-    uint32_t samples;    /* searches averaged */
     uint32_t scan_kernel; /* 1 = streaming (K1) on the stored rows, 5 = K1 on the f16 shadow of a Float32
                              corpus (scan path 4); MFMA batched (K2): 2 = f32 kernel on Float32 rows,
                              3 = f16/int8 kernel on the stored rows, 4 = f16 kernel on the f16 shadow,
@@ -289,17 +305,26 @@ int mvfgpu_merge_topk_packed_device(const void* d_packed, uint32_t nlists,
  */
 typedef struct mvfgpu_shardset mvfgpu_shardset;
 typedef struct mvfgpu_shardset_info {
+    uint32_t struct_size; /* in: sizeof(mvfgpu_shardset_info); out: bytes filled */
     uint32_t n_shards;
     uint32_t rccl_ranks; /* ranks of the RCCL communicator (= n_shards), 0 when the lists travel by device copies */
     uint32_t dimension;
     uint8_t data_type;
-    uint8_t reserved[3];
+    uint8_t reserved[7];
     uint64_t rows;       /* over all shards */
 } mvfgpu_shardset_info;
-typedef struct mvfgpu_shardset_timing { /* host wall clock of the newest search, milliseconds */
-    float search_ms;         /* query upload + per-shard searches (all shards concurrently, max over them) */
-    float exchange_merge_ms; /* all-gather + merge + results to the host */
-    uint64_t searches;
+#define MVFGPU_MAX_SHARDS 64
+typedef struct mvfgpu_shardset_timing { /* the newest search, milliseconds */
+    uint32_t struct_size;    /* in: sizeof(mvfgpu_shardset_timing); out: bytes filled */
+    uint32_t n_shards;
+    uint64_t searches;       /* searches the set has served */
+    float total_ms;          /* HOST wall clock, call to return: query upload, searches, exchange, merge, results on the host */
+    float enqueue_ms;        /* HOST wall clock until every shard's search and the exchange step were enqueued */
+    float search_ms;         /* DEVICE (HIP events on the shard's own stream): query upload + local search of the SLOWEST
+                                shard; the shards run concurrently */
+    float exchange_merge_ms; /* DEVICE, first shard's stream: from the end of ITS local search to the end of the merge =
+                                waiting for the slowest shard + the all-gather (RCCL, or device copies) + merge_shards */
+    float shard_search_ms[MVFGPU_MAX_SHARDS]; /* DEVICE: query upload + local search per shard (row-range order) */
 } mvfgpu_shardset_timing;
 int mvfgpu_shardset_create(mvfgpu_corpus* const* shards, int n_shards, mvfgpu_shardset** out);
 void mvfgpu_shardset_destroy(mvfgpu_shardset* set);

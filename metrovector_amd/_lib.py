@@ -20,10 +20,19 @@ _gpu = None
 _host = None
 
 
-class CorpusInfo(C.Structure):
-    _fields_ = [("rows", C.c_uint64), ("index_base", C.c_uint64), ("dimension", C.c_uint32),
-                ("pitch_bytes", C.c_uint32), ("data_type", C.c_uint8), ("reserved", C.c_uint8 * 3),
-                ("device", C.c_int32), ("device_bytes", C.c_uint64), ("deleted_rows", C.c_uint64)]
+class _OutStruct(C.Structure):
+    """Out-structs of the C ABI carry a caller-set `struct_size` first (include/mvf_gpu.h, "OUT-STRUCTS GROW")."""
+
+    def __init__(self, *a, **kw):
+        super().__init__(*a, **kw)
+        self.struct_size = C.sizeof(type(self))
+
+
+class CorpusInfo(_OutStruct):
+    _fields_ = [("struct_size", C.c_uint32), ("device", C.c_int32), ("rows", C.c_uint64), ("index_base", C.c_uint64),
+                ("dimension", C.c_uint32), ("pitch_bytes", C.c_uint32), ("data_type", C.c_uint8),
+                ("has_vector_ids", C.c_uint8), ("shadows", C.c_uint8), ("reserved", C.c_uint8), ("reserved2", C.c_uint32),
+                ("device_bytes", C.c_uint64), ("deleted_rows", C.c_uint64)]
 
 
 class UploadOptions(C.Structure):
@@ -33,18 +42,23 @@ class UploadOptions(C.Structure):
 UPLOAD_EAGER_NORMS, UPLOAD_EAGER_SHADOW, UPLOAD_PINNED_STAGING, UPLOAD_PAGEABLE = 1, 2, 4, 8
 
 
-class ShardsetInfo(C.Structure):
-    _fields_ = [("n_shards", C.c_uint32), ("rccl_ranks", C.c_uint32), ("dimension", C.c_uint32), ("data_type", C.c_uint8),
-                ("reserved", C.c_uint8 * 3), ("rows", C.c_uint64)]
+MAX_SHARDS = 64
 
 
-class ShardsetTiming(C.Structure):
-    _fields_ = [("search_ms", C.c_float), ("exchange_merge_ms", C.c_float), ("searches", C.c_uint64)]
+class ShardsetInfo(_OutStruct):
+    _fields_ = [("struct_size", C.c_uint32), ("n_shards", C.c_uint32), ("rccl_ranks", C.c_uint32), ("dimension", C.c_uint32),
+                ("data_type", C.c_uint8), ("reserved", C.c_uint8 * 7), ("rows", C.c_uint64)]
 
 
-class Timing(C.Structure):
-    _fields_ = [("scan_ms", C.c_float), ("select_ms", C.c_float), ("total_ms", C.c_float),
-                ("scan_ms_avg", C.c_float), ("select_ms_avg", C.c_float), ("samples", C.c_uint32),
+class ShardsetTiming(_OutStruct):
+    _fields_ = [("struct_size", C.c_uint32), ("n_shards", C.c_uint32), ("searches", C.c_uint64), ("total_ms", C.c_float),
+                ("enqueue_ms", C.c_float), ("search_ms", C.c_float), ("exchange_merge_ms", C.c_float),
+                ("shard_search_ms", C.c_float * MAX_SHARDS)]
+
+
+class Timing(_OutStruct):
+    _fields_ = [("struct_size", C.c_uint32), ("samples", C.c_uint32), ("scan_ms", C.c_float), ("select_ms", C.c_float),
+                ("total_ms", C.c_float), ("scan_ms_avg", C.c_float), ("select_ms_avg", C.c_float),
                 ("scan_kernel", C.c_uint32), ("scan_launches", C.c_uint32), ("scan_bytes", C.c_uint64),
                 ("scan_flops", C.c_uint64), ("search_ms", C.c_float), ("search_ms_avg", C.c_float),
                 ("search_flops", C.c_uint64)]

@@ -1516,20 +1516,23 @@ void mvfgpu_corpus_destroy(mvfgpu_corpus* c) {
 
 int mvfgpu_corpus_get_info(const mvfgpu_corpus* c, mvfgpu_corpus_info* out) {
     if (!c || !out) return fail(MVF_ERR_INVALID_ARGUMENT, "NULL argument");
-    std::memset(out, 0, sizeof(*out));
-    out->rows = c->n;
-    out->index_base = c->index_base;
-    out->dimension = c->dim;
-    out->pitch_bytes = c->pitch;
-    out->data_type = c->dtype;
-    out->device = c->device;
-    out->reserved[0] = c->ids.p ? 1 : 0;  // has_vector_ids
-    out->deleted_rows = c->deleted;
-    std::lock_guard<std::mutex> lk(c->mu);
-    out->device_bytes = c->tomb.bytes + c->ids.bytes + c->rows_bytes + c->cand.bytes + c->bq.bytes + c->bstate.bytes + c->bcand.bytes + c->xnorm.bytes +
-                        c->repair.bytes + c->blk.bytes + c->shadow8.bytes + c->xscale8.bytes + c->shadow.bytes + c->xscale.bytes + c->h_q.bytes + c->h_s.bytes + c->h_i.bytes +
-                        c->h_r.bytes;
-    return MVF_OK;
+    mvfgpu_corpus_info inf{};
+    inf.rows = c->n;
+    inf.index_base = c->index_base;
+    inf.dimension = c->dim;
+    inf.pitch_bytes = c->pitch;
+    inf.data_type = c->dtype;
+    inf.device = c->device;
+    inf.deleted_rows = c->deleted;
+    {
+        std::lock_guard<std::mutex> lk(c->mu);
+        inf.has_vector_ids = c->ids.p ? 1 : 0;
+        inf.shadows = (uint8_t)((c->shadow8_state == 1 ? 1 : 0) | (c->shadow_state == 1 ? 2 : 0));
+        inf.device_bytes = c->tomb.bytes + c->ids.bytes + c->rows_bytes + c->cand.bytes + c->bq.bytes + c->bstate.bytes + c->bcand.bytes +
+                           c->xnorm.bytes + c->repair.bytes + c->blk.bytes + c->shadow8.bytes + c->xscale8.bytes + c->qs_stats.bytes +
+                           c->shadow.bytes + c->xscale.bytes + c->h_q.bytes + c->h_s.bytes + c->h_i.bytes + c->h_r.bytes;
+    }
+    return copy_out_struct(out, inf);
 }
 
 int mvfgpu_corpus_read_rows(const mvfgpu_corpus* c, uint64_t first, uint64_t count, void* out_rows) {
@@ -1895,8 +1898,7 @@ int mvfgpu_last_timing(const mvfgpu_corpus* c, mvfgpu_timing* out) {
         tm.select_ms_avg = cnt ? (float)(lsum / cnt) : 0.f;
         tm.search_ms_avg = wcnt ? (float)(wsum / wcnt) : 0.f;
     }
-    *out = tm;
-    return MVF_OK;
+    return copy_out_struct(out, tm);
 }
 
 int mvfgpu_set_scan_path(mvfgpu_corpus* c, int path) {

@@ -132,6 +132,15 @@ int mvfo_find_top_k_similar_faithful(const uint8_t* block, uint64_t block_len,
 void mvfo_synth_rows(uint64_t seed, uint64_t row0, uint64_t nrows, uint32_t dim,
                      uint8_t dtype, void* out);
 
+/*
+ * NOT THE CHECKER (mvf_cpu_best_effort.c): the host's best effort on one Float32 query -- `threads` OpenMP threads over
+ * rows, no per-row allocation, 16 partial sums per row so the fold vectorises (hence not bit-exact with the reference's
+ * strict left fold), one bounded heap per thread.  bench.py times it as `cpu_baseline_best_effort`; nothing is compared
+ * against its results.
+ */
+int mvfo_search_best_effort_f32(const float* rows, uint64_t n, uint32_t dim, uint8_t metric, const float* query,
+                                uint32_t k, uint64_t index_base, int threads, float* out_scores, uint64_t* out_idx);
+
 #ifdef __cplusplus
 }
 #endif

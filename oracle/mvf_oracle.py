@@ -41,18 +41,27 @@ def build(force: bool = False) -> str:
 _lib = None
 
 
+def cpus_granted() -> dict:
+    """What the cgroup / affinity mask grants this process: {"cpus_allowed": affinity mask size, "cgroup_cpu_quota":
+    cpu.max quota in CPUs or None, "granted": the smaller of the two (>= 1)}."""
+    allowed = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = None
+    for path in ("/sys/fs/cgroup/cpu.max",):
+        try:
+            q, period = open(path).read().split()
+            if q != "max":
+                quota = int(q) / int(period)
+        except (OSError, ValueError):
+            pass
+    granted = allowed if quota is None else min(allowed, max(1, int(quota)))
+    return {"cpus_allowed": allowed, "cgroup_cpu_quota": quota, "granted": max(1, granted)}
+
+
 def _cpu_budget() -> int:
-    """Threads the oracle's OpenMP loops may use: the CPU quota of this container / box
-    (cgroup cpu.max or the affinity mask), at most 16.  Oversubscribing a quota-limited box
-    with one OpenMP team per core turns every parallel region into milliseconds of spinning."""
-    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    try:
-        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
-        if quota != "max":
-            n = min(n, max(1, int(int(quota) / int(period))))
-    except (OSError, ValueError):
-        pass
-    return max(1, min(16, n))
+    """Threads the CHECKER's OpenMP loops use: the CPU quota of this container / box (cgroup cpu.max or the affinity
+    mask), at most 16.  Oversubscribing a quota-limited box with one OpenMP team per core turns every parallel region
+    into milliseconds of spinning."""
+    return max(1, min(16, cpus_granted()["granted"]))
 
 
 def lib() -> C.CDLL:
@@ -81,6 +90,8 @@ def lib() -> C.CDLL:
         _lib.mvfo_merge_topk.argtypes = [vp, vp, vp, u32, u32, u32, u8, u8, vp, vp, vp]
         _lib.mvfo_find_top_k_similar_faithful.restype = i32
         _lib.mvfo_find_top_k_similar_faithful.argtypes = [vp, u64, u64, u32, u8, vp, u32, u32, i32, vp, vp, vp]
+        _lib.mvfo_search_best_effort_f32.restype = i32
+        _lib.mvfo_search_best_effort_f32.argtypes = [vp, u64, u32, u8, vp, u32, u64, i32, vp, vp]
         _lib.mvfo_synth_rows.restype = None
         _lib.mvfo_synth_rows.argtypes = [u64, u64, u64, u32, u8, vp]
     return _lib
@@ -146,6 +157,20 @@ def merge_topk(scores_l: np.ndarray, idx_l: np.ndarray, raw_l: np.ndarray | None
     if rc != 0:
         raise RuntimeError(f"mvfo_merge_topk rc={rc}")
     return sc, idx, raw
+
+
+def search_best_effort_f32(rows: np.ndarray, metric: int, query: np.ndarray, k: int, threads: int, index_base: int = 0):
+    """NOT THE CHECKER: the host's best effort (mvf_cpu_best_effort.c) -- bench.py's cpu_baseline_best_effort leg only."""
+    rows = np.ascontiguousarray(rows, np.float32)
+    n, dim = rows.shape
+    q = np.ascontiguousarray(query, np.float32).reshape(-1)
+    assert q.size == dim
+    sc = np.empty(k, np.float32)
+    idx = np.empty(k, np.uint64)
+    rc = lib().mvfo_search_best_effort_f32(_ptr(rows), n, dim, metric, _ptr(q), k, index_base, threads, _ptr(sc), _ptr(idx))
+    if rc != 0:
+        raise RuntimeError(f"mvfo_search_best_effort_f32 rc={rc}")
+    return sc, idx
 
 
 def find_top_k_similar_faithful(block: bytes | np.ndarray, total_vectors: int, dim: int, dtype: int,

@@ -1,0 +1,274 @@
+"""-m gpu tests added in round 3: FULL-WIDTH equality of the selection paths with the exact ones on
+BASELINE.json configs[1]/[2]'s corpus (every one of the 1024 queries, all three metrics), shard-set hygiene (aligned
+merged list with odd nq*k, n_shards*k at the merge's limit, argument checks before any work, device-event timing), a
+second, clock-independent check that the batched device search does not block, and the out-structs' struct_size rule.
+Everything goes through the C ABI (libmvf_gpu.so); the oracle is only the checker."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from metrovector_amd import _lib, errors as E, gpu as G
+
+from _util import assert_exact, recall_at_k
+
+pytestmark = pytest.mark.gpu
+SEED = 0x4D564631
+TOL = 1e-5  # north_star: "within 1e-5 relative for f32 L2/cosine"
+
+
+@pytest.fixture(scope="module")
+def corpus_10m():
+    c = G.GpuCorpus.synthetic(10_000_000, 768, 0, SEED)
+    yield c
+    c.close()
+
+
+def _score_tol(metric, ref_scores, qnorm, xnorm_max):
+    """L2 1e-5 relative, cosine 1e-5 absolute, inner product 1e-5 |q||x|."""
+    if metric == G.L2:
+        return TOL * np.maximum(np.abs(ref_scores), 1e-30)
+    if metric == G.COSINE:
+        return np.full_like(ref_scores, TOL)
+    return TOL * qnorm[:, None] * xnorm_max * np.ones_like(ref_scores)
+
+
+def _equal_up_to_boundary_ties(got, ref, metric, qnorm, xnorm_max):
+    """Per query: same rows, except rows whose score is within the tolerance of the k-th best (two summation orders may
+    rank such rows either way); every row the two lists share carries the same score within the tolerance.
+    Returns (queries with identical index lists, queries whose sets differ, worst score difference / tolerance)."""
+    tol = _score_tol(metric, ref.scores, qnorm, xnorm_max)
+    same_pos = int((got.indices == ref.indices).all(axis=1).sum())
+    worst, differing = 0.0, 0
+    for qi in range(ref.indices.shape[0]):
+        gi, ri = got.indices[qi], ref.indices[qi]
+        if (gi == ri).all():
+            worst = max(worst, float(np.max(np.abs(got.scores[qi] - ref.scores[qi]) / tol[qi])))
+            continue
+        gs, rs = dict(zip(gi.tolist(), got.scores[qi].tolist())), dict(zip(ri.tolist(), ref.scores[qi].tolist()))
+        for r in set(gs) & set(rs):
+            worst = max(worst, abs(gs[r] - rs[r]) / float(tol[qi, 0]))
+        odd = [gs[r] for r in set(gs) - set(rs)] + [rs[r] for r in set(rs) - set(gs)]
+        if odd:
+            differing += 1
+            kth = float(ref.scores[qi, -1])
+            btol = 2 * float(tol[qi, -1])
+            assert all(abs(v - kth) <= btol for v in odd), \
+                f"query {qi}: the lists differ by a row that is NOT a boundary tie (k-th {kth}, odd {odd[:4]})"
+    return same_pos, differing, worst
+
+
+@pytest.mark.parametrize("metric", [G.COSINE, G.L2, G.INNER_PRODUCT])
+def test_cfg3_selection_paths_equal_the_exact_path_on_all_1024_queries(oracle, corpus_10m, metric):
+    """10M x 768 f32, 1024 queries, top-100: the DEFAULT path (int8-shadow selection + exact re-scoring, scan kernel 6)
+    and scan path 3 (f16-shadow selection) against scan path 2 (exact f32 MFMA on the stored rows) on EVERY query."""
+    nq, k, dim = 1024, 100, 768
+    c = corpus_10m
+    q = oracle.synth_queries(SEED + 1, nq, dim, 0)
+    qnorm = np.linalg.norm(q.astype(np.float64), axis=1)
+    xnorm_max = float(np.sqrt(dim))  # rows are uniform in [-1, 1): |x| <= sqrt(dim)
+    out = {}
+    try:
+        for path in (2, 0, 3):
+            c.set_scan_path(path)
+            c.set_profiling(True)
+            out[path] = c.search(q, k, metric)
+            kern = c.last_timing().scan_kernel
+            c.set_profiling(False)
+            assert kern == {2: 2, 0: 6, 3: 4}[path], f"scan path {path} ran kernel {kern}"
+    finally:
+        c.set_profiling(False)
+        c.set_scan_path(0)
+    for path in (0, 3):
+        same, differing, worst = _equal_up_to_boundary_ties(out[path], out[2], metric, qnorm, xnorm_max)
+        print(f"metric {metric} path {path} vs 2: identical lists {same}/{nq}, sets differing by boundary ties {differing}, "
+              f"worst score diff {worst:.3f} x tolerance")
+        # (rows whose scores differ by less than the two paths' rounding may swap places inside a list: positions are
+        # reported, sets and scores are asserted)
+        assert worst <= 1.0
+
+
+@pytest.mark.parametrize("metric", [G.COSINE, G.L2, G.INNER_PRODUCT])
+def test_cfg2_streamed_int8_shadow_equals_the_exact_stream_on_200_single_queries(oracle, corpus_10m, metric):
+    """Scan path 6 (K1 on the int8 shadow + exact re-scoring) against scan path 1 (K1 on the stored f32 rows), ONE query
+    per search, 200 queries."""
+    k, dim, nq = 100, 768, 200
+    c = corpus_10m
+    q = oracle.synth_queries(SEED + 1, nq, dim, 0)
+    qnorm = np.linalg.norm(q.astype(np.float64), axis=1)
+    res = {}
+    try:
+        for path in (1, 6):
+            c.set_scan_path(path)
+            c.set_profiling(True)
+            one = [c.search(q[i], k, metric) for i in range(nq)]
+            kern = c.last_timing().scan_kernel
+            c.set_profiling(False)
+            assert kern == {1: 1, 6: 7}[path]
+            res[path] = G.SearchResult(np.concatenate([r.scores for r in one]), np.concatenate([r.indices for r in one]),
+                                       np.concatenate([r.raw for r in one]))
+    finally:
+        c.set_profiling(False)
+        c.set_scan_path(0)
+    same, differing, worst = _equal_up_to_boundary_ties(res[6], res[1], metric, qnorm, float(np.sqrt(dim)))
+    print(f"metric {metric} path 6 vs 1: identical lists {same}/{nq}, boundary-tie sets {differing}, worst {worst:.3f} x tolerance")
+    assert worst <= 1.0
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# shard set (include/mvf_gpu.h mvfgpu_shardset_*)
+# ---------------------------------------------------------------------------------------------------------------------
+
+def _shards(oracle, rows, cuts):
+    return [G.GpuCorpus.from_array(rows[a:b], index_base=a) for a, b in zip(cuts[:-1], cuts[1:])]
+
+
+@pytest.mark.parametrize("dtype,metric,nq,k", [(0, 0, 1, 1), (0, 2, 1, 3), (2, 1, 3, 5), (1, 0, 7, 9), (3, 0, 1, 101)])
+def test_shardset_odd_result_counts(oracle, dtype, metric, nq, k):
+    """nq * k odd: the merged list's u64 array must stay 8-byte aligned (round 2 put the f32 scores in front of it);
+    two shards on one device (device copies) and a single shard (1-rank RCCL)."""
+    n, dim = 20_000, 40
+    rows = oracle.synth_rows(SEED, 0, n, dim, dtype)
+    q = oracle.synth_queries(SEED + 1, nq, dim, dtype)
+    with G.GpuCorpus.from_array(rows) as whole:
+        want = whole.search(q, k, metric)
+        with G.ShardSet([whole]) as ss1:
+            one = ss1.search(q, k, metric)
+    assert_exact(one, want.scores, want.indices, want.raw)
+    shards = _shards(oracle, rows, [0, 7_777, n])
+    try:
+        with G.ShardSet(shards) as ss:
+            res = ss.search(q, k, metric)
+    finally:
+        for s in shards:
+            s.close()
+    assert (res.indices == want.indices).all()
+    if dtype in (2, 3):
+        assert_exact(res, want.scores, want.indices, want.raw)
+    else:
+        assert np.abs(res.scores - want.scores).max() <= 1e-5 * max(1.0, float(np.abs(want.scores).max()))
+
+
+def test_shardset_at_the_merge_capacity(oracle):
+    """n_shards * k = 8192 (the cross-shard merge's limit): 8 shards x k = 1024; one more shard is refused."""
+    n, dim, k, nq, dtype, metric = 24_000, 32, 1024, 3, 2, 1
+    rows = oracle.synth_rows(SEED, 0, n, dim, dtype)
+    q = oracle.synth_queries(SEED + 1, nq, dim, dtype)
+    cuts = [0, 100, 3_000, 6_500, 9_000, 12_000, 15_000, 20_000, n]  # the first shard holds fewer rows than k: padding
+    shards = _shards(oracle, rows, cuts)
+    try:
+        with G.ShardSet(shards) as ss:
+            res = ss.search(q, k, metric)
+            tm = ss.last_timing()
+        assert_exact(res, *oracle.search(rows, dtype, metric, q, k))
+        assert tm.n_shards == 8 and tm.searches == 1
+        nine = _shards(oracle, rows, [0, 50] + cuts[1:])
+        try:
+            with G.ShardSet(nine) as ss9, pytest.raises(E.InvalidArgument, match="8192"):
+                ss9.search(q, k, metric)
+        finally:
+            for s in nine:
+                s.close()
+    finally:
+        for s in shards:
+            s.close()
+
+
+def test_shardset_checks_arguments_before_any_work_and_times_on_the_device(oracle):
+    n, dim, k, nq = 60_000, 64, 20, 16
+    rows = oracle.synth_rows(SEED, 0, n, dim, 1)
+    q = oracle.synth_queries(SEED + 1, nq, dim, 1)
+    shards = _shards(oracle, rows, [0, 20_000, 40_000, n])
+    try:
+        with G.ShardSet(shards) as ss:
+            with pytest.raises(E.DimensionMismatch, match="expected 64, got 63"):
+                ss.search(np.ascontiguousarray(q[:, :63]), k, G.L2)
+            with pytest.raises(E.BuildError, match="query data type"):
+                ss.search(q.astype(np.int8), k, G.L2)
+            with pytest.raises(E.InvalidArgument, match="metric"):
+                ss.search(q, k, 7)
+            with pytest.raises(E.InvalidArgument):
+                ss.search(q, 0, G.L2)
+            assert ss.last_timing().searches == 0  # nothing ran
+            res = ss.search(q, k, G.L2)
+            res = ss.search(q, k, G.L2)
+            tm = ss.last_timing()
+        assert tm.searches == 2 and tm.n_shards == 3
+        per = [tm.shard_search_ms[i] for i in range(3)]
+        assert all(p > 0 for p in per) and abs(tm.search_ms - max(per)) < 1e-6
+        assert tm.exchange_merge_ms > 0 and tm.total_ms >= tm.search_ms and tm.enqueue_ms <= tm.total_ms
+        with G.GpuCorpus.from_array(rows) as whole:
+            want = whole.search(q, k, G.L2)
+        assert (res.indices == want.indices).all()
+    finally:
+        for s in shards:
+            s.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the batched device search does not block -- without a wall-clock ratio
+# ---------------------------------------------------------------------------------------------------------------------
+
+def test_batched_search_device_returns_behind_unfinished_work(oracle):
+    """~200 ms of GEMMs are queued on the stream, then a batched search: when mvfgpu_search_device returns, an event
+    recorded right behind it has NOT completed (the call would have had to wait for the GEMMs to finish first if it
+    synchronised anywhere), and the results are right once it has."""
+    import torch
+    n, dim, nq, k = 2_000_000, 256, 300, 20
+    with G.GpuCorpus.synthetic(n, dim, 1, SEED) as c:
+        dq = torch.empty((nq, dim), dtype=torch.float32, device="cuda")
+        _lib.gpu_check(_lib.gpu().mvfgpu_synth_queries_device(dq.data_ptr(), nq, dim, 1, SEED + 1, 0, None))
+        ds = torch.empty((nq, k), dtype=torch.float32, device="cuda")
+        di = torch.empty((nq, k), dtype=torch.int64, device="cuda")
+        stream = torch.cuda.current_stream().cuda_stream
+        args = (c._h, G.L2, dq.data_ptr(), 0, dim, nq, k, ds.data_ptr(), di.data_ptr(), None, C.c_void_p(stream))
+        _lib.gpu_check(_lib.gpu().mvfgpu_search_device(*args))  # warm-up: norms, shadow, scratch
+        torch.cuda.synchronize()
+        first = di.cpu().numpy().copy()
+        a = torch.randn(8192, 8192, device="cuda", dtype=torch.float32)
+        torch.cuda.synchronize()
+        for _ in range(24):  # fp32 8192^3 GEMMs: ~10 ms each on this part
+            a @ a
+        _lib.gpu_check(_lib.gpu().mvfgpu_search_device(*args))
+        ev = torch.cuda.Event()
+        ev.record()
+        assert not ev.query(), "mvfgpu_search_device returned only after the stream had drained"
+        torch.cuda.synchronize()
+        assert (di.cpu().numpy() == first).all()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# out-structs carry a caller-set struct_size (include/mvf_gpu.h "OUT-STRUCTS GROW")
+# ---------------------------------------------------------------------------------------------------------------------
+
+def test_out_structs_honour_struct_size(oracle):
+    rows = oracle.synth_rows(SEED, 0, 1000, 16, 0)
+    with G.GpuCorpus.from_array(rows, index_base=5) as c:
+        full = c.info()
+        assert full.struct_size == C.sizeof(_lib.CorpusInfo) and full.rows == 1000 and full.index_base == 5
+        assert full.device_bytes >= 1000 * 64 and full.shadows == 0
+        # an older, shorter caller struct: only its bytes are written
+        buf = (C.c_uint8 * 128)()
+        C.memset(buf, 0xAB, 128)
+        short = C.cast(buf, C.POINTER(_lib.CorpusInfo))
+        short.contents.struct_size = 24  # struct_size, device, rows, index_base
+        _lib.gpu_check(_lib.gpu().mvfgpu_corpus_get_info(c._h, short))
+        assert short.contents.struct_size == 24 and short.contents.rows == 1000 and short.contents.index_base == 5
+        assert all(b == 0xAB for b in bytes(buf)[24:])
+        # a newer, longer caller struct: the library fills what it knows and says how much
+        C.memset(buf, 0, 128)
+        short.contents.struct_size = 120
+        _lib.gpu_check(_lib.gpu().mvfgpu_corpus_get_info(c._h, short))
+        assert short.contents.struct_size == C.sizeof(_lib.CorpusInfo) and short.contents.dimension == 16
+        # not initialised
+        short.contents.struct_size = 0
+        rc = _lib.gpu().mvfgpu_corpus_get_info(c._h, short)
+        assert rc == 12 and b"struct_size" in _lib.gpu().mvfgpu_last_error_message()
+        t = c.last_timing()
+        assert t.struct_size == C.sizeof(_lib.Timing)
+        # device_bytes follows the shadows
+        q = oracle.synth_queries(SEED + 1, 64, 16, 0)
+        c.set_scan_path(5)
+        c.search(q, 5, G.COSINE)
+        after = c.info()
+        assert after.shadows & 1 and after.device_bytes > full.device_bytes
