@@ -109,6 +109,11 @@ struct mvfgpu_corpus {
     mutable bool qs_redo_pending = false, qs_disabled = false;
     mutable uint32_t qs_redo_nq = 0;
     mutable uint32_t qs_seen = 0, qs_redone = 0;  // running totals of int8-selected queries / of those the repair pass redid
+    // the same feedback guards the folded pre-filter of the i32-accumulator K2 kernels (scan_mfma16_bias.inc): rows whose
+    // norms differ wildly inside a lane's four defeat its per-lane bounds, the wave regions overflow and the queries go
+    // to the repair pass -- exact, but 50x slower; such a corpus goes back to round 2's epilogue first (fb_bias: the
+    // search the pending count belongs to used the folded pre-filter; fb_qs: it selected on the int8 shadow)
+    mutable bool bias_disabled = false, fb_bias = false, fb_qs = false;
     mutable const uint32_t* last_redo_cnt = nullptr;  // device: the count the newest repair pass produced
     mutable bool xnorm_ready = false;
     mutable uint32_t bstate_slots = 0;    // queries the K2 state arrays are armed for
@@ -407,6 +412,13 @@ uint32_t k2_growth_cap() {
     return 4u;
 }
 
+// The folded pre-filter of the LDS-DMA kernel's i32-accumulator flavours (scan_mfma16_bias.inc); MVF_K2_BIAS=0 keeps
+// round 2's epilogue (A/B runs).
+bool k2_bias_enabled() {
+    const char* e = getenv("MVF_K2_BIAS");
+    return !e || atoi(e) != 0;
+}
+
 bool k2_dma_persistent(uint8_t) {  // measured: int8 15 % and f16 5 % faster with one persistent block per CU
     if (const char* e = getenv("MVF_K2_PERSISTENT16")) return atoi(e) != 0;
     return true;
@@ -485,10 +497,18 @@ void qs_feedback_poll(const mvfgpu_corpus* c) {
     c->qs_seen += c->qs_redo_nq;
     c->qs_redone += std::min(*c->qs_redo_host, c->qs_redo_nq);
     if (c->qs_redone >= 4 && (uint64_t)c->qs_redone * 8 > c->qs_seen) {
-        c->qs_disabled = true;
-        if (getenv("MVF_DEBUG_REPAIR"))
-            fprintf(stderr, "[mvfgpu] int8-shadow selection switched off for this corpus: %u of %u queries needed the repair path\n",
-                    c->qs_redone, c->qs_seen);
+        if (c->fb_bias && !c->bias_disabled) {  // first suspect: the folded pre-filter's per-lane bounds
+            c->bias_disabled = true;
+            if (getenv("MVF_DEBUG_REPAIR"))
+                fprintf(stderr, "[mvfgpu] folded pre-filter switched off for this corpus: %u of %u queries needed the repair path\n",
+                        c->qs_redone, c->qs_seen);
+            c->qs_seen = c->qs_redone = 0;
+        } else if (c->fb_qs) {
+            c->qs_disabled = true;
+            if (getenv("MVF_DEBUG_REPAIR"))
+                fprintf(stderr, "[mvfgpu] int8-shadow selection switched off for this corpus: %u of %u queries needed the repair path\n",
+                        c->qs_redone, c->qs_seen);
+        }
     } else if (c->qs_seen >= 8192) {
         c->qs_seen /= 2;
         c->qs_redone /= 2;
@@ -497,8 +517,10 @@ void qs_feedback_poll(const mvfgpu_corpus* c) {
 
 // ... and the request for it: the repair count of the search just enqueued, copied to pinned memory behind an event
 // (never waited for).
-int qs_feedback_post(const mvfgpu_corpus* c, uint32_t nq, hipStream_t s) {
+int qs_feedback_post(const mvfgpu_corpus* c, uint32_t nq, hipStream_t s, bool used_bias = false, bool used_qs = true) {
     if (c->qs_redo_pending || !c->repair.p) return MVF_OK;
+    c->fb_bias = used_bias;
+    c->fb_qs = used_qs;
     if (!c->qs_redo_host) {
         HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&c->qs_redo_host), 64, hipHostMallocDefault));
         HIP_TRY(hipEventCreateWithFlags(&c->qs_redo_ev, hipEventDisableTiming));
@@ -795,11 +817,17 @@ int search_batched_path(const mvfgpu_corpus* c, uint8_t metric, const void* d_qu
     hp.nq_pad = nq_pad;
     hp.mtiles = nq_pad / qpb;
     hp.cap = cap;
-    if (dma) {  // candidates leave the kernel through per-block regions (no global atomics in the epilogue)
-        HIP_TRY(c->blk.reserve((size_t)kBlkMaxBlocks * kBlkCap * 16 + (size_t)kBlkMaxBlocks * 4));
+    // candidates leave the narrow-type kernels through per-block regions (no global atomics in the epilogue): T records in
+    // all -- twice what the per-query lists can hold, at least the 128 MiB of round 2 -- split evenly over the blocks of
+    // the launch; the LDS-DMA kernel's i32-accumulator flavours split a block's share once more per wave (raw records)
+    uint64_t blk_records = 0;
+    if (dma) {
+        blk_records = std::min<uint64_t>(std::max<uint64_t>((uint64_t)kBlkMaxBlocks * kBlkCap, 2ull * nq_pad * cap), 32ull << 20);
+        blk_records -= blk_records % ((uint64_t)kBlkMaxBlocks * kBlkWaves);
+        HIP_TRY(c->blk.reserve((size_t)blk_records * 16 + (size_t)kBlkMaxBlocks * kBlkWaves * 4));
         hp.blk_cand = static_cast<uint4*>(c->blk.p);
-        hp.blk_cnt = reinterpret_cast<uint32_t*>(static_cast<unsigned char*>(c->blk.p) + (size_t)kBlkMaxBlocks * kBlkCap * 16);
-        hp.blk_cap = kBlkCap;
+        hp.blk_cnt = reinterpret_cast<uint32_t*>(static_cast<unsigned char*>(c->blk.p) + (size_t)blk_records * 16);
+        hp.blk_cap = (uint32_t)(blk_records / kBlkMaxBlocks);
     }
 
     CompactParams cp{};
@@ -864,7 +892,7 @@ int search_batched_path(const mvfgpu_corpus* c, uint8_t metric, const void* d_qu
     }
     size_t bi = 0;
     uint64_t begin = 0, end = bounds[0];
-    bool regions_armed = false;
+    bool regions_armed = false, used_bias = false;
     for (;;) {
         const bool last = end >= n;
         if (end > begin) {
@@ -873,19 +901,28 @@ int search_batched_path(const mvfgpu_corpus* c, uint8_t metric, const void* d_qu
             bp.ntiles = hp.ntiles = (uint32_t)((end - begin + tile_rows - 1) / tile_rows);
             bp.direct = hp.direct = (begin == 0 && end - begin <= cap) ? 1u : 0u;
             const bool regions = hp.blk_cand && !hp.direct;
+            // which kernel takes the phase
+            const bool use_pp = !wide && dma && qpb == 256u && k2_pp_wanted(kdtype, hp.ntiles, hp.mtiles, c->num_cus) &&
+                                scan_mfma16_pp_usable(hp.mtiles, c->num_cus, KT);
+            const bool use_sb = !wide && !use_pp && dma && qpb == 64u && k2_sb_enabled() && scan_mfma16_sb_usable(nq_pad, KT, nq);
+            const bool persistent = k2_dma_persistent(kdtype);
+            // per-wave regions of raw records (scan_mfma16_bias.inc): the persistent LDS-DMA kernel on i32 accumulators
+            const bool wave_regions = !wide && dma && !use_pp && !use_sb && persistent && !c->bias_disabled && k2_bias_enabled() &&
+                                      scan_mfma16_dma_wave_regions(kdtype, qpb, hp.direct != 0, regions, c->dim);
+            hp.wave_regions = wave_regions ? 1u : 0u;
+            used_bias |= wave_regions;
+            const uint32_t region_blocks = wave_regions ? (uint32_t)c->num_cus : kBlkMaxBlocks;
+            if (regions) hp.blk_cap = (uint32_t)(blk_records / region_blocks) & ~(kBlkWaves - 1u);
             // the region counters: zeroed once, re-armed by every scatter after it has read them
             if (regions && (!regions_armed || nq_pad > scatter_rearm_max_queries())) {
-                HIP_TRY(hipMemsetAsync(hp.blk_cnt, 0, (size_t)kBlkMaxBlocks * 4, s));
+                HIP_TRY(hipMemsetAsync(hp.blk_cnt, 0, (size_t)kBlkMaxBlocks * kBlkWaves * 4, s));
                 regions_armed = true;
             }
             if (ps && last) HIP_TRY(hipEventRecord(ps->e[0], s));
             if (wide) HIP_TRY(launch_scan_mfma_f32(bp, metric, c->num_cus, s));
-            else if (dma && qpb == 256u && k2_pp_wanted(kdtype, hp.ntiles, hp.mtiles, c->num_cus) &&
-                     scan_mfma16_pp_usable(hp.mtiles, c->num_cus, KT))
-                HIP_TRY(launch_scan_mfma16_pp(hp, kdtype, metric, c->num_cus, s));
-            else if (dma && qpb == 64u && k2_sb_enabled() && scan_mfma16_sb_usable(nq_pad, KT, nq))
-                HIP_TRY(launch_scan_mfma16_sb(hp, kdtype, metric, c->num_cus, s));
-            else if (dma) HIP_TRY(launch_scan_mfma16_dma(hp, kdtype, metric, c->num_cus, qpb, k2_dma_persistent(kdtype), s));
+            else if (use_pp) HIP_TRY(launch_scan_mfma16_pp(hp, kdtype, metric, c->num_cus, s));
+            else if (use_sb) HIP_TRY(launch_scan_mfma16_sb(hp, kdtype, metric, c->num_cus, s));
+            else if (dma) HIP_TRY(launch_scan_mfma16_dma(hp, kdtype, metric, c->num_cus, qpb, persistent, s));
             else HIP_TRY(launch_scan_mfma16(hp, kdtype, metric, c->num_cus, s));
             if (ps && last) {
                 HIP_TRY(hipEventRecord(ps->e[1], s));
@@ -894,7 +931,11 @@ int search_batched_path(const mvfgpu_corpus* c, uint8_t metric, const void* d_qu
                 tm.scan_flops = 2ull * nq * (end - begin) * c->dim;
             }
             tm.scan_launches++;
-            if (regions) HIP_TRY(launch_scatter_cand(hp, kBlkMaxBlocks, s));
+            if (regions) {
+                Batch16Params sp = hp;  // the scatter pass sees a wave's slice as a region of its own
+                if (wave_regions) sp.blk_cap = hp.blk_cap / kBlkWaves;
+                HIP_TRY(launch_scatter_cand(sp, wave_regions ? region_blocks * kBlkWaves : region_blocks, metric, kdtype, s));
+            }
         }
         cp.direct_cnt = (begin == 0 && end > begin && end - begin <= cap) ? (uint32_t)(end - begin) : 0u;
         if (approx) HIP_TRY(launch_compact_margin(cp, nq, s));
@@ -957,7 +998,8 @@ int search_batched_path(const mvfgpu_corpus* c, uint8_t metric, const void* d_qu
     }
 
     int rc = repair_flagged_queries(c, metric, d_queries, nq, nq_pad, k, overflow, d_scores, d_indices, d_raw, s);
-    if (rc == MVF_OK && use_qs && c->scan_path != 5 && c->scan_path != 6) rc = qs_feedback_post(c, nq, s);
+    if (rc == MVF_OK && ((use_qs && c->scan_path != 5 && c->scan_path != 6) || used_bias))
+        rc = qs_feedback_post(c, nq, s, used_bias, use_qs && c->scan_path != 5 && c->scan_path != 6);
     return rc;
 }
 

@@ -61,10 +61,17 @@ struct Batch16Params {
     uint4* blk_cand;
     uint32_t* blk_cnt;
     uint32_t blk_cap;
+    // The LDS-DMA kernel's i32-accumulator flavours (scan_mfma16_bias.inc) split a block's region into one slice per wave
+    // (8 x blk_cap / 8 records, counts in blk_cnt[block * 8 + wave]) and write RAW records {exact sum, row, query, 1}; the
+    // scatter pass computes their keys (scan_mfma16_key.h).  Set by the caller for launches that
+    // scan_mfma16_dma_wave_regions() allows and whose grid fits the regions; the scatter pass is then given
+    // 8 x the regions at 1/8 of the capacity.
+    uint32_t wave_regions;
 };
 
 constexpr uint32_t kBlkMaxBlocks = 512;  // grids this size or smaller use per-block candidate regions ...
-constexpr uint32_t kBlkCap = 16384;      // ... of this many 16-byte records each (128 MiB in all)
+constexpr uint32_t kBlkCap = 16384;      // ... of at least this many 16-byte records each (128 MiB in all; more for large batches)
+constexpr uint32_t kBlkWaves = 8;        // waves per block of the kernels that split their region per wave
 
 struct CompactParams {
     uint64_t* cand;
@@ -144,14 +151,16 @@ bool scan_mfma16_sb_usable(uint32_t nq_pad, uint32_t KT, uint32_t nq);
 hipError_t launch_scan_mfma16_sb(const Batch16Params& p, int dtype, int metric, int num_cus, hipStream_t s);
 uint32_t scan_mfma16_dma_queries_per_block(uint32_t nq);
 uint32_t scan_mfma16_dma_tile_rows(uint32_t bmq);
+bool scan_mfma16_dma_wave_regions(int dtype, uint32_t bmq, bool direct, bool has_regions, uint32_t dim);
 hipError_t launch_scan_mfma16_dma(const Batch16Params& p, int dtype, int metric, int num_cus, uint32_t bmq, bool persistent,
                                   hipStream_t s);
 // ping-pong schedule of the 256-query tile (scan_mfma16_pp.hip); same parameters as the LDS-DMA kernel with bmq = 256
 bool scan_mfma16_pp_usable(uint32_t mtiles, int num_cus, uint32_t KT);
 hipError_t launch_scan_mfma16_pp(const Batch16Params& p, int dtype, int metric, int num_cus, hipStream_t s);
-// files the per-block candidate records of one K2 launch into the per-query lists (p.cand / p.cnt)
+// files the per-block candidate records of one K2 launch into the per-query lists (p.cand / p.cnt); RAW records (the
+// exact integer sum instead of a key: scan_mfma16_key.h) get their keys here, with `metric` and the rows' `dtype`
 // (re-arms blk_cnt[] to zero for the next phase, unless more than `scatter_rearm_max_queries()` queries take the simple form)
-hipError_t launch_scatter_cand(const Batch16Params& p, uint32_t nblocks, hipStream_t s);
+hipError_t launch_scatter_cand(const Batch16Params& p, uint32_t nblocks, int metric, int dtype, hipStream_t s);
 uint32_t scatter_rearm_max_queries();
 hipError_t launch_prep_queries16(const void* q, int dtype, uint32_t nq, uint32_t nq_pad, uint32_t dim, uint32_t KPB,
                                  unsigned char* qprep, float* qaux0, float* qaux1, hipStream_t s);

@@ -32,6 +32,7 @@
 
 #include "bitonic.h"
 #include "mvf_common.h"
+#include "scan_mfma16_key.h"
 
 #include <hip/hip_fp16.h>
 
@@ -391,9 +392,25 @@ __global__ void __launch_bounds__(256) row_norms_f32_kernel(const unsigned char*
 // (8 regions x 2 passes: 50-100 us per call, 0.4 ms of a 10.8-ms search).
 constexpr uint32_t kScatterBlocks = 128, kScatterMaxQueries = 8192, kScatterMaxPer = 64;
 
-__global__ void __launch_bounds__(1024) scatter_cand_kernel(const uint4* blk_cand, uint32_t* blk_cnt, uint32_t blk_cap,
+// RAW records {integer sum, row, query, 1} (scan_mfma16_dma.hip's i32-accumulator flavours, scan_mfma16_key.h) are turned
+// into keyed ones in pass 1, in place: key computed, the threshold / padding-query / deletion tests applied; a record that
+// fails gets the void query and is skipped from then on.
+constexpr uint32_t kVoidQuery = 0xFFFFFFFFu;
+
+__device__ __forceinline__ uint4 resolve_record(uint4* slot, const RawKeyArgs& rk) {
+    uint4 rec = *slot;
+    if (rec.w != 0u) {
+        uint32_t key = 0;
+        const bool ok = raw_record_key(rk, (int32_t)rec.x, rec.y, rec.z, key);
+        rec = make_uint4(key, rec.y, ok ? rec.z : kVoidQuery, 0u);
+        *slot = rec;
+    }
+    return rec;
+}
+
+__global__ void __launch_bounds__(1024) scatter_cand_kernel(uint4* blk_cand, uint32_t* blk_cnt, uint32_t blk_cap,
                                                              uint32_t nregions, uint64_t* cand, uint32_t* cnt, uint32_t cap,
-                                                             uint32_t nq_pad) {
+                                                             uint32_t nq_pad, RawKeyArgs rk) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t* hist = reinterpret_cast<uint32_t*>(smem);  // [nq_pad] records of this block per query, then their global base
     __shared__ uint32_t start_s[kScatterMaxPer + 1];     // flat offset of each of the block's regions
@@ -412,17 +429,20 @@ __global__ void __launch_bounds__(1024) scatter_cand_kernel(const uint4* blk_can
     }
     __syncthreads();
     const uint32_t nreg = r_hi > r_lo ? r_hi - r_lo : 0u, total = start_s[nreg];
-    auto record = [&](uint32_t e) __attribute__((always_inline)) -> uint4 {
+    auto record = [&](uint32_t e) __attribute__((always_inline)) -> uint4* {
         uint32_t lo = 0, hi = nreg;  // the region with start_s[lo] <= e < start_s[lo + 1]
         while (hi - lo > 1) {
             const uint32_t mid = (lo + hi) >> 1;
             if (start_s[mid] <= e) lo = mid;
             else hi = mid;
         }
-        return blk_cand[(size_t)(r_lo + lo) * blk_cap + (e - start_s[lo])];
+        return blk_cand + (size_t)(r_lo + lo) * blk_cap + (e - start_s[lo]);
     };
-    // pass 1: histogram
-    for (uint32_t e = threadIdx.x; e < total; e += 1024) atomicAdd(&hist[record(e).z], 1u);
+    // pass 1: keys of the raw records, histogram
+    for (uint32_t e = threadIdx.x; e < total; e += 1024) {
+        const uint32_t q = resolve_record(record(e), rk).z;
+        if (q != kVoidQuery) atomicAdd(&hist[q], 1u);
+    }
     __syncthreads();
     // pass 2: reserve the ranges
     for (uint32_t i = threadIdx.x; i < nq_pad; i += 1024) {
@@ -433,7 +453,8 @@ __global__ void __launch_bounds__(1024) scatter_cand_kernel(const uint4* blk_can
     // pass 3: store (a query's records take consecutive slots from its base, in arrival order of the LDS atomics;
     // the lists are unordered)
     for (uint32_t e = threadIdx.x; e < total; e += 1024) {
-        const uint4 rec = record(e);
+        const uint4 rec = *record(e);  // this thread resolved it in pass 1
+        if (rec.z == kVoidQuery) continue;
         const uint32_t slot = atomicAdd(&hist[rec.z], 1u);
         if (slot < cap) cand[(size_t)rec.z * cap + slot] = ((uint64_t)rec.x << 32) | rec.y;
     }
@@ -441,12 +462,13 @@ __global__ void __launch_bounds__(1024) scatter_cand_kernel(const uint4* blk_can
     if (threadIdx.x < nreg) blk_cnt[r_lo + threadIdx.x] = 0u;
 }
 
-__global__ void __launch_bounds__(256) scatter_cand_simple_kernel(const uint4* blk_cand, const uint32_t* blk_cnt, uint32_t blk_cap,
-                                                                   uint64_t* cand, uint32_t* cnt, uint32_t cap) {
+__global__ void __launch_bounds__(256) scatter_cand_simple_kernel(uint4* blk_cand, const uint32_t* blk_cnt, uint32_t blk_cap,
+                                                                   uint64_t* cand, uint32_t* cnt, uint32_t cap, RawKeyArgs rk) {
     const uint32_t b = blockIdx.y;
     const uint32_t n = min(blk_cnt[b], blk_cap);
     for (uint32_t e = blockIdx.x * 256u + threadIdx.x; e < n; e += gridDim.x * 256u) {
-        const uint4 rec = blk_cand[(size_t)b * blk_cap + e];
+        const uint4 rec = resolve_record(blk_cand + (size_t)b * blk_cap + e, rk);
+        if (rec.z == kVoidQuery) continue;
         const uint32_t slot = atomicAdd(&cnt[rec.z], 1u);
         if (slot < cap) cand[(size_t)rec.z * cap + slot] = ((uint64_t)rec.x << 32) | rec.y;
     }
@@ -832,8 +854,9 @@ hipError_t launch_row_norms_f32(const unsigned char* rows, uint32_t n, uint32_t 
 
 uint32_t scatter_rearm_max_queries() { return kScatterMaxQueries; }
 
-hipError_t launch_scatter_cand(const Batch16Params& p, uint32_t nblocks, hipStream_t s) {
+hipError_t launch_scatter_cand(const Batch16Params& p, uint32_t nblocks, int metric, int dtype, hipStream_t s) {
     if (!p.blk_cand || nblocks == 0) return hipSuccess;
+    const RawKeyArgs rk = raw_key_args(p, metric, dtype);
     if (p.nq_pad <= kScatterMaxQueries) {
         const size_t lds = (size_t)p.nq_pad * 4;
         if (lds > 48 * 1024) {
@@ -843,10 +866,10 @@ hipError_t launch_scatter_cand(const Batch16Params& p, uint32_t nblocks, hipStre
         }
         const uint32_t grid = std::max(std::min(kScatterBlocks, nblocks), (nblocks + kScatterMaxPer - 1) / kScatterMaxPer);
         hipLaunchKernelGGL(scatter_cand_kernel, dim3(grid), dim3(1024), lds, s, p.blk_cand, p.blk_cnt, p.blk_cap, nblocks, p.cand,
-                           p.cnt, p.cap, p.nq_pad);
+                           p.cnt, p.cap, p.nq_pad, rk);
     } else {
         hipLaunchKernelGGL(scatter_cand_simple_kernel, dim3(4, nblocks), dim3(256), 0, s, p.blk_cand, p.blk_cnt, p.blk_cap, p.cand,
-                           p.cnt, p.cap);
+                           p.cnt, p.cap, rk);
     }
     return hipGetLastError();
 }

@@ -31,6 +31,7 @@
 #include "scan_mfma.h"
 
 #include "mvf_common.h"
+#include "scan_mfma16_key.h"
 
 #include <hip/hip_fp16.h>
 
@@ -41,6 +42,7 @@ namespace mvf {
 namespace {
 
 #include "scan_mfma16_common.inc"
+#include "scan_mfma16_bias.inc"
 
 constexpr int DKB = 64;                       // k-tile bytes per row
 
@@ -74,7 +76,7 @@ template <int BMQ_> struct CfT {
     // for them (4 x 36 KB of ring) and keeps the loads.
     static constexpr bool RC_LDS = BMQ == 256;
     static constexpr int NRC = 8;                               // >= NSTAGE + 1 (one k-tile per tile) with room for waves that lag inside the epilogue
-    static constexpr size_t LDS = (size_t)NSTAGE * STAGE_B + 4 * BMQ * 4 + (RC_LDS ? NRC * 2 * BR * 4 : 0) + 16;  // ring + qaux0 + tau + qaux1 + prefilter [+ row constants] + candidate counter
+    static constexpr size_t LDS = (size_t)NSTAGE * STAGE_B + 4 * BMQ * 4 + (RC_LDS ? NRC * 2 * BR * 4 + 2 * BMQ * 4 : 0) + 16;  // ring + qaux0 + tau + qaux1 + prefilter [+ row constants + the L2 bounds' per-query pair] + candidate counter
 };
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -88,7 +90,9 @@ constexpr int SH = 16;  // MFMA sub-tile: a wave's WQ x WR outputs are (WQ/16) x
 // makes each group touch 16 distinct (row & 3, slot) pairs (SQ_LDS_BANK_CONFLICT = 0).
 __device__ __forceinline__ uint32_t slot_swz(uint32_t x) { return (0x78u >> (2u * x)) & 3u; }
 
-template <int DT, int METRIC, bool DIRECT, bool XS, int BMQ_>
+// REG: the launch has per-block candidate regions (p.blk_cand; persistent grids) -- what the folded pre-filter of the
+// i32-accumulator flavours hands its raw records to; without them those flavours keep round 2's epilogue.
+template <int DT, int METRIC, bool DIRECT, bool XS, int BMQ_, bool REG>
 __global__ void __launch_bounds__(512, 2) scan_mfma16_dma_kernel(Batch16Params p) {
     using AccT = typename std::conditional<DT == MVF_DTYPE_FLOAT16, f32x4, i32x4>::type;
     using Cf = CfT<BMQ_>;
@@ -102,6 +106,8 @@ __global__ void __launch_bounds__(512, 2) scan_mfma16_dma_kernel(Batch16Params p
     float* thr_s = qb_s + BMQ;                                        // [BMQ] pre-filter threshold
     uint32_t* rc_s = reinterpret_cast<uint32_t*>(thr_s + BMQ);        // [NRC][2][BR] per-row constants (RC_LDS)
     uint32_t* bc_s = rc_s + (Cf::RC_LDS ? Cf::NRC * 2 * Cf::BR : 0);  // records in the block's candidate region
+    float* thu_s = reinterpret_cast<float*>(bc_s + 4);                // [BMQ] int8 shadow, L2: (th - |th| 1e-6) / (2 s_q) ...
+    float* u_s = thu_s + BMQ;                                         // [BMQ] ... and 1 / (2 s_q) (scan_mfma16_bias.inc)
     // per-row constants the epilogue needs (scan_mfma16_common.inc): array 0 = norms, array 1 = shadow scale / UInt8 bias
     constexpr bool QSF = DT == MVF_DTYPE_FLOAT16 || (DT == MVF_DTYPE_INT8 && XS);  // float scores
     constexpr bool NEED0 = METRIC != MVF_METRIC_INNER_PRODUCT;
@@ -109,6 +115,9 @@ __global__ void __launch_bounds__(512, 2) scan_mfma16_dma_kernel(Batch16Params p
     const uint32_t* arr0 = QSF ? reinterpret_cast<const uint32_t*>(METRIC == MVF_METRIC_COSINE ? p.xnorm_f : p.xx2)
                                : reinterpret_cast<const uint32_t*>(p.xnorm_i);
     const uint32_t* arr1 = QSF ? reinterpret_cast<const uint32_t*>(p.xscale) : reinterpret_cast<const uint32_t*>(p.xbias_i);
+
+    // i32 accumulators behind a threshold: the pre-filter is folded into the accumulators (scan_mfma16_bias.inc)
+    constexpr bool BIAS = !DIRECT && DT != MVF_DTYPE_FLOAT16 && Cf::RC_LDS && REG;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -149,10 +158,20 @@ __global__ void __launch_bounds__(512, 2) scan_mfma16_dma_kernel(Batch16Params p
             b_src[j] = p.rows + (size_t)(r < p.row_end ? r : r0) * p.pitch;
         }
         if constexpr (Cf::RC_LDS) {  // BR = 256: one 1-KB piece per array (entries r0 .. r0 + 255; beyond row_end: unused)
-            uint32_t* dst = rc_s + (n & (Cf::NRC - 1)) * 2 * Cf::BR;
-            const uint32_t e = min(r0 + 4u * (uint32_t)lane, (p.row_end - 1u) & ~3u);
-            if (NEED0 && wave == 0) __builtin_amdgcn_global_load_lds((glb_ptr_t)(arr0 + e), (lds_ptr_t)dst, 16, 0, 0);
-            if (NEED1 && wave == 1) __builtin_amdgcn_global_load_lds((glb_ptr_t)(arr1 + e), (lds_ptr_t)(dst + Cf::BR), 16, 0, 0);
+            auto rc_tile = [&](uint32_t m) __attribute__((always_inline)) {
+                uint32_t mnt, mmt;
+                slot_tile(m, mnt, mmt);
+                uint32_t* dst = rc_s + (m & (Cf::NRC - 1)) * 2 * Cf::BR;
+                const uint32_t e = min(p.row_begin + mnt * Cf::BR + 4u * (uint32_t)lane, (p.row_end - 1u) & ~3u);
+                if (NEED0 && wave == 0) __builtin_amdgcn_global_load_lds((glb_ptr_t)(arr0 + e), (lds_ptr_t)dst, 16, 0, 0);
+                if (NEED1 && wave == 1) __builtin_amdgcn_global_load_lds((glb_ptr_t)(arr1 + e), (lds_ptr_t)(dst + Cf::BR), 16, 0, 0);
+            };
+            if constexpr (BIAS) {  // one tile AHEAD: the next tile's bounds are computed while this one is multiplied
+                if (n == 0) rc_tile(0);
+                if (n + 1 < my_tiles) rc_tile(n + 1);
+            } else {
+                rc_tile(n);
+            }
         }
     };
     // In the k-loop the pieces are issued after the groups of four MFMAs, so the address path works underneath the
@@ -190,7 +209,7 @@ __global__ void __launch_bounds__(512, 2) scan_mfma16_dma_kernel(Batch16Params p
 #pragma unroll
                 for (int e = 0; e < NE; e++) acc[i][j][e] = 0;
     };
-    zero_acc();
+    if constexpr (!BIAS) zero_acc();
 
     uint32_t c_n = 0, c_kt = 0, c_nt, c_mt;  // compute cursor
     slot_tile(0, c_nt, c_mt);
@@ -224,49 +243,183 @@ __global__ void __launch_bounds__(512, 2) scan_mfma16_dma_kernel(Batch16Params p
             c = __builtin_amdgcn_mfma_i32_16x16x64_i8(__builtin_bit_cast(i32x4, fa), __builtin_bit_cast(i32x4, fb), c, 0, 0, 0);
     };
 
+    // ---- pre-filter folded into the accumulators (scan_mfma16_bias.inc): per-lane state ------------------------------
+    [[maybe_unused]] AccT negb[NI];        // -B of the tile being multiplied, one 4-query vector per group
+    [[maybe_unused]] int32_t br_cur[NJ];   // R(row) of that tile
+    // the lane's smallest threshold (float thresholds; L2 on the int8 shadow: the smallest (th - |th| 1e-6) / (2 s_q)) and,
+    // L2 on the shadow, its smallest 1 / (2 s_q)
+    [[maybe_unused]] float umin = 0.f, thumin = 0.f;
+    [[maybe_unused]] bool thr_ok = false;  // wave-uniform: every threshold of the wave's queries allows the short form of the bounds
+    // the wave's own slice of the block's candidate region and its running record count (wave-uniform)
+    [[maybe_unused]] const uint32_t wcap = p.blk_cap / (uint32_t)NW;
+    [[maybe_unused]] uint4* const wbase = p.blk_cand + ((size_t)blockIdx.x * NW + (uint32_t)wave) * wcap;
+    [[maybe_unused]] uint32_t wcnt = 0;
+    constexpr bool L2Q = QSF && METRIC == MVF_METRIC_L2;
+    auto rc_of = [&](uint32_t n) __attribute__((always_inline)) { return rc_s + (n & (Cf::NRC - 1)) * 2 * Cf::BR; };
+    auto read_thr = [&](int i, u32x4& th4, u32x4& sc4, bool transformed) __attribute__((always_inline)) {
+        const int ql = wm * WQ + 4 * (lane / SH) + i * SH;
+        th4 = *reinterpret_cast<const u32x4*>((L2Q && transformed ? thu_s : thr_s) + ql);
+        sc4 = u32x4{0, 0, 0, 0};
+        if (L2Q) sc4 = *reinterpret_cast<const u32x4*>((transformed ? u_s : qa_s) + ql);  // u / s_q
+        if (U8 && METRIC == MVF_METRIC_COSINE) sc4 = *reinterpret_cast<const u32x4*>(qb_s + ql);  // c_q
+    };
+    // once per query tile: can the lane's thresholds take the short form?  (the caller has published thr_s / qa_s)
+    auto query_prep = [&]() {
+        if constexpr (!QSF && METRIC != MVF_METRIC_COSINE) {  // integer thresholds: the padding queries' 2^30 -> 2^29 (still out of reach here)
+            if (tid < BMQ && c_mt * BMQ + (uint32_t)tid >= p.nq) thr_s[tid] = __int_as_float(kBiasBig);
+            __syncthreads();
+        }
+        if constexpr (L2Q) {
+            if (tid < BMQ) {
+                const float th = thr_s[tid], u = 0.5f * __builtin_amdgcn_rcpf(qa_s[tid]);
+                thu_s[tid] = (th - fabsf(th) * 1e-6f) * u;
+                u_s[tid] = u;
+            }
+            __syncthreads();
+        }
+        bool ok = true;
+        umin = __builtin_inff();
+        thumin = __builtin_inff();
+#pragma unroll
+        for (int i = 0; i < NI; i++) {
+            u32x4 th4, sc4;
+            read_thr(i, th4, sc4, true);
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                if constexpr (L2Q) {
+                    const float a = __uint_as_float(th4[e]), u = __uint_as_float(sc4[e]);
+                    ok &= (fabsf(a) < 3.0e38f) && (u >= 0.0f) && (u < 3.0e38f);
+                    thumin = fminf(thumin, a);
+                    umin = fminf(umin, u);
+                } else if constexpr (QSF || METRIC == MVF_METRIC_COSINE) {
+                    const float th = __uint_as_float(th4[e]);
+                    ok &= th >= 0.0f;  // +inf (padding queries) is fine: their B saturates at 2^29
+                    thumin = fminf(thumin, th);
+                } else {
+                    const int32_t th = (int32_t)th4[e];
+                    ok &= th >= -kBiasBig && th <= kBiasBig;
+                }
+            }
+        }
+        if (!ok) thumin = 0.f;  // a negative (or NaN) threshold in the lane: no multiplicative row term
+        thr_ok = __builtin_amdgcn_ballot_w64(!ok) == 0;
+    };
+    // -B of every query group and R of every row of block tile n: at the start of the tile, in the open
+    auto bias_all = [&](uint32_t n) {
+        uint32_t nt, mt;
+        slot_tile(n, nt, mt);
+        const uint32_t* rc = rc_of(n);
+        LaneRows L;
+        lane_rows16<DT, METRIC, XS, SH, WR, Cf::BR, true, true>(p, nt, wn, lane, rc, rc + Cf::BR, umin, thumin, L, br_cur);
+        bool ok = thr_ok;
+        float kmul = 0.f, xlo_adj = 0.f;
+        if constexpr (QSF || METRIC == MVF_METRIC_COSINE) {
+            ok = ok && L.inv_hi >= 0.0f && L.inv_hi < 3.0e38f;
+            kmul = -L.inv_hi * (1.0f - 2e-6f);
+        }
+        if constexpr (L2Q) {
+            xlo_adj = L.xlo - L.xhi * 1e-6f;
+            ok = ok && xlo_adj >= 0.0f && thumin + xlo_adj * umin >= 0.0f;  // every (th' + xlo') u of the lane is >= 0
+        }
+        if (__builtin_amdgcn_ballot_w64(!ok) == 0) {
+#pragma unroll
+            for (int i = 0; i < NI; i++) {
+                u32x4 th4, sc4;
+                read_thr(i, th4, sc4, true);
+                negb[i] = __builtin_bit_cast(AccT, bias_group16_fast<DT, METRIC, XS>(L, kmul, xlo_adj, th4, sc4));
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NI; i++) {
+                u32x4 th4, sc4;
+                read_thr(i, th4, sc4, false);
+                negb[i] = __builtin_bit_cast(AccT, bias_group16<DT, METRIC, XS>(L, th4, sc4));
+            }
+        }
+    };
+    if constexpr (BIAS) {
+        query_prep();
+        bias_all(0);
+    }
+
     uint32_t cs = 0, ds = NSTAGE - 1;  // compute stage (k-tile g), DMA target (k-tile g + NSTAGE - 1: the stage g - 1 read)
     for (uint32_t g = 0; g < G; g++) {
         const unsigned char* st = smem + cs * STAGE_B;
         // NI groups of NJ MFMAs (one A fragment x NJ B fragments each, the whole 64-B k in one MFMA); the next group's
-        // A fragment is read while this group's MFMAs run; the DMA pieces follow the groups
-        u32x4 fb[NJ], fa[2];
+        // A fragment is read while this group's MFMAs run; the DMA pieces follow the groups; with BIAS the first k-tile
+        // of a tile starts every accumulator from -B
+        auto ktile = [&](auto first_c) __attribute__((always_inline)) {
+            constexpr bool FIRST = decltype(first_c)::value;
+            u32x4 fb[NJ], fa[2];
 #pragma unroll
-        for (int j = 0; j < NJ; j++) fb[j] = read_b(st, j);
-        fa[0] = read_a(st, 0);
+            for (int j = 0; j < NJ; j++) fb[j] = read_b(st, j);
+            fa[0] = read_a(st, 0);
 #pragma unroll
-        for (int i = 0; i < NI; i++) {
-            if (i + 1 < NI) fa[(i + 1) & 1] = read_a(st, i + 1);
+            for (int i = 0; i < NI; i++) {
+                if (i + 1 < NI) fa[(i + 1) & 1] = read_a(st, i + 1);
 #pragma unroll
-            for (int j = 0; j < NJ; j++) mfma1(acc[i][j], fa[i & 1], fb[j]);
-            if (NI == 8 ? (i & 1) == 0 : true) dma_piece(ds, NI == 8 ? i / 2 : i);          // 4 pieces over 8 groups, or
-            if (NI == 4 && i == NI - 1 && Cf::PIECES > NI) dma_piece(ds, NI);                    // 5 pieces over 4 groups
-            __builtin_amdgcn_sched_barrier(0);
-        }
+                for (int j = 0; j < NJ; j++) {
+                    if constexpr (BIAS && FIRST) acc[i][j] = negb[i];  // the MFMA's C operand: no copy is emitted
+                    mfma1(acc[i][j], fa[i & 1], fb[j]);
+                }
+                if (NI == 8 ? (i & 1) == 0 : true) dma_piece(ds, NI == 8 ? i / 2 : i);          // 4 pieces over 8 groups, or
+                if (NI == 4 && i == NI - 1 && Cf::PIECES > NI) dma_piece(ds, NI);                    // 5 pieces over 4 groups
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        if (BIAS && c_kt == 0) ktile(std::true_type{});
+        else ktile(std::false_type{});
         dma_advance();
         cs = cs + 1 == NSTAGE ? 0 : cs + 1;
         ds = ds + 1 == NSTAGE ? 0 : ds + 1;
         if (++c_kt == p.KT) {  // tile finished: its successor's first k-tiles are already in the ring
+            if constexpr (BIAS) {
+#ifndef MVF_DIAG_NOEPI
+                if (lane == 0) MVF_DIAG_ADD(0, 1);
+                epilogue_bias16<BiasTraits<DT, METRIC, XS>::HAS_BR, BMQ, SH, WQ, WR, Cf::BR>(p, acc, negb, br_cur, c_nt, c_mt, wm, wn, lane, wbase, wcap, wcnt);
+                wcnt = __builtin_amdgcn_readfirstlane(wcnt);
+#else
+#pragma unroll
+                for (int i = 0; i < NI; i++)
+#pragma unroll
+                    for (int j = 0; j < NJ; j++) asm volatile("" ::"v"(acc[i][j]));
+#endif
+                c_kt = 0;
+                if (++c_n < my_tiles) {
+                    uint32_t nmt;
+                    slot_tile(c_n, c_nt, nmt);
+                    if (nmt != c_mt) {  // block-uniform; rare
+                        __syncthreads();
+                        load_query_consts16<DT, METRIC, BMQ, (DT == MVF_DTYPE_INT8 && XS)>(p, nmt * BMQ, tid, qa_s, qb_s, tau_s, thr_s);
+                        c_mt = nmt;
+                        __syncthreads();
+                        query_prep();
+                    }
+                    bias_all(c_n);
+                }
+            } else {
 #ifdef MVF_DIAG_NOEPI  // diagnostic build only: the k-loop alone (the sums are kept alive, nothing is selected)
 #pragma unroll
-            for (int i = 0; i < NI; i++)
+                for (int i = 0; i < NI; i++)
 #pragma unroll
-                for (int j = 0; j < NJ; j++) asm volatile("" ::"v"(acc[i][j]));
-            if (false)
+                    for (int j = 0; j < NJ; j++) asm volatile("" ::"v"(acc[i][j]));
+                if (false)
 #endif
-            {
-                const uint32_t* rc = rc_s + (c_n & (Cf::NRC - 1)) * 2 * Cf::BR;
-                epilogue16<DT, METRIC, DIRECT, XS, BMQ, SH, WQ, WR, Cf::BR, Cf::RC_LDS>(p, acc, c_nt, c_mt, wm, wn, lane, qa_s, qb_s, tau_s,
-                                                                                       thr_s, rc, rc + Cf::BR, p.blk_cand ? bc_s : nullptr);
-            }
-            zero_acc();
-            c_kt = 0;
-            if (++c_n < my_tiles) {
-                uint32_t nmt;
-                slot_tile(c_n, c_nt, nmt);
-                if (nmt != c_mt) {  // block-uniform; rare
-                    __syncthreads();
-                    load_query_consts16<DT, METRIC, BMQ, (DT == MVF_DTYPE_INT8 && XS)>(p, nmt * BMQ, tid, qa_s, qb_s, tau_s, thr_s);
-                    c_mt = nmt;
+                {
+                    const uint32_t* rc = rc_s + (c_n & (Cf::NRC - 1)) * 2 * Cf::BR;
+                    epilogue16<DT, METRIC, DIRECT, XS, BMQ, SH, WQ, WR, Cf::BR, Cf::RC_LDS>(p, acc, c_nt, c_mt, wm, wn, lane, qa_s, qb_s, tau_s,
+                                                                                           thr_s, rc, rc + Cf::BR, p.blk_cand ? bc_s : nullptr);
+                }
+                zero_acc();
+                c_kt = 0;
+                if (++c_n < my_tiles) {
+                    uint32_t nmt;
+                    slot_tile(c_n, c_nt, nmt);
+                    if (nmt != c_mt) {  // block-uniform; rare
+                        __syncthreads();
+                        load_query_consts16<DT, METRIC, BMQ, (DT == MVF_DTYPE_INT8 && XS)>(p, nmt * BMQ, tid, qa_s, qb_s, tau_s, thr_s);
+                        c_mt = nmt;
+                    }
                 }
             }
         }
@@ -278,16 +431,22 @@ __global__ void __launch_bounds__(512, 2) scan_mfma16_dma_kernel(Batch16Params p
     }
     // the DMAs issued for k-tiles past the end target this block's own LDS: let them land before the wave exits
     __builtin_amdgcn_s_waitcnt(0x0070 | 0x0F00);  // vmcnt(0)
-    if (tid == 0 && p.blk_cnt) p.blk_cnt[blockIdx.x] = min(*bc_s, p.blk_cap);  // behind the loop's last barrier: every epilogue is done
+    if constexpr (BIAS) {
+        if (lane == 0) p.blk_cnt[blockIdx.x * NW + (uint32_t)wave] = min(wcnt, wcap);  // one region per wave (scan_mfma16_dma_wave_regions)
+    } else {
+        if (tid == 0 && p.blk_cnt) p.blk_cnt[blockIdx.x] = min(*bc_s, p.blk_cap);  // behind the loop's last barrier: every epilogue is done
+    }
 }
 
 template <int DT, int METRIC, int BMQ>
 hipError_t launch_dtm(const Batch16Params& p, dim3 grid, hipStream_t s) {
-    void (*fn)(Batch16Params) =
-        p.direct ? &scan_mfma16_dma_kernel<DT, METRIC, true, false, BMQ> : &scan_mfma16_dma_kernel<DT, METRIC, false, false, BMQ>;
-    if constexpr (DT == MVF_DTYPE_FLOAT16 || DT == MVF_DTYPE_INT8)  // rows are a scaled shadow (f16, or the int8 shadow)
-        if (p.xscale)
-            fn = p.direct ? &scan_mfma16_dma_kernel<DT, METRIC, true, true, BMQ> : &scan_mfma16_dma_kernel<DT, METRIC, false, true, BMQ>;
+    constexpr bool XSOK = DT == MVF_DTYPE_FLOAT16 || DT == MVF_DTYPE_INT8;  // rows may be a scaled shadow (f16, or the int8 shadow)
+    constexpr bool REGOK = DT != MVF_DTYPE_FLOAT16 && BMQ == 256;           // flavours with the folded pre-filter
+    const bool xs = XSOK && p.xscale, reg = REGOK && !p.direct && p.blk_cand && p.wave_regions;
+    void (*fn)(Batch16Params);
+    if (p.direct) fn = xs ? &scan_mfma16_dma_kernel<DT, METRIC, true, XSOK, BMQ, false> : &scan_mfma16_dma_kernel<DT, METRIC, true, false, BMQ, false>;
+    else if (reg) fn = xs ? &scan_mfma16_dma_kernel<DT, METRIC, false, XSOK, BMQ, REGOK> : &scan_mfma16_dma_kernel<DT, METRIC, false, false, BMQ, REGOK>;
+    else fn = xs ? &scan_mfma16_dma_kernel<DT, METRIC, false, XSOK, BMQ, false> : &scan_mfma16_dma_kernel<DT, METRIC, false, false, BMQ, false>;
     // > 64 KiB of dynamic LDS needs the attribute; it is per device, and one process may drive several devices
     const size_t lds = CfT<BMQ>::LDS;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -314,6 +473,17 @@ hipError_t launch_bmq(const Batch16Params& p, int dtype, int metric, dim3 grid, 
 
 }  // namespace
 
+#ifdef MVF_DIAG_COUNT
+extern "C" int mvfgpu_diag_bias_counts(unsigned long long* out8, int reset) {
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_bias_diag), 64) != hipSuccess) return 1;
+    if (reset) {
+        unsigned long long z[8] = {};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_bias_diag), z, 64) != hipSuccess) return 1;
+    }
+    return 0;
+}
+#endif
+
 // queries per block tile for a batch of nq: the 64-query tile (HBM-bound) up to 128 queries, else the 256-query tile
 uint32_t scan_mfma16_dma_queries_per_block(uint32_t nq) {
     if (const char* e = getenv("MVF_K2_TILE")) return atoi(e) == 64 ? 64u : 256u;
@@ -321,6 +491,13 @@ uint32_t scan_mfma16_dma_queries_per_block(uint32_t nq) {
 }
 
 uint32_t scan_mfma16_dma_tile_rows(uint32_t bmq) { return bmq == 64 ? CfT<64>::BR : CfT<256>::BR; }
+
+// Does a launch with these properties hand RAW records to per-WAVE regions (8 per block, blk_cap / 8 records each, counts
+// in blk_cnt[block * 8 + wave]) instead of keyed records to the block's region?  (the folded pre-filter of the
+// i32-accumulator flavours, scan_mfma16_bias.inc; the caller passes the scatter pass 8 x the regions at 1/8 the capacity)
+bool scan_mfma16_dma_wave_regions(int dtype, uint32_t bmq, bool direct, bool has_regions, uint32_t dim) {
+    return dtype != MVF_DTYPE_FLOAT16 && bmq == 256 && !direct && has_regions && dim <= 8192u;  // wider rows: sums beyond 2^27
+}
 
 // p.KPB / p.KT are in 64-byte k-tiles here; p.zeros points at >= 16 zero bytes; p.mtiles = nq_pad / bmq;
 // p.ntiles = ceil(rows / scan_mfma16_dma_tile_rows(bmq)).
@@ -331,7 +508,8 @@ hipError_t launch_scan_mfma16_dma(const Batch16Params& p, int dtype, int metric,
     if (nls > p.mtiles) nls -= nls % p.mtiles;
     const dim3 grid(persistent ? std::min(total, nls * 8u) : total);
     Batch16Params q = p;
-    if (grid.x > kBlkMaxBlocks) q.blk_cand = nullptr, q.blk_cnt = nullptr;  // one candidate region per block: small grids only
+    if (grid.x > kBlkMaxBlocks || (q.wave_regions && grid.x > (uint32_t)num_cus))  // one candidate region per block: small grids only
+        q.blk_cand = nullptr, q.blk_cnt = nullptr, q.wave_regions = 0;
     return bmq == 64 ? launch_bmq<64>(q, dtype, metric, grid, s) : launch_bmq<256>(q, dtype, metric, grid, s);
 }
 
