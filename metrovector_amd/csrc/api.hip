@@ -148,10 +148,12 @@ namespace {
 // round 1 picked "the widest group within 80 % of the best lane utilisation": up to 46 % off the best width on the
 // shapes it had not been measured on (dim 100 / 200 f32, 512 f16, 384 / 1024 int8).  MVF_K1_G forces a width (sweeps).
 void choose_group(uint32_t V, int nqv, int* G_out, uint32_t* J_out) {
-    int g = V <= 2 ? 1 : V <= 8 ? 4 : (V < 192 || (nqv == 4 && V < 512)) ? 16 : 64;
+    // round 3: 5..8 vectors (65..128 B) take 8 lanes -- with 4 a row took two steps and every 128-byte line two separate
+    // wave-loads (128-B rows: 3.3 -> 5.0-5.3 TB/s together with the reduce-scatter of the row sums, profiles/r03_k1_shape_sweep.csv) (3.3 TB/s); one step per row also gets the kernel's software pipeline (scan_stream.inc)
+    int g = V <= 2 ? 1 : V <= 4 ? 4 : V <= 8 ? 8 : (V < 192 || (nqv == 4 && V < 512)) ? 16 : 64;
     if (const char* e = getenv("MVF_K1_G")) {
         const int f = atoi(e);
-        if (f == 64 || f == 16 || f == 4 || f == 1) g = f;
+        if (f == 64 || f == 16 || f == 8 || f == 4 || f == 1) g = f;
     }
     *G_out = g;
     *J_out = (V + g - 1) / g;

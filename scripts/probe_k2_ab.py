@@ -27,10 +27,13 @@ CFGS = {
 }
 ALL_VARIANTS = {"lockstep": {"MVF_K2_PP": "0", "MVF_K2_GROWTH": None, "MVF_I8_SHADOW": "0"},   # f16 / native kernels, no int8 shadow
                 "pingpong": {"MVF_K2_PP": "1", "MVF_K2_GROWTH": None, "MVF_I8_SHADOW": "0"},
-                "default": {"MVF_K2_PP": None, "MVF_K2_GROWTH": None, "MVF_I8_SHADOW": None, "MVF_QS_REFINE": None},
+                "default": {"MVF_K2_PP": None, "MVF_K2_GROWTH": None, "MVF_I8_SHADOW": None, "MVF_QS_REFINE": None, "MVF_K2_BIAS": None},
                 "g3": {"MVF_K2_PP": None, "MVF_K2_GROWTH": "3", "MVF_I8_SHADOW": None, "MVF_QS_REFINE": None},
                 "g5": {"MVF_K2_PP": None, "MVF_K2_GROWTH": "5", "MVF_I8_SHADOW": None, "MVF_QS_REFINE": None},
                 "g6": {"MVF_K2_PP": None, "MVF_K2_GROWTH": "6", "MVF_I8_SHADOW": None, "MVF_QS_REFINE": None},
+                "g8": {"MVF_K2_PP": None, "MVF_K2_GROWTH": "8", "MVF_I8_SHADOW": None, "MVF_QS_REFINE": None},
+                "g12": {"MVF_K2_PP": None, "MVF_K2_GROWTH": "12", "MVF_I8_SHADOW": None, "MVF_QS_REFINE": None},
+                "oldepi": {"MVF_K2_PP": None, "MVF_K2_GROWTH": None, "MVF_I8_SHADOW": None, "MVF_QS_REFINE": None, "MVF_K2_BIAS": "0"},
                 "norefine": {"MVF_K2_PP": None, "MVF_K2_GROWTH": None, "MVF_I8_SHADOW": None, "MVF_QS_REFINE": "0"},
                 "pp_g8": {"MVF_K2_PP": "1", "MVF_K2_GROWTH": "8", "MVF_I8_SHADOW": "0"},
                 "pp_g4": {"MVF_K2_PP": "1", "MVF_K2_GROWTH": "4", "MVF_I8_SHADOW": "0"},

@@ -10,7 +10,7 @@ import torch
 
 from metrovector_amd import _lib, gpu as G
 
-DIMS = [64, 100, 128, 200, 256, 384, 512, 768, 1024, 1536, 2048]
+DIMS = [int(x) for x in os.environ.get("MVF_SWEEP_DIMS", "32,64,100,128,200,256,384,512,768,1024,1536,2048").split(",")]
 ES = {0: 4, 1: 2, 2: 1, 3: 1}
 lib = _lib.gpu()
 print("dtype,dim,row_bytes,G,chosen_by_default,ms_per_scan,GB_per_s,frac_of_hbm_peak", flush=True)
@@ -19,7 +19,7 @@ for dt in (0, 1, 2, 3):
         rb = dim * ES[dt]
         n = min(200_000_000, (4 << 30) // rb)
         res = {}
-        for g in ("", "64", "16", "4", "1"):
+        for g in ("", "64", "16", "8", "4", "1"):
             if g:
                 os.environ["MVF_K1_G"] = g
             else:
