@@ -142,8 +142,9 @@ int mvfgpu_corpus_create(const void* rows, uint64_t n, uint32_t dimension,
  * The same upload with options (NULL = the defaults of mvfgpu_corpus_create).  The upload is a two-stream pipeline
  * (DESIGN.md §6): chunks of `chunk_mib` MiB (0 = 256) cross PCIe on one stream while the other re-pitches the chunk
  * before (rows whose size is not a multiple of 16 bytes, or that lie further apart than their size) and, on request,
- * computes what the first BATCHED search would otherwise build -- the row norms, and for Float32 spaces the scaled-f16
- * shadow used for candidate selection (+50 % device memory; skipped silently when that would leave < 2 GiB free).
+ * computes what the first BATCHED search would otherwise build -- the row norms, and for Float32 / Float16 spaces the
+ * int8 shadow used for candidate selection (+25 % / +50 % device memory; skipped silently when that would leave < 2 GiB
+ * free).
  * Checksum validation of the block (the reference leaves it `todo!()`, src/reader.rs:220) lives in libmvf_host
  * (mvf_reader_validate_with_checksum): run it on another thread beside this call.
  */
@@ -154,7 +155,9 @@ typedef struct mvfgpu_upload_options {
     uint32_t reserved;
 } mvfgpu_upload_options;
 #define MVFGPU_UPLOAD_EAGER_NORMS 1u    /* row norms (K4) per chunk, beside the copy of the next */
-#define MVFGPU_UPLOAD_EAGER_SHADOW 2u   /* Float32 spaces: norms + the f16 shadow per chunk */
+#define MVFGPU_UPLOAD_EAGER_SHADOW 2u   /* Float32 / Float16 spaces: norms + the selection shadow batched searches use, per
+                                           chunk: the INT8 shadow (+dimension bytes per row; the default selection), or
+                                           the scaled-f16 one of a Float32 space when MVF_I8_SHADOW=0 */
 #define MVFGPU_UPLOAD_PINNED_STAGING 4u /* double-buffer through two pinned host chunks filled by memcpy threads: the default
                                            for uploads of >= 256 MiB (50 GB/s measured against 10-21 GB/s for the
                                            pageable source handed to the runtime); this flag forces it for small ones */
@@ -367,20 +370,21 @@ int mvfgpu_last_timing(const mvfgpu_corpus* corpus, mvfgpu_timing* out);
  * 6 = as 5, and ONE TO FOUR queries STREAM THE INT8 SHADOW through K1
  * (`dimension` bytes per row instead of 4x / 2x that; same bound, same exact
  * re-scoring: 1.2-1.3 ms for one query instead of 4.5 on 10M x 768 f32).
- * Path 0 does this for ONE query by itself once the corpus holds an int8
- * shadow anyway (a batched search or an eager upload built it: nothing more
- * to store or build; MVF_STREAM_I8=0 opts out); a corpus without one reads the
- * stored rows.  Two to four queries are served as fast by the 64-query MFMA
- * tile.
+ * MVF_STREAM_I8=1 makes path 0 do this for ONE query once the corpus holds an
+ * int8 shadow anyway (round 2 did so unasked: the answer to the same query then
+ * depended, within the tolerance, on what the handle had served before).  Two
+ * to four queries are served as fast by the 64-query MFMA tile.
  *
- * The f16 shadow: batched searches on a Float32 corpus select candidates with
- * the f16 MFMA kernel on a scaled-f16 copy of the rows (built on the first
- * such search, +50 % of the corpus' device memory; skipped automatically when
- * that would leave < 2 GiB free, or with MVF_F16_SHADOW=0 in the environment),
- * keep every row whose approximate score is within a proven error bound of
- * the k-th, and re-score the kept rows from the stored f32 rows and the f32
- * query.  Scores and order are those of the exact path; only the selection
- * arithmetic differs (~4x faster than the exact f32 MFMA kernel). */
+ * Selection shadows: batched searches on a Float32 / Float16 corpus select
+ * candidates on an INT8 copy of the rows (path 5's, the default: built by the
+ * first such search or an eager upload; skipped when it would leave < 2 GiB
+ * free; MVF_I8_SHADOW=0 opts out) -- or, Float32 corpora on scan path 3 /
+ * without the int8 one, on a scaled-f16 copy (+50 %; MVF_F16_SHADOW=0 opts
+ * out) -- keep every row whose approximate score is within a proven error bound
+ * of the k-th, and re-score the kept rows from the stored rows and the f32
+ * query.  Rows and order are those of the exact path; only the selection
+ * arithmetic differs.  mvfgpu_corpus_get_info reports which shadows a handle
+ * holds (`shadows`) and counts them in `device_bytes`. */
 int mvfgpu_set_scan_path(mvfgpu_corpus* corpus, int path);
 
 #ifdef __cplusplus

@@ -104,16 +104,21 @@ struct mvfgpu_corpus {
     // repair launches had to redo is copied to pinned host memory (no wait); a later search that finds it large
     // (the data defeats the int8 bound: near-duplicates everywhere, heavy-tailed rows) switches this corpus back to the
     // f16 selection for good
-    mutable uint32_t* qs_redo_host = nullptr;
-    mutable hipEvent_t qs_redo_ev = nullptr;
-    mutable bool qs_redo_pending = false, qs_disabled = false;
-    mutable uint32_t qs_redo_nq = 0;
+    // Two slots, used alternately: a search first CONSUMES the count the search two before it posted into its slot
+    // (waiting for that copy if need be: it is two searches old), then posts its own -- so which path a search takes
+    // depends on the sequence of searches alone, never on how fast the host runs ahead of the device.
+    mutable uint32_t* qs_redo_host = nullptr;  // [2] pinned
+    mutable hipEvent_t qs_redo_ev[2] = {nullptr, nullptr};
+    mutable bool qs_redo_pending[2] = {false, false};
+    mutable bool qs_disabled = false;
+    mutable uint32_t qs_redo_nq[2] = {0, 0};
+    mutable uint32_t qs_slot = 0;  // the slot the next post goes to
     mutable uint32_t qs_seen = 0, qs_redone = 0;  // running totals of int8-selected queries / of those the repair pass redid
     // the same feedback guards the folded pre-filter of the i32-accumulator K2 kernels (scan_mfma16_bias.inc): rows whose
     // norms differ wildly inside a lane's four defeat its per-lane bounds, the wave regions overflow and the queries go
     // to the repair pass -- exact, but 50x slower; such a corpus goes back to round 2's epilogue first (fb_bias: the
     // search the pending count belongs to used the folded pre-filter; fb_qs: it selected on the int8 shadow)
-    mutable bool bias_disabled = false, fb_bias = false, fb_qs = false;
+    mutable bool bias_disabled = false, fb_bias[2] = {false, false}, fb_qs[2] = {false, false};
     mutable const uint32_t* last_redo_cnt = nullptr;  // device: the count the newest repair pass produced
     mutable bool xnorm_ready = false;
     mutable uint32_t bstate_slots = 0;    // queries the K2 state arrays are armed for
@@ -488,24 +493,27 @@ bool qs_wanted(const mvfgpu_corpus* c, uint32_t k = 0) {
     return !e || atoi(e) != 0;
 }
 
-// Non-blocking look at what the previous int8-selected search had to repair.
+// What the search before the previous one had to repair (its count was copied to pinned memory behind it; waited for
+// here -- by now it is two searches old -- so the decision does not depend on timing).
 void qs_feedback_poll(const mvfgpu_corpus* c) {
-    if (!c->qs_redo_pending || hipEventQuery(c->qs_redo_ev) != hipSuccess) {
+    const uint32_t sl = c->qs_slot;
+    if (!c->qs_redo_pending[sl]) return;
+    if (hipEventSynchronize(c->qs_redo_ev[sl]) != hipSuccess) {
         (void)hipGetLastError();
         return;
     }
-    c->qs_redo_pending = false;
+    c->qs_redo_pending[sl] = false;
     // running totals (a single streamed query says little by itself), halved now and then so that old history fades
-    c->qs_seen += c->qs_redo_nq;
-    c->qs_redone += std::min(*c->qs_redo_host, c->qs_redo_nq);
+    c->qs_seen += c->qs_redo_nq[sl];
+    c->qs_redone += std::min(c->qs_redo_host[sl], c->qs_redo_nq[sl]);
     if (c->qs_redone >= 4 && (uint64_t)c->qs_redone * 8 > c->qs_seen) {
-        if (c->fb_bias && !c->bias_disabled) {  // first suspect: the folded pre-filter's per-lane bounds
+        if (c->fb_bias[sl] && !c->bias_disabled) {  // first suspect: the folded pre-filter's per-lane bounds
             c->bias_disabled = true;
             if (getenv("MVF_DEBUG_REPAIR"))
                 fprintf(stderr, "[mvfgpu] folded pre-filter switched off for this corpus: %u of %u queries needed the repair path\n",
                         c->qs_redone, c->qs_seen);
             c->qs_seen = c->qs_redone = 0;
-        } else if (c->fb_qs) {
+        } else if (c->fb_qs[sl]) {
             c->qs_disabled = true;
             if (getenv("MVF_DEBUG_REPAIR"))
                 fprintf(stderr, "[mvfgpu] int8-shadow selection switched off for this corpus: %u of %u queries needed the repair path\n",
@@ -517,20 +525,22 @@ void qs_feedback_poll(const mvfgpu_corpus* c) {
     }
 }
 
-// ... and the request for it: the repair count of the search just enqueued, copied to pinned memory behind an event
-// (never waited for).
+// ... and the request for it: the repair count of the search just enqueued, copied to pinned memory behind an event.
 int qs_feedback_post(const mvfgpu_corpus* c, uint32_t nq, hipStream_t s, bool used_bias = false, bool used_qs = true) {
-    if (c->qs_redo_pending || !c->repair.p) return MVF_OK;
-    c->fb_bias = used_bias;
-    c->fb_qs = used_qs;
+    const uint32_t sl = c->qs_slot;
+    if (c->qs_redo_pending[sl] || !c->repair.p) return MVF_OK;  // (pending: this search did not poll -- it took another path first)
     if (!c->qs_redo_host) {
         HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&c->qs_redo_host), 64, hipHostMallocDefault));
-        HIP_TRY(hipEventCreateWithFlags(&c->qs_redo_ev, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&c->qs_redo_ev[0], hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&c->qs_redo_ev[1], hipEventDisableTiming));
     }
-    HIP_TRY(hipMemcpyAsync(c->qs_redo_host, c->last_redo_cnt, 4, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipEventRecord(c->qs_redo_ev, s));
-    c->qs_redo_pending = true;
-    c->qs_redo_nq = nq;
+    c->fb_bias[sl] = used_bias;
+    c->fb_qs[sl] = used_qs;
+    HIP_TRY(hipMemcpyAsync(c->qs_redo_host + sl, c->last_redo_cnt, 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipEventRecord(c->qs_redo_ev[sl], s));
+    c->qs_redo_pending[sl] = true;
+    c->qs_redo_nq[sl] = nq;
+    c->qs_slot = sl ^ 1u;
     return MVF_OK;
 }
 
@@ -1165,18 +1175,22 @@ int search_stream_qs_path(const mvfgpu_corpus* c, uint8_t metric, const void* d_
     return rc;
 }
 
-// One to four queries stream the int8 shadow on request (scan path 6), and ONE query does so by itself once the corpus
-// HOLDS an int8 shadow anyway (a batched search or an eager upload built it): nothing more to store or to build, 1.24
-// instead of 4.5 ms on 10M x 768, same results.  A corpus without one keeps reading the stored rows (the bench's
-// headline: no extra memory, no build).  Two to four queries are served as fast by the 64-query MFMA tile on the same
+// One to four queries stream the int8 shadow on request (scan path 6; MVF_STREAM_I8=1: one query on scan path 0, once the
+// corpus HOLDS an int8 shadow anyway): 1.24 instead of 4.5 ms on 10M x 768, same rows, scores within the tolerance (the
+// re-scoring kernel sums in another order than K1).  By default one query reads the stored rows, whatever the handle
+// has served before (the bench's headline: no extra memory, no build).  Two to four queries are served as fast by the 64-query MFMA tile on the same
 // shadow (1.55-1.65 ms against 1.53-1.72: profiles/r02_stream_int8_shadow_1to4_queries.txt).  MVF_STREAM_I8=0 opts
 // out; a corpus whose queries keep needing the repair pass switches itself back (qs_disabled).
 bool stream_qs_wanted(const mvfgpu_corpus* c, uint32_t nq, uint32_t k) {
     if (nq < 1 || nq > 4 || k > kQsStreamMaxK || !qs_wanted(c, k)) return false;
     if (c->scan_path == 6) return true;
+    // scan path 0: only with MVF_STREAM_I8=1 and once the corpus holds an int8 shadow anyway.  (Round 2 did this by itself:
+    // the same query on the same handle then gave scores in a different summation order -- K1's against the re-scoring
+    // kernel's -- depending on whether an earlier batched search had built the shadow.  An automatic path must not
+    // depend on the handle's history.)
     if (c->scan_path != 0 || nq != 1 || c->shadow8_state != 1) return false;
     const char* e = getenv("MVF_STREAM_I8");
-    return !e || atoi(e) != 0;
+    return e && atoi(e) != 0;
 }
 
 // Scan path 4 applies to one or two queries on a Float32 corpus whose shadow exists (or can be built now).
@@ -1548,7 +1562,8 @@ void mvfgpu_corpus_destroy(mvfgpu_corpus* c) {
         c->h_r.release();
         if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
         if (c->up_stream) (void)hipStreamDestroy(c->up_stream);
-        if (c->qs_redo_ev) (void)hipEventDestroy(c->qs_redo_ev);
+        for (auto e : c->qs_redo_ev)
+            if (e) (void)hipEventDestroy(e);
         if (c->qs_redo_host) (void)hipHostFree(c->qs_redo_host);
         if (c->ev_done) (void)hipEventDestroy(c->ev_done);
         for (auto& ps : c->prof)
@@ -1720,6 +1735,20 @@ int mvfgpu_search_device(const mvfgpu_corpus* c, uint8_t metric, const void* d_q
         wps->whole = false;
         HIP_TRY(hipEventRecord(wps->e[3], s));
     }
+    // Whatever happens below, work may already sit on the stream (norms, a shadow build, scratch): the next call on
+    // ANOTHER stream orders itself behind ev_done, so it is recorded on every way out.
+    struct DoneGuard {
+        const mvfgpu_corpus* c;
+        hipStream_t s;
+        ~DoneGuard() {
+            if (hipEventRecord(c->ev_done, s) == hipSuccess) {
+                c->has_done = true;
+                c->last_stream = s;
+            } else {
+                (void)hipGetLastError();
+            }
+        }
+    } done_guard{c, s};
     bool shadow_stream = false, qs_stream = false;
     if (stream_qs_wanted(c, nq, k)) qs_feedback_poll(c);  // may switch the int8 selection off
     if (stream_qs_wanted(c, nq, k)) {
@@ -1744,10 +1773,7 @@ int mvfgpu_search_device(const mvfgpu_corpus* c, uint8_t metric, const void* d_q
         wps->whole = true;
         c->timing.search_flops = 2ull * nq * c->n * c->dim;
     }
-    HIP_TRY(hipEventRecord(c->ev_done, s));
-    c->has_done = true;
-    c->last_stream = s;
-    return MVF_OK;
+    return MVF_OK;  // ev_done: DoneGuard
 }
 
 int mvfgpu_search(const mvfgpu_corpus* c, uint8_t metric, const void* queries, uint8_t query_dtype,
