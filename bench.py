@@ -739,9 +739,11 @@ def main():
                 if tmb.samples and tmb.scan_ms_avg > 0 and tmb.scan_kernel >= 2:
                     leg["roofline"] = mfma_roofline(tmb, args.dtype)
                     # HBM bytes per launch from the committed PMC passes of this exact workload and kernel
-                    tp = os.path.join(ROOT, "profiles", {2: "r02_bench_n1_q1024_hbm_traffic.json",
-                                                         4: "r02_bench_n1_q1024_shadow_hbm_traffic.json",
-                                                         6: "r02_bench_n1_q1024_i8_shadow_hbm_traffic.json"}.get(tmb.scan_kernel, "-"))
+                    tp = os.path.join(ROOT, "profiles", {2: "r03_bench_n1_q1024_hbm_traffic.json",
+                                                         4: "r03_bench_n1_q1024_shadow_hbm_traffic.json",
+                                                         6: "r03_bench_n1_q1024_i8_shadow_hbm_traffic.json"}.get(tmb.scan_kernel, "-"))
+                    if not os.path.exists(tp):
+                        tp = tp.replace("r03_", "r02_")
                     if os.path.exists(tp):
                         leg["roofline"]["traffic"] = json.load(open(tp))["roofline_traffic_bytes_per_launch"]
                         leg["roofline"]["traffic_source"] = "profiles/" + os.path.basename(tp)

@@ -125,6 +125,35 @@ def k2traffic(fd, wd, out, kname, alg_bytes, comment):
                "roofline_traffic_bytes_per_launch": 2 * f[i] * 1024 + wv * 1024}, open(out, "w"), indent=1)
 
 
+def searchtraffic(fd, wd, out, alg_bytes, comment):
+    """HBM bytes of a WHOLE search: 2 x FETCH_SIZE + WRITE_SIZE summed over every dispatch of the search's kernels,
+    divided by the number of searches in the run (= dispatches of the query-preparation kernel)."""
+    names = ("scan_mfma", "scatter_cand", "compact", "scan_stream", "select_final", "prep_queries", "flag_compact", "rescore", "refine_tau")
+
+    def total(d, counter):
+        t, searches, per = 0.0, 0, defaultdict(float)
+        seen = set()
+        for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+            for r in csv.DictReader(open(f)):
+                if r["Counter_Name"] != counter or not any(n in r["Kernel_Name"] for n in names):
+                    continue
+                t += float(r["Counter_Value"])
+                per[next((n for n in names if n in r["Kernel_Name"]), "other")] += float(r["Counter_Value"])
+                if "prep_queries" in r["Kernel_Name"] and r["Dispatch_Id"] not in seen:
+                    seen.add(r["Dispatch_Id"])
+                    searches += 1
+        return t, max(searches, 1), per
+    f, nf, pf = total(fd, "FETCH_SIZE")
+    w, nw, pw = total(wd, "WRITE_SIZE")
+    json.dump({"source": comment, "searches_in_the_fetch_pass": nf, "searches_in_the_write_pass": nw,
+               "fetch_size_kib_per_search": f / nf, "write_size_kib_per_search": w / nw,
+               "fetch_size_kib_per_search_by_kernel": {k: v / nf for k, v in sorted(pf.items(), key=lambda kv: -kv[1])},
+               "correction": "x2 on FETCH_SIZE for every kernel (gfx950: exact for the 16-byte-per-lane streaming reads of the scan, "
+                             "which is 99 % of the bytes; an upper bound for the small kernels); WRITE_SIZE exact",
+               "algorithmic_bytes_per_search": float(alg_bytes),
+               "search_traffic_bytes": 2 * f / nf * 1024 + w / nw * 1024}, open(out, "w"), indent=1)
+
+
 def calibrate(d, log, out):
     """Pairs the `expect <kernel> <bytes>` lines of scripts/calibrate_fetch_size.py with the largest FETCH_SIZE dispatch of
     that kernel: known bytes / (FETCH_SIZE KiB x 1024) = the factor the counter has to be multiplied by."""
@@ -158,5 +187,7 @@ if __name__ == "__main__":
         calibrate(sys.argv[2], sys.argv[3], sys.argv[4])
     elif mode == "k2traffic":
         k2traffic(*sys.argv[2:])
+    elif mode == "searchtraffic":
+        searchtraffic(*sys.argv[2:])
     elif mode == "traffic":
         traffic(sys.argv[2], sys.argv[3], sys.argv[4], *[int(x) for x in sys.argv[5:11]], sys.argv[11])
