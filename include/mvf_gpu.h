@@ -107,6 +107,10 @@ typedef struct mvfgpu_timing {
     float search_ms;      /* newest search */
     float search_ms_avg;  /* mean over the profiled searches */
     uint64_t search_flops; /* 2 * nq * rows * dim of the whole search */
+    uint32_t repaired_queries; /* newest BATCHED search (whether profiled or not): queries whose candidate budget or region
+                                  overflowed and that the streaming kernel re-did exactly (0 on sane data; a corpus that
+                                  keeps producing them goes back to the slower selection paths by itself) */
+    uint32_t reserved;
 } mvfgpu_timing;
 
 /* ---- library / device ---------------------------------------------------- */

@@ -61,7 +61,7 @@ class Timing(_OutStruct):
                 ("total_ms", C.c_float), ("scan_ms_avg", C.c_float), ("select_ms_avg", C.c_float),
                 ("scan_kernel", C.c_uint32), ("scan_launches", C.c_uint32), ("scan_bytes", C.c_uint64),
                 ("scan_flops", C.c_uint64), ("search_ms", C.c_float), ("search_ms_avg", C.c_float),
-                ("search_flops", C.c_uint64)]
+                ("search_flops", C.c_uint64), ("repaired_queries", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 def _preload_torch_hip() -> None:

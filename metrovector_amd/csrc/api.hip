@@ -835,6 +835,8 @@ int search_batched_path(const mvfgpu_corpus* c, uint8_t metric, const void* d_qu
     uint64_t blk_records = 0;
     if (dma) {
         blk_records = std::min<uint64_t>(std::max<uint64_t>((uint64_t)kBlkMaxBlocks * kBlkCap, 2ull * nq_pad * cap), 32ull << 20);
+        if (const char* e = getenv("MVF_K2_REGION_RECORDS"))  // tests: force the regions to overflow
+            blk_records = std::max<uint64_t>((uint64_t)kBlkMaxBlocks * kBlkWaves, strtoull(e, nullptr, 10));
         blk_records -= blk_records % ((uint64_t)kBlkMaxBlocks * kBlkWaves);
         HIP_TRY(c->blk.reserve((size_t)blk_records * 16 + (size_t)kBlkMaxBlocks * kBlkWaves * 4));
         hp.blk_cand = static_cast<uint4*>(c->blk.p);
@@ -1934,6 +1936,13 @@ int mvfgpu_last_timing(const mvfgpu_corpus* c, mvfgpu_timing* out) {
     if (!c || !out) return fail(MVF_ERR_INVALID_ARGUMENT, "NULL argument");
     std::lock_guard<std::mutex> lk(c->mu);
     mvfgpu_timing tm = c->timing;
+    if (c->last_redo_cnt) {  // the newest batched search's repair count (waits for the handle's last search)
+        DeviceGuard guard(c->device);
+        if (c->has_done) HIP_TRY(hipEventSynchronize(c->ev_done));
+        uint32_t n = 0;
+        HIP_TRY(hipMemcpy(&n, c->last_redo_cnt, 4, hipMemcpyDeviceToHost));
+        tm.repaired_queries = n;
+    }
     if (c->prof_next > 0) {
         DeviceGuard guard(c->device);
         const uint64_t newest = c->prof_next - 1;

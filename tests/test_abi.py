@@ -42,7 +42,7 @@ def test_struct_layouts_match_header():
     want = {"mvfgpu_corpus_info": _lib.CorpusInfo, "mvfgpu_timing": _lib.Timing, "mvfgpu_upload_options": _lib.UploadOptions,
             "mvfgpu_shardset_info": _lib.ShardsetInfo, "mvfgpu_shardset_timing": _lib.ShardsetTiming,
             "mvf_data_block": _lib.DataBlock, "mvf_vector_space": _lib.CVectorSpace, "mvf_vector_slice": _lib.CVectorSlice}
-    assert C.sizeof(_lib.CorpusInfo) == 56 and C.sizeof(_lib.Timing) == 72 and C.sizeof(_lib.DataBlock) == 40
+    assert C.sizeof(_lib.CorpusInfo) == 56 and C.sizeof(_lib.Timing) == 80 and C.sizeof(_lib.DataBlock) == 40
     import subprocess
     import tempfile
     body = "".join('printf("%s %%zu\\n", sizeof(%s));' % (n, n) for n in want)

@@ -272,3 +272,67 @@ def test_out_structs_honour_struct_size(oracle):
         c.search(q, 5, G.COSINE)
         after = c.info()
         assert after.shadows & 1 and after.device_bytes > full.device_bytes
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the folded pre-filter of the int8 / uint8 / int8-shadow kernels (scan_mfma16_bias.inc): bounds that hold, regions that
+# overflow
+# ---------------------------------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("dtype", [0, 1, 2, 3])
+@pytest.mark.parametrize("metric", [G.L2, G.INNER_PRODUCT, G.COSINE])
+def test_batched_search_on_sane_data_needs_no_repairs(oracle, dtype, metric):
+    """300 queries on 300k rows through the default batched path: exact results AND not one query sent to the repair pass
+    -- a conservative bound that is far too loose still gives right answers (every score passes, the regions overflow, the
+    streaming kernel redoes every query), only 50-500 x slower: that happened to UInt8 cosine while this was built."""
+    n, dim, nq, k = 300_000, 96, 300, 33
+    rows = oracle.synth_rows(SEED, 0, n, dim, dtype)
+    q = oracle.synth_queries(SEED + 1, nq, dim, dtype)
+    with G.GpuCorpus.from_array(rows) as c:
+        got = c.search(q, k, metric)
+        assert c.last_timing().repaired_queries == 0
+        c.set_scan_path(1)
+        want = c.search(q[:24], k, metric)
+    if dtype in (2, 3):
+        assert_exact(G.SearchResult(got.scores[:24], got.indices[:24], got.raw[:24]), want.scores, want.indices, want.raw)
+    else:
+        assert recall_at_k(got.indices[:24], want.indices) >= 0.999
+        assert np.abs(got.scores[:24] - want.scores).max() <= 1e-5 * max(1.0, float(np.abs(want.scores).max()))
+
+
+@pytest.mark.parametrize("dtype,metric", [(2, G.INNER_PRODUCT), (3, G.L2), (0, G.COSINE)])
+def test_overflowing_wave_regions_are_repaired_exactly(oracle, monkeypatch, dtype, metric):
+    """MVF_K2_REGION_RECORDS shrinks the candidate regions to two records per wave: nearly every candidate finds its
+    region full, its query is marked, and the streaming kernel redoes it -- the answers stay exact."""
+    n, dim, nq, k = 200_000, 64, 300, 20
+    rows = oracle.synth_rows(SEED, 0, n, dim, dtype)
+    q = oracle.synth_queries(SEED + 1, nq, dim, dtype)
+    monkeypatch.setenv("MVF_K2_REGION_RECORDS", "4096")
+    with G.GpuCorpus.from_array(rows) as c:
+        got = c.search(q, k, metric)
+        repaired = c.last_timing().repaired_queries
+    assert repaired > nq // 2, f"only {repaired} of {nq} queries overflowed: the regions were not small"
+    osc, oidx, oraw = oracle.search(rows, dtype, metric, q, k)
+    if dtype in (2, 3):
+        assert_exact(got, osc, oidx, oraw)
+    else:
+        assert recall_at_k(got.indices, oidx) >= 0.999
+
+
+def test_rows_of_wildly_different_norms_keep_the_batched_path_exact(oracle):
+    """Float rows whose norms span two orders of magnitude (the per-lane bounds of the folded pre-filter are loose there;
+    the multiplicative row term has to carry them): cosine and inner product stay on the fast path, every metric is exact."""
+    rng = np.random.default_rng(4)
+    n, dim, nq, k = 200_000, 64, 300, 25
+    rows = (rng.standard_normal((n, dim)) * np.exp(rng.uniform(-2.3, 2.3, n))[:, None]).astype(np.float32)
+    q = rng.standard_normal((nq, dim)).astype(np.float32)
+    with G.GpuCorpus.from_array(rows) as c:
+        for metric in (G.COSINE, G.INNER_PRODUCT, G.L2):
+            c.set_scan_path(0)
+            got = c.search(q, k, metric)
+            repaired = c.last_timing().repaired_queries
+            c.set_scan_path(1)
+            want = c.search(q[:16], k, metric)
+            assert recall_at_k(got.indices[:16], want.indices) >= 0.999
+            if metric != G.L2:  # (the int8 selection's L2 bound itself gives up on such rows: repairs are legitimate there)
+                assert repaired == 0, f"metric {metric}: {repaired} queries repaired"
