@@ -135,7 +135,7 @@ const char* mvfgpu_last_error_message(void);
  *                  for an unsharded space.
  * Errors: MVF_ERR_BUILD for a data type other than Float32/Float16/Int8/UInt8
  * ("Unsupported vector data type", vector_space.rs:126); MVF_ERR_INVALID_
- * ARGUMENT for dimension 0, NULL rows with n > 0, n >= 2^32-1 rows per shard;
+ * ARGUMENT for dimension 0, NULL rows with n > 0, n > 2^32-65536 rows per shard;
  * MVF_ERR_DEVICE for HIP failures (incl. out of memory).
  */
 int mvfgpu_corpus_create(const void* rows, uint64_t n, uint32_t dimension,

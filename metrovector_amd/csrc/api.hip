@@ -180,7 +180,8 @@ int validate_shape(uint64_t n, uint32_t dim, uint8_t dtype) {
     if (is_int_dtype(dtype) && dim > MVFGPU_MAX_INT_DIM)
         return fail(MVF_ERR_BUILD, "Int8/UInt8 dimension exceeds the exact-i32 bound (33025)");
     if ((uint64_t)dim * elem_size(dtype) > (1ull << 30)) return fail(MVF_ERR_INVALID_ARGUMENT, "a row holds at most 1 GiB");
-    if (n >= 0xFFFFFFFFull) return fail(MVF_ERR_INVALID_ARGUMENT, "a shard holds at most 2^32-2 rows");
+    // local row numbers are u32, and the streaming kernel rounds the last chunk up (by < 2^16 rows) before it masks
+    if (n > 0xFFFF0000ull) return fail(MVF_ERR_INVALID_ARGUMENT, "a shard holds at most 2^32-65536 rows");
     return MVF_OK;
 }
 
@@ -257,13 +258,13 @@ int search_stream_path(const mvfgpu_corpus* c, uint8_t metric, const void* d_que
         int G;
         uint32_t J;
         choose_group(kV, nqv, &G, &J);  // the lane-group width depends on the queries per pass
-        uint32_t chunk_rows = scan_chunk_rows(G), pmax = next_pow2(k + chunk_rows);
+        uint32_t chunk_rows = scan_chunk_rows(G, J, nqv), pmax = next_pow2(k + scan_chunk_safe(G));
         size_t lds = scan_lds_bytes(kdtype, G, J, nqv, pmax);
         if (nqv == 4 && lds > 150 * 1024) {
             nqv = 1;
             choose_group(kV, nqv, &G, &J);
-            chunk_rows = scan_chunk_rows(G);
-            pmax = next_pow2(k + chunk_rows);
+            chunk_rows = scan_chunk_rows(G, J, nqv);
+            pmax = next_pow2(k + scan_chunk_safe(G));
             lds = scan_lds_bytes(kdtype, G, J, nqv, pmax);
         }
         uint32_t nchunks = (uint32_t)((c->n + chunk_rows - 1) / chunk_rows);
@@ -285,9 +286,10 @@ int search_stream_path(const mvfgpu_corpus* c, uint8_t metric, const void* d_que
                // blocks -> 782, 52 -> 31 us per search).  Up to four chunks per block the last round is uneven (700K x 256:
                // 1368 chunks on 1280 blocks, i.e. two rounds for 7 % of the blocks): P = ceil(chunks / blocks) rounds of
                // equal, smaller chunks instead (181 -> 144 us; 1M..3M rows: 1-5 %).  Larger corpora keep the 512-row chunks
-               // (the headline's 496-row "balanced" chunks measured 1.4 % slower than 512).
+               // (the headline's 496-row "balanced" chunks measured 1.4 % slower than 512); the long chunks of short rows
+               // (scan_chunk_rows) are few per block and stay balanced up to 16 rounds.
                 const uint32_t slots = (uint32_t)occ * (uint32_t)c->num_cus, step = 16u * 64u / (uint32_t)G;
-                if (nchunks >= slots && nchunks < 4u * slots) {
+                if (nchunks >= slots && nchunks < (chunk_rows > scan_chunk_safe(G) ? 16u : 4u) * slots) {
                     const uint32_t P = (nchunks + slots - 1) / slots;
                     const uint64_t per = (c->n + (uint64_t)P * slots - 1) / ((uint64_t)P * slots);
                     const uint32_t cr = (uint32_t)((per + step - 1) / step * step);
@@ -331,6 +333,7 @@ int search_stream_path(const mvfgpu_corpus* c, uint8_t metric, const void* d_que
             sp.kcap = kcap;
             sp.pmax = pmax;
             sp.chunk_rows = chunk_rows;
+            sp.chunk_safe = std::min(scan_chunk_safe(G), chunk_rows);
             sp.nchunks = nchunks;
             if (ps && first) HIP_TRY(hipEventRecord(ps->e[0], s));
             if (alt8) HIP_TRY(scan_stream_launch_dt2x(sp, metric, G, nqv, dim3(nblocks), lds, s));
@@ -631,13 +634,13 @@ int repair_flagged_queries(const mvfgpu_corpus* c, uint8_t metric, const void* d
     int nqv = 4, G;
     uint32_t J;
     choose_group(c->V, nqv, &G, &J);
-    uint32_t chunk_rows = scan_chunk_rows(G), pmax = next_pow2(k + chunk_rows);
+    uint32_t chunk_rows = scan_chunk_rows(G, J, nqv), pmax = next_pow2(k + scan_chunk_safe(G));
     size_t lds = scan_lds_bytes(c->dtype, G, J, nqv, pmax);
     if (lds > 150 * 1024) {
         nqv = 1;
         choose_group(c->V, nqv, &G, &J);
-        chunk_rows = scan_chunk_rows(G);
-        pmax = next_pow2(k + chunk_rows);
+        chunk_rows = scan_chunk_rows(G, J, nqv);
+        pmax = next_pow2(k + scan_chunk_safe(G));
         lds = scan_lds_bytes(c->dtype, G, J, nqv, pmax);
     }
     const uint32_t nchunks = (uint32_t)((c->n + chunk_rows - 1) / chunk_rows);
@@ -676,6 +679,7 @@ int repair_flagged_queries(const mvfgpu_corpus* c, uint8_t metric, const void* d
         sp.kcap = kcap;
         sp.pmax = pmax;
         sp.chunk_rows = chunk_rows;
+        sp.chunk_safe = std::min(scan_chunk_safe(G), chunk_rows);
         sp.nchunks = nchunks;
         sp.redo_list = redo_list;
         sp.redo_cnt = redo_cnt;

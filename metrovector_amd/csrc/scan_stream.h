@@ -27,8 +27,9 @@ struct ScanParams {
     uint32_t nq_total;
     uint32_t k;
     uint32_t kcap;              // next_pow2(k): entries per emitted list
-    uint32_t pmax;              // next_pow2(k + chunk_rows): LDS buffer entries per query
-    uint32_t chunk_rows;
+    uint32_t pmax;              // next_pow2(k + chunk_safe): LDS buffer entries per query
+    uint32_t chunk_rows;        // rows per chunk (blocks take chunks in turn); a multiple of 16*64/G
+    uint32_t chunk_safe;        // rows per piece that cannot overflow the buffer (<= chunk_rows)
     uint32_t nchunks;
     // REPAIR launches (api.hip: queries whose K2 candidate budget overflowed are redone exactly, decided ON THE DEVICE):
     // the queries are redo_list[redo_base + i], i < min(*redo_cnt - redo_base, redo_max); the block walks them in
@@ -51,8 +52,21 @@ MVF_DECL_SCAN(1x)  // Float16 rows of an f32 corpus' shadow, scaled back by Scan
 MVF_DECL_SCAN(2x)  // Int8 shadow rows of a float corpus: exact i32 dot, float keys dot * xscale[r] * qaux0[q]; nqv = 1 or 4
 #undef MVF_DECL_SCAN
 
-// rows per chunk for a lane-group width G (multiple of the 16*64/G rows a block covers per step)
-inline uint32_t scan_chunk_rows(int G) { return G == 1 ? 1024u : 512u; }
+// Rows per SAFE piece for a lane-group width G (multiple of the 16*64/G rows a block covers per iteration): the candidate
+// buffer of a query holds pmax = next_pow2(k + safe) entries, so a piece of `safe` rows cannot overflow it.
+inline uint32_t scan_chunk_safe(int G) { return G == 1 ? 1024u : 512u; }
+
+// Rows per chunk.  A wave covers 4 * 64/G rows per iteration, so on short rows a 512-row chunk is 2-8 iterations between
+// two barriers, each starting from an empty memory pipeline (64-B Int8 rows ran at 4.1 TB/s, 128-B Float32 rows at 4.8).
+// One query per pass takes chunks of >= 16 row-steps per wave; the kernel scans them as one guarded piece once the
+// threshold is set and falls back to safe pieces if the buffer overflows (scan_stream.inc).  Larger buffers instead cost
+// occupancy: 2048-row chunks with a 4096-entry buffer were slower than 1024.  Four queries per pass keep one safe piece.
+inline uint32_t scan_chunk_rows(int G, uint32_t J, int nqv) {
+    const uint32_t safe = scan_chunk_safe(G);
+    if (nqv != 1) return safe;
+    const uint32_t step = 16u * 64u / (uint32_t)G, want = 16u * step / (J ? J : 1u);
+    return want <= safe ? safe : (want + safe - 1) / safe * safe;
+}
 
 // bytes of dynamic LDS the kernel carves
 inline size_t scan_lds_bytes(int dtype, int G, uint32_t J, int nqv, uint32_t pmax) {  // dtype: of the rows the kernel reads

@@ -336,3 +336,76 @@ def test_rows_of_wildly_different_norms_keep_the_batched_path_exact(oracle):
             assert recall_at_k(got.indices[:16], want.indices) >= 0.999
             if metric != G.L2:  # (the int8 selection's L2 bound itself gives up on such rows: repairs are legitimate there)
                 assert repaired == 0, f"metric {metric}: {repaired} queries repaired"
+
+
+def _numpy_topk(scores, k, largest):
+    """k best of an exact score vector, ties to the lower row (the composite order of the kernels)."""
+    key = -scores if largest else scores
+    order = np.lexsort((np.arange(scores.shape[0]), key))[:k]
+    return order, scores[order]
+
+
+@pytest.mark.parametrize("k", [10, 1000])
+@pytest.mark.parametrize("case", ["i8_64B", "f32_128B", "f32_256B", "i8_16B"])
+def test_short_rows_arriving_best_last_overflow_the_long_pieces_and_stay_exact(case, k):
+    """K1 scans short rows in long guarded pieces (scan_stream.inc).  Rows whose score improves with the row number beat the
+    running threshold every time: every long piece overflows its candidate buffer and is redone in safe pieces.  A dropped
+    survivor would be one of the BEST rows of its piece, so a fallback that did not run shows as a wrong list."""
+    n = 3_000_000
+    r = np.arange(n, dtype=np.int64)
+    if case == "i8_64B":  # inner product = d0 + 100 d1 + 10^4 d2, strictly increasing over 600k rows, then again
+        dim, metric, m = 64, G.INNER_PRODUCT, r % 600_000
+        rows = np.zeros((n, dim), np.int8)
+        rows[:, 0], rows[:, 1] = m % 100, (m // 100) % 100
+        d2 = (m // 10_000)[:, None]
+        rows[:, 2:62] = np.where(np.arange(60)[None, :] < d2, 100, 0)
+        q = np.zeros((1, dim), np.int8)
+        q[0, 0], q[0, 1], q[0, 2:62] = 1, 100, 100
+        exact = rows[:, :2].astype(np.int64) @ q[0, :2].astype(np.int64) + 10_000 * d2[:, 0]
+        largest = True
+    elif case == "i8_16B":  # one lane per row; the same digits in 16 bytes, strictly increasing over 150k rows
+        dim, metric, m = 16, G.INNER_PRODUCT, r % 150_000
+        rows = np.zeros((n, dim), np.int8)
+        rows[:, 0], rows[:, 1] = m % 100, (m // 100) % 100
+        d2 = (m // 10_000)[:, None]
+        rows[:, 2:16] = np.where(np.arange(14)[None, :] < d2, 100, 0)
+        q = np.zeros((1, dim), np.int8)
+        q[0, 0], q[0, 1], q[0, 2:16] = 1, 100, 100
+        exact = rows[:, :2].astype(np.int64) @ q[0, :2].astype(np.int64) + 10_000 * d2[:, 0]
+        largest = True
+    else:
+        dim = 32 if case == "f32_128B" else 64
+        metric = G.L2
+        rows = np.zeros((n, dim), np.float32)
+        rows[:, 0] = (4_000_000 - r).astype(np.float32)  # distance to the origin falls by one per row, exactly
+        q = np.zeros((1, dim), np.float32)
+        exact = np.abs(rows[:, 0].astype(np.float64))
+        largest = False
+    widx, wsc = _numpy_topk(exact, k, largest)
+    with G.GpuCorpus.from_array(rows) as c:
+        c.set_scan_path(1)
+        got = c.search(q, k, metric)
+    assert (got.indices[0] == widx).all()
+    if rows.dtype == np.int8:
+        assert (got.raw[0] == wsc).all()
+    else:
+        assert np.abs(got.scores[0] - wsc).max() == 0.0
+
+
+@pytest.mark.parametrize("dtype,dim", [(2, 64), (0, 32), (1, 64), (0, 64), (3, 32)])
+@pytest.mark.parametrize("metric", [G.L2, G.INNER_PRODUCT, G.COSINE])
+def test_short_rows_in_long_pieces_match_the_oracle(oracle, dtype, dim, metric):
+    """Random short rows, enough of them for the long pieces to be in play (> 2048 blocks x 512 rows), one query: K1 vs the
+    CPU oracle -- integers bit-exact, floats within the tolerance."""
+    n, k = 2_500_000, 100
+    rows = oracle.synth_rows(SEED, 0, n, dim, dtype)
+    q = oracle.synth_queries(SEED + 7, 1, dim, dtype)
+    with G.GpuCorpus.from_array(rows) as c:
+        c.set_scan_path(1)
+        got = c.search(q, k, metric)
+    osc, oidx, oraw = oracle.search(rows, dtype, metric, q, k)
+    if dtype in (2, 3):
+        assert_exact(got, osc, oidx, oraw)
+    else:
+        assert recall_at_k(got.indices, oidx) >= 0.999
+        assert np.abs(got.scores - osc).max() <= 1e-5 * max(1.0, float(np.abs(osc).max()))
