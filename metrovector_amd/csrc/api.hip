@@ -154,11 +154,17 @@ namespace {
 // shapes it had not been measured on (dim 100 / 200 f32, 512 f16, 384 / 1024 int8).  MVF_K1_G forces a width (sweeps).
 void choose_group(uint32_t V, int nqv, int* G_out, uint32_t* J_out) {
     // round 3: 5..8 vectors (65..128 B) take 8 lanes -- with 4 a row took two steps and every 128-byte line two separate
-    // wave-loads (128-B rows: 3.3 -> 5.0-5.3 TB/s together with the reduce-scatter of the row sums, profiles/r03_k1_shape_sweep.csv) (3.3 TB/s); one step per row also gets the kernel's software pipeline (scan_stream.inc)
-    int g = V <= 2 ? 1 : V <= 4 ? 4 : V <= 8 ? 8 : (V < 192 || (nqv == 4 && V < 512)) ? 16 : 64;
+    // wave-loads.
+    int g = V <= 1 ? 1 : V <= 4 ? 4 : V <= 8 ? 8 : (V < 192 || (nqv == 4 && V < 512)) ? 16 : 64;
+    // Rows that are not a multiple of 128 B (V % 8 != 0) start in the middle of a cache line: a 16-lane group's load is four
+    // separate unaligned spans and the ragged last step idles most lanes (4.0-4.5 TB/s for every such V from 17 up,
+    // profiles/r03_k1_vectors_per_row.csv).  The widest group whose ONE load covers whole adjacent rows is better there:
+    // 64 lanes from 33 vectors on (800-B rows 4.2 -> 5.1 TB/s, 1600-B 4.8 -> 5.6), 32 lanes for 17..31 (two adjacent rows
+    // per wave-load); 32-B rows take 4 lanes, half of them idle, instead of one lane per row (3.4 -> 4.6 TB/s).
+    if (nqv == 1 && V % 8 != 0 && V > 16 && V < 192) g = V > 32 ? 64 : 32;
     if (const char* e = getenv("MVF_K1_G")) {
         const int f = atoi(e);
-        if (f == 64 || f == 16 || f == 8 || f == 4 || f == 1) g = f;
+        if (f == 64 || f == 32 || f == 16 || f == 8 || f == 4 || f == 1) g = f;
     }
     *G_out = g;
     *J_out = (V + g - 1) / g;

@@ -19,7 +19,7 @@ for dt in (0, 1, 2, 3):
         rb = dim * ES[dt]
         n = min(200_000_000, (4 << 30) // rb)
         res = {}
-        for g in ("", "64", "16", "8", "4", "1"):
+        for g in ("", "64", "32", "16", "8", "4", "1"):
             if g:
                 os.environ["MVF_K1_G"] = g
             else:

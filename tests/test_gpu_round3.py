@@ -409,3 +409,22 @@ def test_short_rows_in_long_pieces_match_the_oracle(oracle, dtype, dim, metric):
     else:
         assert recall_at_k(got.indices, oidx) >= 0.999
         assert np.abs(got.scores - osc).max() <= 1e-5 * max(1.0, float(np.abs(osc).max()))
+
+
+@pytest.mark.parametrize("dtype,dim", [(0, 100), (0, 200), (0, 300), (2, 300), (1, 200), (2, 32), (3, 24), (1, 9)])
+@pytest.mark.parametrize("metric", [G.L2, G.INNER_PRODUCT, G.COSINE])
+def test_rows_that_are_no_multiple_of_128_bytes_take_the_wide_groups(oracle, dtype, dim, metric):
+    """One query on rows of 17..31 vectors (32 lanes, two adjacent rows per wave-load), of 33..191 vectors that are no
+    multiple of 8 (64 lanes) and of 32 bytes (4 lanes, half of them idle) -- choose_group's round-3 rules -- vs the oracle."""
+    n, k = 400_000, 64
+    rows = oracle.synth_rows(SEED, 0, n, dim, dtype)
+    q = oracle.synth_queries(SEED + 3, 1, dim, dtype)
+    with G.GpuCorpus.from_array(rows) as c:
+        c.set_scan_path(1)
+        got = c.search(q, k, metric)
+    osc, oidx, oraw = oracle.search(rows, dtype, metric, q, k)
+    if dtype in (2, 3):
+        assert_exact(got, osc, oidx, oraw)
+    else:
+        assert recall_at_k(got.indices, oidx) >= 0.999
+        assert np.abs(got.scores - osc).max() <= 1e-5 * max(1.0, float(np.abs(osc).max()))
