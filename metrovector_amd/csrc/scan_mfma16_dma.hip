@@ -46,17 +46,20 @@ namespace {
 
 constexpr int DKB = 64;                       // k-tile bytes per row
 
-// Two block shapes, both 8 waves:
+// Three block shapes, all 8 waves:
 //   BMQ = 256 queries x 256 corpus rows: waves 2 (queries) x 4 (rows), each 128 x 64 outputs; ring of 4 stages x 32 KB.
 //     MFMA-bound (power-limited).
-//   BMQ = 64 queries x 512 corpus rows (batches <= 128): waves 1 x 8, each 64 x 64 outputs; a quarter of the MFMA work
+//   BMQ = 64 queries x 512 corpus rows (batches <= 64): waves 1 x 8, each 64 x 64 outputs; a quarter of the MFMA work
 //     per corpus byte, so the kernel is HBM-bound: ring of 4 stages x 36 KB, two of them (64 KB of corpus bytes) in
 //     flight, and twice the rows per barrier of the other shape (with 256 rows and 8 MFMAs per wave between barriers
 //     the k-tile iteration was latency-bound at 4.9 TB/s, whatever the ring depth).
+//   BMQ = 128 queries x 256 corpus rows (batches of 65..128): waves 2 x 4, each 64 x 64 outputs; ring of 4 x 24 KB.  With
+//     two 64-query tiles such a batch moved every corpus byte into LDS twice and ran at 2/3 of the HBM rate; padded to
+//     the 256-query tile it did twice the matrix work it needed (50M x 768 int8, 128 queries: 10.0 ms either way).
 template <int BMQ_> struct CfT {
     static constexpr int NW = 8;
     static constexpr int BMQ = BMQ_;                            // queries (A rows) per block
-    static constexpr int BR = BMQ == 256 ? 256 : 512;           // corpus rows per block tile
+    static constexpr int BR = BMQ == 64 ? 512 : 256;            // corpus rows per block tile
     static constexpr int WQ = BMQ == 256 ? 128 : 64;            // a wave's share of the tile: queries ...
     static constexpr int WR = 64;                               // ... x corpus rows
     static constexpr int WN = BR / WR;                          // waves along the rows (4 or 8); NW / WN along the queries
@@ -74,7 +77,7 @@ template <int BMQ_> struct CfT {
     // ordinary global load in the epilogue waits a full HBM round trip with the matrix pipe idle AND drains the ring
     // (s_waitcnt vmcnt(0)): that was 20 % of the int8-selection scan.  The 64-query shape has no LDS left
     // for them (4 x 36 KB of ring) and keeps the loads.
-    static constexpr bool RC_LDS = BMQ == 256;
+    static constexpr bool RC_LDS = BR == 256;
     static constexpr int NRC = 8;                               // >= NSTAGE + 1 (one k-tile per tile) with room for waves that lag inside the epilogue
     static constexpr size_t LDS = (size_t)NSTAGE * STAGE_B + 4 * BMQ * 4 + (RC_LDS ? NRC * 2 * BR * 4 + 2 * BMQ * 4 : 0) + 16;  // ring + qaux0 + tau + qaux1 + prefilter [+ row constants + the L2 bounds' per-query pair] + candidate counter
 };
@@ -362,8 +365,8 @@ __global__ void __launch_bounds__(512, 2) scan_mfma16_dma_kernel(Batch16Params p
                     if constexpr (BIAS && FIRST) acc[i][j] = negb[i];  // the MFMA's C operand: no copy is emitted
                     mfma1(acc[i][j], fa[i & 1], fb[j]);
                 }
-                if (NI == 8 ? (i & 1) == 0 : true) dma_piece(ds, NI == 8 ? i / 2 : i);          // 4 pieces over 8 groups, or
-                if (NI == 4 && i == NI - 1 && Cf::PIECES > NI) dma_piece(ds, NI);                    // 5 pieces over 4 groups
+                if (NI == 8 ? (i & 1) == 0 : i < Cf::PIECES) dma_piece(ds, NI == 8 ? i / 2 : i);  // 4 pieces over 8 groups, or
+                if (NI == 4 && i == NI - 1 && Cf::PIECES > NI) dma_piece(ds, NI);                    // 3 or 5 pieces over 4 groups
                 __builtin_amdgcn_sched_barrier(0);
             }
         };
@@ -441,7 +444,7 @@ __global__ void __launch_bounds__(512, 2) scan_mfma16_dma_kernel(Batch16Params p
 template <int DT, int METRIC, int BMQ>
 hipError_t launch_dtm(const Batch16Params& p, dim3 grid, hipStream_t s) {
     constexpr bool XSOK = DT == MVF_DTYPE_FLOAT16 || DT == MVF_DTYPE_INT8;  // rows may be a scaled shadow (f16, or the int8 shadow)
-    constexpr bool REGOK = DT != MVF_DTYPE_FLOAT16 && BMQ == 256;           // flavours with the folded pre-filter
+    constexpr bool REGOK = DT != MVF_DTYPE_FLOAT16 && CfT<BMQ>::RC_LDS;     // flavours with the folded pre-filter
     const bool xs = XSOK && p.xscale, reg = REGOK && !p.direct && p.blk_cand && p.wave_regions;
     void (*fn)(Batch16Params);
     if (p.direct) fn = xs ? &scan_mfma16_dma_kernel<DT, METRIC, true, XSOK, BMQ, false> : &scan_mfma16_dma_kernel<DT, METRIC, true, false, BMQ, false>;
@@ -484,19 +487,24 @@ extern "C" int mvfgpu_diag_bias_counts(unsigned long long* out8, int reset) {
 }
 #endif
 
-// queries per block tile for a batch of nq: the 64-query tile (HBM-bound) up to 128 queries, else the 256-query tile
+// queries per block tile for a batch of nq: the 64-query tile (HBM-bound) up to 64 queries, the 128-query tile up to 128,
+// else the 256-query tile
 uint32_t scan_mfma16_dma_queries_per_block(uint32_t nq) {
-    if (const char* e = getenv("MVF_K2_TILE")) return atoi(e) == 64 ? 64u : 256u;
-    return nq <= 128 ? 64u : 256u;
+    if (const char* e = getenv("MVF_K2_TILE")) {
+        const int t = atoi(e);
+        return t == 64 ? 64u : t == 128 ? 128u : 256u;
+    }
+    return nq <= 64 ? 64u : nq <= 128 ? 128u : 256u;
 }
 
-uint32_t scan_mfma16_dma_tile_rows(uint32_t bmq) { return bmq == 64 ? CfT<64>::BR : CfT<256>::BR; }
+uint32_t scan_mfma16_dma_tile_rows(uint32_t bmq) { return bmq == 64 ? CfT<64>::BR : CfT<256>::BR; }  // 128: as 256
+static_assert(CfT<128>::BR == CfT<256>::BR, "tile rows");
 
 // Does a launch with these properties hand RAW records to per-WAVE regions (8 per block, blk_cap / 8 records each, counts
 // in blk_cnt[block * 8 + wave]) instead of keyed records to the block's region?  (the folded pre-filter of the
 // i32-accumulator flavours, scan_mfma16_bias.inc; the caller passes the scatter pass 8 x the regions at 1/8 the capacity)
 bool scan_mfma16_dma_wave_regions(int dtype, uint32_t bmq, bool direct, bool has_regions, uint32_t dim) {
-    return dtype != MVF_DTYPE_FLOAT16 && bmq == 256 && !direct && has_regions && dim <= 8192u;  // wider rows: sums beyond 2^27
+    return dtype != MVF_DTYPE_FLOAT16 && bmq >= 128 && !direct && has_regions && dim <= 8192u;  // wider rows: sums beyond 2^27
 }
 
 // p.KPB / p.KT are in 64-byte k-tiles here; p.zeros points at >= 16 zero bytes; p.mtiles = nq_pad / bmq;
@@ -510,7 +518,8 @@ hipError_t launch_scan_mfma16_dma(const Batch16Params& p, int dtype, int metric,
     Batch16Params q = p;
     if (grid.x > kBlkMaxBlocks || (q.wave_regions && grid.x > (uint32_t)num_cus))  // one candidate region per block: small grids only
         q.blk_cand = nullptr, q.blk_cnt = nullptr, q.wave_regions = 0;
-    return bmq == 64 ? launch_bmq<64>(q, dtype, metric, grid, s) : launch_bmq<256>(q, dtype, metric, grid, s);
+    return bmq == 64 ? launch_bmq<64>(q, dtype, metric, grid, s) : bmq == 128 ? launch_bmq<128>(q, dtype, metric, grid, s)
+                                                                                : launch_bmq<256>(q, dtype, metric, grid, s);
 }
 
 }  // namespace mvf

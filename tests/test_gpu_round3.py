@@ -428,3 +428,24 @@ def test_rows_that_are_no_multiple_of_128_bytes_take_the_wide_groups(oracle, dty
     else:
         assert recall_at_k(got.indices, oidx) >= 0.999
         assert np.abs(got.scores - osc).max() <= 1e-5 * max(1.0, float(np.abs(osc).max()))
+
+
+@pytest.mark.parametrize("dtype", [0, 1, 2, 3])
+@pytest.mark.parametrize("metric", [G.L2, G.INNER_PRODUCT, G.COSINE])
+@pytest.mark.parametrize("nq", [65, 128])
+def test_batches_of_65_to_128_queries_take_the_128_query_tile(oracle, dtype, metric, nq):
+    """The 128-query block shape of the LDS-DMA kernel (scan_mfma16_dma.hip, batches of 65..128): default batched path vs
+    the streaming kernel on the same handle -- integers bit-exact, floats within the tolerance; no repairs."""
+    n, dim, k = 200_000, 200, 40
+    rows = oracle.synth_rows(SEED, 0, n, dim, dtype)
+    q = oracle.synth_queries(SEED + 5, nq, dim, dtype)
+    with G.GpuCorpus.from_array(rows) as c:
+        got = c.search(q, k, metric)
+        assert c.last_timing().repaired_queries == 0
+        c.set_scan_path(1)
+        want = c.search(q, k, metric)
+    if dtype in (2, 3):
+        assert_exact(got, want.scores, want.indices, want.raw)
+    else:
+        assert recall_at_k(got.indices, want.indices) >= 0.999
+        assert np.abs(got.scores - want.scores).max() <= 1e-5 * max(1.0, float(np.abs(want.scores).max()))
