@@ -449,3 +449,19 @@ def test_batches_of_65_to_128_queries_take_the_128_query_tile(oracle, dtype, met
     else:
         assert recall_at_k(got.indices, want.indices) >= 0.999
         assert np.abs(got.scores - want.scores).max() <= 1e-5 * max(1.0, float(np.abs(want.scores).max()))
+
+
+@pytest.mark.parametrize("metric", [G.INNER_PRODUCT, G.L2, G.COSINE])
+def test_two_to_four_queries_on_a_large_int8_corpus_take_the_batched_path_and_stay_exact(metric):
+    """Int8 corpora of 4 GiB and more send 2..4 queries through the streaming MFMA kernel instead of K1's four-query pass:
+    bit-identical to the streaming kernel's answer on the same handle."""
+    n, dim, k = 6_000_000, 768, 100  # 4.6 GB
+    import torch
+    dq = torch.empty((3, dim), dtype=torch.int8, device="cuda:0")
+    _lib.gpu_check(_lib.gpu().mvfgpu_synth_queries_device(dq.data_ptr(), 3, dim, 2, SEED + 9, 0, None))
+    q = dq.cpu().numpy()
+    with G.GpuCorpus.synthetic(n, dim, 2, SEED) as c:
+        got = c.search(q, k, metric)
+        c.set_scan_path(1)
+        want = c.search(q, k, metric)
+    assert_exact(got, want.scores, want.indices, want.raw)
