@@ -63,7 +63,7 @@ template <int BMQ_> struct CfT {
     static constexpr int WQ = BMQ == 256 ? 128 : 64;            // a wave's share of the tile: queries ...
     static constexpr int WR = 64;                               // ... x corpus rows
     static constexpr int WN = BR / WR;                          // waves along the rows (4 or 8); NW / WN along the queries
-    static constexpr int NSTAGE = 4;
+    static constexpr int NSTAGE = 4;                            // (five stages for the 128-query shape: no gain, it is not short of bytes in flight)
     static constexpr int A_B = BMQ * DKB;                       // bytes of A per stage
     static constexpr int STAGE_B = A_B + BR * DKB;              // A then B
     static constexpr int APIECES = BMQ / 16;                    // 1-KB DMA pieces of A per k-tile (16 or 4)

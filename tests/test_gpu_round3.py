@@ -465,3 +465,23 @@ def test_two_to_four_queries_on_a_large_int8_corpus_take_the_batched_path_and_st
         c.set_scan_path(1)
         want = c.search(q, k, metric)
     assert_exact(got, want.scores, want.indices, want.raw)
+
+
+@pytest.mark.parametrize("n", [1, 63, 4095, 4097, 70_001, 262_144, 1_050_001, 4_200_003])
+def test_short_rows_at_every_chunking_regime(n):
+    """64-byte Int8 rows (4 lanes per row, 4096-row chunks) at sizes that walk the host's chunking rules -- fewer rows than a
+    step, one chunk per block with chunks below / above the safe piece, whole rounds of equal chunks, the plain long
+    chunks with a ragged last one -- against numpy on the same bytes, bit-exact (inner product and L2)."""
+    rng = np.random.default_rng(n)
+    rows = rng.integers(-128, 128, (n, 64), dtype=np.int8)
+    q = rng.integers(-128, 128, (1, 64), dtype=np.int8)
+    k = min(n, 50)
+    with G.GpuCorpus.from_array(rows) as c:
+        c.set_scan_path(1)
+        for metric in (G.INNER_PRODUCT, G.L2):
+            got = c.search(q, k, metric)
+            x, y = rows.astype(np.int64), q[0].astype(np.int64)
+            exact = x @ y if metric == G.INNER_PRODUCT else ((x - y) ** 2).sum(axis=1)
+            widx, wsc = _numpy_topk(exact, k, metric == G.INNER_PRODUCT)
+            assert (got.indices[0] == widx).all(), f"n={n} metric={metric}"
+            assert (got.raw[0] == wsc).all()
