@@ -53,17 +53,19 @@ constexpr int DKB = 64;                       // k-tile bytes per row
 //     per corpus byte, so the kernel is HBM-bound: ring of 4 stages x 36 KB, two of them (64 KB of corpus bytes) in
 //     flight, and twice the rows per barrier of the other shape (with 256 rows and 8 MFMAs per wave between barriers
 //     the k-tile iteration was latency-bound at 4.9 TB/s, whatever the ring depth).
-//   BMQ = 128 queries x 256 corpus rows (batches of 65..128): waves 2 x 4, each 64 x 64 outputs; ring of 4 x 24 KB.  With
-//     two 64-query tiles such a batch moved every corpus byte into LDS twice and ran at 2/3 of the HBM rate; padded to
-//     the 256-query tile it did twice the matrix work it needed (50M x 768 int8, 128 queries: 10.0 ms either way).
+//   BMQ = 128 queries x 512 corpus rows (batches of 65..128): waves 1 x 8, each 128 x 64 outputs -- the 256-query shape's
+//     wave tile (32 MFMAs per k-tile and barrier) on half the queries; ring of 3 stages x 40 KB.  With two 64-query tiles
+//     such a batch moved every corpus byte into LDS twice and ran at 2/3 of the HBM rate; padded to the 256-query tile it
+//     did twice the matrix work it needed (50M x 768 int8, 128 queries: 10.0 ms either way).  A first cut with 64 x 64
+//     wave tiles (waves 2 x 4 on 256 rows, 16 MFMAs per barrier) held 1.36 POP/s and 7.6 ms.
 template <int BMQ_> struct CfT {
     static constexpr int NW = 8;
     static constexpr int BMQ = BMQ_;                            // queries (A rows) per block
-    static constexpr int BR = BMQ == 64 ? 512 : 256;            // corpus rows per block tile
-    static constexpr int WQ = BMQ == 256 ? 128 : 64;            // a wave's share of the tile: queries ...
+    static constexpr int BR = BMQ == 256 ? 256 : 512;           // corpus rows per block tile
+    static constexpr int WQ = BMQ == 64 ? 64 : 128;             // a wave's share of the tile: queries ...
     static constexpr int WR = 64;                               // ... x corpus rows
     static constexpr int WN = BR / WR;                          // waves along the rows (4 or 8); NW / WN along the queries
-    static constexpr int NSTAGE = 4;                            // (five stages for the 128-query shape: no gain, it is not short of bytes in flight)
+    static constexpr int NSTAGE = BMQ == 128 ? 3 : 4;           // 128 queries: 40-KB stages, one k-tile (32 KB of corpus bytes) in flight across the barrier
     static constexpr int A_B = BMQ * DKB;                       // bytes of A per stage
     static constexpr int STAGE_B = A_B + BR * DKB;              // A then B
     static constexpr int APIECES = BMQ / 16;                    // 1-KB DMA pieces of A per k-tile (16 or 4)
@@ -77,7 +79,7 @@ template <int BMQ_> struct CfT {
     // ordinary global load in the epilogue waits a full HBM round trip with the matrix pipe idle AND drains the ring
     // (s_waitcnt vmcnt(0)): that was 20 % of the int8-selection scan.  The 64-query shape has no LDS left
     // for them (4 x 36 KB of ring) and keeps the loads.
-    static constexpr bool RC_LDS = BR == 256;
+    static constexpr bool RC_LDS = BMQ != 64;
     static constexpr int NRC = 8;                               // >= NSTAGE + 1 (one k-tile per tile) with room for waves that lag inside the epilogue
     static constexpr size_t LDS = (size_t)NSTAGE * STAGE_B + 4 * BMQ * 4 + (RC_LDS ? NRC * 2 * BR * 4 + 2 * BMQ * 4 : 0) + 16;  // ring + qaux0 + tau + qaux1 + prefilter [+ row constants + the L2 bounds' per-query pair] + candidate counter
 };
@@ -160,14 +162,17 @@ __global__ void __launch_bounds__(512, 2) scan_mfma16_dma_kernel(Batch16Params p
             const uint32_t r = r0 + ((uint32_t)wave * Cf::BPW + j) * 16u + rl;
             b_src[j] = p.rows + (size_t)(r < p.row_end ? r : r0) * p.pitch;
         }
-        if constexpr (Cf::RC_LDS) {  // BR = 256: one 1-KB piece per array (entries r0 .. r0 + 255; beyond row_end: unused)
+        if constexpr (Cf::RC_LDS) {  // BR / 256 1-KB pieces per array (entries r0 .. r0 + BR - 1; beyond row_end: unused)
             auto rc_tile = [&](uint32_t m) __attribute__((always_inline)) {
+                constexpr int RCP = Cf::BR / 256;  // waves [0, RCP) bring array 0, waves [RCP, 2 RCP) array 1
                 uint32_t mnt, mmt;
                 slot_tile(m, mnt, mmt);
                 uint32_t* dst = rc_s + (m & (Cf::NRC - 1)) * 2 * Cf::BR;
-                const uint32_t e = min(p.row_begin + mnt * Cf::BR + 4u * (uint32_t)lane, (p.row_end - 1u) & ~3u);
-                if (NEED0 && wave == 0) __builtin_amdgcn_global_load_lds((glb_ptr_t)(arr0 + e), (lds_ptr_t)dst, 16, 0, 0);
-                if (NEED1 && wave == 1) __builtin_amdgcn_global_load_lds((glb_ptr_t)(arr1 + e), (lds_ptr_t)(dst + Cf::BR), 16, 0, 0);
+                const uint32_t part = (uint32_t)(wave % RCP) * 256u;
+                const uint32_t e = min(p.row_begin + mnt * Cf::BR + part + 4u * (uint32_t)lane, (p.row_end - 1u) & ~3u);
+                if (NEED0 && wave < RCP) __builtin_amdgcn_global_load_lds((glb_ptr_t)(arr0 + e), (lds_ptr_t)(dst + part), 16, 0, 0);
+                if (NEED1 && wave >= RCP && wave < 2 * RCP)
+                    __builtin_amdgcn_global_load_lds((glb_ptr_t)(arr1 + e), (lds_ptr_t)(dst + Cf::BR + part), 16, 0, 0);
             };
             if constexpr (BIAS) {  // one tile AHEAD: the next tile's bounds are computed while this one is multiplied
                 if (n == 0) rc_tile(0);
@@ -365,8 +370,9 @@ __global__ void __launch_bounds__(512, 2) scan_mfma16_dma_kernel(Batch16Params p
                     if constexpr (BIAS && FIRST) acc[i][j] = negb[i];  // the MFMA's C operand: no copy is emitted
                     mfma1(acc[i][j], fa[i & 1], fb[j]);
                 }
-                if (NI == 8 ? (i & 1) == 0 : i < Cf::PIECES) dma_piece(ds, NI == 8 ? i / 2 : i);  // 4 pieces over 8 groups, or
-                if (NI == 4 && i == NI - 1 && Cf::PIECES > NI) dma_piece(ds, NI);                    // 3 or 5 pieces over 4 groups
+                if (NI == 8 ? (i & 1) == 0 : true) dma_piece(ds, NI == 8 ? i / 2 : i);          // 4 pieces over 8 groups (a 5th behind group 1), or
+                if (NI == 8 && i == 1 && Cf::PIECES > 4) dma_piece(ds, 4);
+                if (NI == 4 && i == NI - 1 && Cf::PIECES > NI) dma_piece(ds, NI);                    // 5 pieces over 4 groups
                 __builtin_amdgcn_sched_barrier(0);
             }
         };
@@ -497,8 +503,9 @@ uint32_t scan_mfma16_dma_queries_per_block(uint32_t nq) {
     return nq <= 64 ? 64u : nq <= 128 ? 128u : 256u;
 }
 
-uint32_t scan_mfma16_dma_tile_rows(uint32_t bmq) { return bmq == 64 ? CfT<64>::BR : CfT<256>::BR; }  // 128: as 256
-static_assert(CfT<128>::BR == CfT<256>::BR, "tile rows");
+uint32_t scan_mfma16_dma_tile_rows(uint32_t bmq) { return bmq == 256 ? CfT<256>::BR : CfT<64>::BR; }  // 128: as 64
+static_assert(CfT<128>::BR == CfT<64>::BR && CfT<128>::PIECES == 5 && CfT<256>::PIECES == 4 && CfT<64>::PIECES == 5, "tile shapes");
+static_assert(CfT<128>::LDS <= 160 * 1024 && CfT<64>::LDS <= 160 * 1024 && CfT<256>::LDS <= 160 * 1024, "LDS");
 
 // Does a launch with these properties hand RAW records to per-WAVE regions (8 per block, blk_cap / 8 records each, counts
 // in blk_cnt[block * 8 + wave]) instead of keyed records to the block's region?  (the folded pre-filter of the
