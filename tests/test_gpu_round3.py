@@ -384,12 +384,14 @@ def test_short_rows_arriving_best_last_overflow_the_long_pieces_and_stay_exact(c
     widx, wsc = _numpy_topk(exact, k, largest)
     with G.GpuCorpus.from_array(rows) as c:
         c.set_scan_path(1)
-        got = c.search(q, k, metric)
-    assert (got.indices[0] == widx).all()
-    if rows.dtype == np.int8:
-        assert (got.raw[0] == wsc).all()
-    else:
-        assert np.abs(got.scores[0] - wsc).max() == 0.0
+        for nq in (1, 3):  # one query per pass, and the four-query pass (each query has its own guarded buffer)
+            got = c.search(np.repeat(q, nq, axis=0), k, metric)
+            for i in range(nq):
+                assert (got.indices[i] == widx).all(), f"nq={nq} query {i}"
+                if rows.dtype == np.int8:
+                    assert (got.raw[i] == wsc).all()
+                else:
+                    assert np.abs(got.scores[i] - wsc).max() == 0.0
 
 
 @pytest.mark.parametrize("dtype,dim", [(2, 64), (0, 32), (1, 64), (0, 64), (3, 32)])
@@ -400,15 +402,21 @@ def test_short_rows_in_long_pieces_match_the_oracle(oracle, dtype, dim, metric):
     n, k = 2_500_000, 100
     rows = oracle.synth_rows(SEED, 0, n, dim, dtype)
     q = oracle.synth_queries(SEED + 7, 1, dim, dtype)
+    q4 = oracle.synth_queries(SEED + 8, 3, dim, dtype)
     with G.GpuCorpus.from_array(rows) as c:
         c.set_scan_path(1)
         got = c.search(q, k, metric)
+        got4 = c.search(q4, k, metric)  # the four-query pass takes the long pieces too
     osc, oidx, oraw = oracle.search(rows, dtype, metric, q, k)
+    osc4, oidx4, oraw4 = oracle.search(rows, dtype, metric, q4, k)
     if dtype in (2, 3):
         assert_exact(got, osc, oidx, oraw)
+        assert_exact(got4, osc4, oidx4, oraw4)
     else:
         assert recall_at_k(got.indices, oidx) >= 0.999
         assert np.abs(got.scores - osc).max() <= 1e-5 * max(1.0, float(np.abs(osc).max()))
+        assert recall_at_k(got4.indices, oidx4) >= 0.999
+        assert np.abs(got4.scores - osc4).max() <= 1e-5 * max(1.0, float(np.abs(osc4).max()))
 
 
 @pytest.mark.parametrize("dtype,dim", [(0, 100), (0, 200), (0, 300), (2, 300), (1, 200), (2, 32), (3, 24), (1, 9)])
