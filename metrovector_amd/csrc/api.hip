@@ -657,11 +657,14 @@ int repair_flagged_queries(const mvfgpu_corpus* c, uint8_t metric, const void* d
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kfn, 256, lds));
     if (occ < 1) occ = 1;
     // Two blocks per CU at most: the repair is rare, and every block's list costs scratch for EVERY query a launch pair may
-    // serve -- with fewer lists a pair serves up to 256 queries, and a 1024-query search enqueues 4 (empty) pairs
-    // instead of 16 (0.14 ms of launches on a 10-ms search).
+    // serve -- with fewer lists a pair serves more queries (up to 4096 within 256 MiB of lists: 512 at k = 100, all of a
+    // 10,000-query batch in three pairs at k = 10), and a 1024-query search enqueues 2 (empty) pairs instead of 16
+    // (0.14 ms of launches on a 10-ms search; a 10,000-query search on 1M x 128 spent 0.36 of its 5.6 ms in 40 empty pairs
+    // while the cap was 256).
     const uint32_t nblocks = std::min<uint32_t>(nchunks, (uint32_t)std::min(occ, 2) * (uint32_t)c->num_cus);
     const size_t per_query = (size_t)nblocks * kcap * 8;
-    const uint32_t R = (uint32_t)std::min<size_t>(256, std::max<size_t>(4, ((size_t)256 << 20) / per_query));
+    uint32_t R = (uint32_t)std::min<size_t>(4096, std::max<size_t>(4, ((size_t)256 << 20) / per_query));
+    if (const char* e = getenv("MVF_REPAIR_WINDOW")) R = std::min<uint32_t>(R, std::max(4, atoi(e)));  // tests: several windows on small batches
     HIP_TRY(c->repair.reserve((size_t)R * per_query + (size_t)nq * 4 + 16));
     uint64_t* lists = static_cast<uint64_t*>(c->repair.p);
     uint32_t* redo_cnt = reinterpret_cast<uint32_t*>(static_cast<unsigned char*>(c->repair.p) + (size_t)R * per_query);

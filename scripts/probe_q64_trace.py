@@ -10,9 +10,11 @@ if len(sys.argv) > 2 and sys.argv[2] == "cfg4":
     n, dim, dt, metric = 50_000_000, 768, 2, 1
 if len(sys.argv) > 2 and sys.argv[2] == "cfg5":
     n, dim, dt, metric = 12_500_000, 1024, 1, 0
+if len(sys.argv) > 2 and sys.argv[2].startswith("shape:"):  # shape:n,dim,dtype,metric,k
+    n, dim, dt, metric, k = (int(x) for x in sys.argv[2][6:].split(","))
 lib = _lib.gpu()
 c = G.GpuCorpus.synthetic(n, dim, dt, 0x4D564631)
-dq = torch.empty((nq, dim), dtype=torch.int8 if dt >= 2 else torch.float32, device="cuda:0")
+dq = torch.empty((nq, dim), dtype=torch.int8 if dt == 2 else torch.uint8 if dt == 3 else torch.float32, device="cuda:0")
 _lib.gpu_check(lib.mvfgpu_synth_queries_device(dq.data_ptr(), nq, dim, dt, 0x4D564632, 0, None))
 ds = torch.empty((nq, k), dtype=torch.float32, device="cuda:0"); di = torch.empty((nq, k), dtype=torch.int64, device="cuda:0")
 for _ in range(4):

@@ -1,8 +1,8 @@
 #!/bin/bash
-# Kernel trace of a few 1024-query searches (development aid): bash scripts/trace_search.sh <tag> [cfg4|cfg5] -> gpurun_out/<tag>_kernels.txt
+# Kernel trace of a few 1024-query searches (development aid): bash scripts/trace_search.sh <tag> [cfg4|cfg5|shape:n,dim,dtype,metric,k] [queries] -> gpurun_out/<tag>_kernels.txt
 set -o pipefail
 TAG=${1:-trace}; CFG=${2:-}
-NQ=1024; [ "$CFG" = cfg4 ] && NQ=256
+NQ=${3:-1024}; [ "$CFG" = cfg4 ] && [ -z "$3" ] && NQ=256
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
 O=gpurun_out/kt_$TAG
 timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $O -- python3 scripts/probe_q64_trace.py $NQ $CFG > $O.log 2>&1 || { tail -5 $O.log; exit 1; }
