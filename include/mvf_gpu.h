@@ -358,16 +358,20 @@ int mvfgpu_last_timing(const mvfgpu_corpus* corpus, mvfgpu_timing* out);
  * the other types), 4 = as 0, but one or two queries on a Float32 corpus
  * STREAM THE F16 SHADOW instead of the stored rows (half the bytes, so about
  * half the time; same proven-margin selection and exact re-scoring as the
- * batched path, hence the same results; also enabled by
- * MVF_STREAM_SHADOW=1 in the environment).  Off by default: the default
- * single-query path reads the stored f32 rows.
+ * batched path: the same rows as path 1, scores within the 1e-5 tolerance --
+ * the re-scoring kernel sums in another order than the streaming kernel;
+ * also enabled by MVF_STREAM_SHADOW=1 in the environment).  Off by default:
+ * the default single-query path reads the stored rows, whatever the handle
+ * has served before.
  * 5 = K2 selecting on an INT8 SHADOW of a Float32 / Float16 corpus (per-row
  * scale; built on first use, `dimension` bytes per row; also enabled by
  * MVF_I8_SHADOW=1): the int8 MFMA runs at about twice the f16 kernel's rate
  * under the part's power limit; every row whose approximate score is within a
  * PROVEN bound of the k-th best (5-8 x k rows per query on uniform data; the
  * f16 shadow keeps a handful) is re-scored from the stored rows and the f32
- * query, so results are again those of the exact path.  Same as 0 on Int8 /
+ * query, so the rows are again those of the exact path (up to ties within
+ * the tolerance; tests/test_gpu_round3.py compares all 1024 lists of the
+ * benchmark batch).  Same as 0 on Int8 /
  * UInt8 corpora, and for k > 409 (path 6's streaming: k > 204): the margin
  * would not fit the candidate budget, such requests take the f16 shadow / the
  * stored rows.
