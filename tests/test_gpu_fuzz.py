@@ -163,3 +163,41 @@ def test_every_combination_of_the_tuning_switches_returns_the_same_rows(oracle, 
                 assert recall_at_k(got.indices, want.indices) >= 0.999, env
                 assert recall_at_k(got_small.indices, want_small.indices) >= 0.999, env
                 assert np.abs(np.sort(got.scores, axis=1) - np.sort(want.scores, axis=1)).max() <= 2e-5 * max(1.0, float(np.abs(want.scores).max())), env
+
+
+@pytest.mark.parametrize("case", range(12))
+def test_random_short_rows_in_long_pieces(oracle, case):
+    """The streaming kernel's long guarded pieces are only in play from a few million short rows on (smaller corpora get
+    one short chunk per block): random shapes of <= 256-byte rows at 2.2M..5M rows, one to four queries per search,
+    deletions and ids at random, against "filter, then search" on the oracle."""
+    rng = np.random.default_rng(5000 + case)
+    dtype = int(rng.integers(0, 4))
+    metric = int(rng.integers(0, 3))
+    es = {0: 4, 1: 2, 2: 1, 3: 1}[dtype]
+    dim = int(rng.choice([16, 24, 32, 40, 50, 64, 100, 128, 200, 256])) // es
+    dim = max(dim, 4)
+    n = int(rng.integers(2_200_000, 5_000_000))
+    rows = oracle.synth_rows(SEED + 31 * case, 0, n, dim, dtype)
+    dead = (rng.random(n) < rng.choice([0.001, 0.2])) if rng.random() < 0.5 else None
+    ids = rng.permutation(np.arange(7, 7 + n)).astype(np.uint64) if rng.random() < 0.3 else None
+    with G.GpuCorpus.from_array(rows) as c:
+        if dead is not None:
+            c.set_tombstones(np.packbits(dead, bitorder="little"))
+        if ids is not None:
+            c.set_vector_ids(ids)
+        c.set_scan_path(1)
+        live = np.ones(n, bool) if dead is None else ~dead
+        sub, pos = rows[live], np.nonzero(live)[0]
+        for nq, k in ((1, int(rng.choice([1, 10, 100, 1000]))), (int(rng.integers(2, 5)), int(rng.choice([5, 64])))):
+            q = oracle.synth_queries(SEED + 11 * case + nq, nq, dim, dtype)
+            res = c.search(q, k, metric)
+            osc, oidx, oraw = oracle.search(sub, dtype, metric, q, k)
+            p = pos[oidx.astype(np.int64)]
+            want = ids[p] if ids is not None else p.astype(np.uint64)
+            tag = f"case {case}: dtype {dtype} metric {metric} n {n} dim {dim} nq {nq} k {k}"
+            if dtype >= 2:
+                assert (res.indices == want).all(), tag
+                assert (res.raw == oraw).all(), tag
+            else:
+                assert recall_at_k(res.indices, want) >= 0.99, tag
+                assert np.abs(res.scores - osc).max() <= 1e-5 * max(1.0, float(np.abs(osc).max())), tag
