@@ -345,9 +345,17 @@ __global__ void __launch_bounds__(512, 2) scan_mfma16_dma_kernel(Batch16Params p
             }
         }
     };
+#ifdef MVF_DIAG_NOBIAS  // diagnostic build only (with MVF_DIAG_NOEPI): the tile's bounds are not computed, the sums start from zero
+#define MVF_BIAS_ALL(n)                                         \
+    do {                                                        \
+        for (int i_ = 0; i_ < NI; i_++) negb[i_] = AccT{0, 0, 0, 0}; \
+    } while (0)
+#else
+#define MVF_BIAS_ALL(n) bias_all(n)
+#endif
     if constexpr (BIAS) {
         query_prep();
-        bias_all(0);
+        MVF_BIAS_ALL(0);
     }
 
     uint32_t cs = 0, ds = NSTAGE - 1;  // compute stage (k-tile g), DMA target (k-tile g + NSTAGE - 1: the stage g - 1 read)
@@ -404,7 +412,7 @@ __global__ void __launch_bounds__(512, 2) scan_mfma16_dma_kernel(Batch16Params p
                         __syncthreads();
                         query_prep();
                     }
-                    bias_all(c_n);
+                    MVF_BIAS_ALL(c_n);
                 }
             } else {
 #ifdef MVF_DIAG_NOEPI  // diagnostic build only: the k-loop alone (the sums are kept alive, nothing is selected)

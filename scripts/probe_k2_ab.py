@@ -21,6 +21,9 @@ CFGS = {
     "cfg3": (10_000_000, 768, 0, 2, 1024),    # f32 cosine (f16 shadow), 1024 queries
     "cfg5c": (12_500_000, 1024, 1, 2, 1024),  # f16 cosine
     "u8": (20_000_000, 768, 3, 0, 256),       # uint8 L2
+    "d128": (15_000_000, 128, 0, 2, 4096),    # short rows: f32 cosine through the int8 shadow, 2 k-tiles per row
+    "d64": (30_000_000, 64, 0, 2, 4096),      # 1 k-tile per row
+    "d768": (2_500_000, 768, 0, 2, 4096),     # the same number of elements at 12 k-tiles per row
     "cfg5z": (12_500_000, 1024, 1, 0, 1024),  # cfg5 with all-but-one-element-zero rows (clock / power diagnostic)
     "cfg4z": (50_000_000, 768, 2, 1, 256),
     "cfg5b": (12_500_000, 1024, 1, 0, 1024),  # bf16-compatible f16 bit patterns (MVF_DIAG_BF16 builds)
