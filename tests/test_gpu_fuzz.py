@@ -2,6 +2,8 @@
 and index bases against the oracle ("filter, then search" on the CPU).  Each case is small; the point is the combinations
 no hand-written case names -- batch sizes that are not a multiple of any tile, k next to the live row count, a scan path
 forced on a shape it was not tuned for, several searches on one handle in a row (state carried between calls)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -11,6 +13,7 @@ from _util import PAD, assert_exact, assert_float_topk, recall_at_k
 
 pytestmark = pytest.mark.gpu
 SEED = 0x4D564631
+OFFSET = int(os.environ.get("MVF_FUZZ_OFFSET", "0"))  # soak runs: other cases than the 300 + 24 + 12 the suite pins
 
 
 def _dims(rng):
@@ -19,7 +22,7 @@ def _dims(rng):
 
 @pytest.mark.parametrize("case", range(300))
 def test_random_case_against_the_oracle(oracle, case):
-    rng = np.random.default_rng(1000 + case)
+    rng = np.random.default_rng(1000 + case + OFFSET)
     dtype = int(rng.integers(0, 4))
     metric = int(rng.integers(0, 3))
     dim = _dims(rng)
@@ -64,7 +67,7 @@ def test_random_case_against_the_oracle(oracle, case):
                 # positions in the live sub-corpus for the tolerance-aware comparison
                 inv = {int(v): i for i, v in enumerate(ids[pos] if ids is not None else pos.astype(np.uint64) + np.uint64(index_base))}
                 rf = sub.astype(np.float32)
-                for qi in sorted(set([0, nq // 2, nq - 1])):
+                for qi in (range(nq) if nq <= 8 else sorted(set([0, nq // 2, nq - 1]))):  # small batches: every query
                     got = res.indices[qi]
                     kk = min(k, len(pos))
                     assert (got[kk:] == PAD).all(), tag
@@ -73,14 +76,16 @@ def test_random_case_against_the_oracle(oracle, case):
                     padded = np.concatenate([local, got[kk:]])
                     assert_float_topk(metric, res.scores[qi], padded, sc, rf, q[qi], k)
                 if dim >= 16:  # tiny dimensions: crowds of scores within the tolerance of each other (checked above)
-                    assert recall_at_k(res.indices, want) >= 0.99, tag
+                    # one boundary tie ranked the other way (legitimate within the tolerance; the check above is the
+                    # criterion) is 2 % of a 5 x 10 answer: allow one such row on small answers
+                    assert recall_at_k(res.indices, want) >= min(0.99, 1.0 - 1.5 / (nq * min(k, len(pos)))), tag
 
 
 @pytest.mark.parametrize("case", range(24))
 def test_random_shard_splits_merge_to_the_unsharded_answer(oracle, case):
     """Row-range shards (random cut points, empty-ish and one-row shards included), per-shard deletions and ids, through
     the single-process shard set: the merged top-k equals the unsharded corpus' (ties by global position)."""
-    rng = np.random.default_rng(5000 + case)
+    rng = np.random.default_rng(5000 + case + OFFSET)
     dtype = int(rng.integers(0, 4))
     metric = int(rng.integers(0, 3))
     dim = int(rng.choice([8, 33, 64, 200]))
@@ -170,7 +175,7 @@ def test_random_short_rows_in_long_pieces(oracle, case):
     """The streaming kernel's long guarded pieces are only in play from a few million short rows on (smaller corpora get
     one short chunk per block): random shapes of <= 256-byte rows at 2.2M..5M rows, one to four queries per search,
     deletions and ids at random, against "filter, then search" on the oracle."""
-    rng = np.random.default_rng(5000 + case)
+    rng = np.random.default_rng(5000 + case + OFFSET)
     dtype = int(rng.integers(0, 4))
     metric = int(rng.integers(0, 3))
     es = {0: 4, 1: 2, 2: 1, 3: 1}[dtype]
