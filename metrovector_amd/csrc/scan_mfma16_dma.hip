@@ -455,6 +455,8 @@ __global__ void __launch_bounds__(512, 2) scan_mfma16_dma_kernel(Batch16Params p
     }
 }
 
+#undef MVF_BIAS_ALL
+
 template <int DT, int METRIC, int BMQ>
 hipError_t launch_dtm(const Batch16Params& p, dim3 grid, hipStream_t s) {
     constexpr bool XSOK = DT == MVF_DTYPE_FLOAT16 || DT == MVF_DTYPE_INT8;  // rows may be a scaled shadow (f16, or the int8 shadow)
