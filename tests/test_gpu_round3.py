@@ -493,3 +493,21 @@ def test_short_rows_at_every_chunking_regime(n):
             widx, wsc = _numpy_topk(exact, k, metric == G.INNER_PRODUCT)
             assert (got.indices[0] == widx).all(), f"n={n} metric={metric}"
             assert (got.raw[0] == wsc).all()
+
+
+def test_repairs_on_a_large_corpus_of_short_rows_use_the_long_pieces(oracle, monkeypatch):
+    """Tiny candidate regions send nearly every query of a batch to the repair pass -- the streaming kernel's four-query
+    REDO variant, which on 3M rows of 64 bytes runs in long guarded pieces: the repaired answers equal the one-query
+    streaming kernel's, bit for bit."""
+    n, dim, nq, k = 3_000_000, 64, 300, 20
+    rows = oracle.synth_rows(SEED, 0, n, dim, 2)
+    q = oracle.synth_queries(SEED + 1, nq, dim, 2)
+    monkeypatch.setenv("MVF_K2_REGION_RECORDS", "4096")
+    with G.GpuCorpus.from_array(rows) as c:
+        got = c.search(q, k, G.INNER_PRODUCT)
+        repaired = c.last_timing().repaired_queries
+        c.set_scan_path(1)
+        want = [c.search(q[i:i + 1], k, G.INNER_PRODUCT) for i in range(0, nq, 37)]
+    assert repaired > nq // 2, f"only {repaired} of {nq} queries overflowed: the regions were not small"
+    for j, i in enumerate(range(0, nq, 37)):
+        assert (got.indices[i] == want[j].indices[0]).all() and (got.raw[i] == want[j].raw[0]).all(), f"query {i}"
