@@ -1232,7 +1232,7 @@ bool use_batched_path(const mvfgpu_corpus* c, uint8_t metric, uint32_t nq) {
     // launches.  Measured crossovers (scripts/probe_small_corpora.py, profiles/r02_small_corpora_crossover.txt): Float32 /
     // Float16 rows with a shadow from 2 queries up at every size measured (1M x 768 f32, 16 queries: 0.25 ms against K1's
     // 2.4 -- until round 2 corpora under 1 GiB kept K1 up to 31 queries), Int8 / UInt8 rows from 5 (from 2 on 2 GiB and more,
-    // 512 MiB when the rows are <= 256 B: the four-query pass of K1 holds 4.3-5.3 TB/s on 768-B rows and ~2 TB/s on
+    // 1 GiB when the rows are <= 256 B: the four-query pass of K1 holds 4.3-5.3 TB/s on 768-B rows and ~3 TB/s on
     // short ones, the streaming MFMA kernel 6.2 behind ~0.13 ms of fixed cost -- 50M x 768, 2 queries: 7.3 -> 6.2 ms), Float32 rows without
     // a shadow (exact f32 MFMA kernel, 128-query tiles) from 9 on >= 1 GiB and from 32 below.  Corpora under 16 MiB keep K1
     // until the batch is MFMA-sized: their searches take tens of microseconds either way, and the batched path's scratch
@@ -1243,7 +1243,7 @@ bool use_batched_path(const mvfgpu_corpus* c, uint8_t metric, uint32_t nq) {
                            (size_t)((c->dim + 7u) & ~7u) * 4 + kBatchCap * 4 <= 64 * 1024);
     const uint32_t threshold = bytes < (16ull << 20)                          ? 32u
                                : c->dtype == MVF_DTYPE_FLOAT32 && !shadowed ? (bytes < (1ull << 30) ? 32u : 9u)
-                               : is_int_dtype(c->dtype)                     ? (bytes < ((c->pitch <= 256u ? 1ull : 4ull) << 29) ? 5u : 2u)
+                               : is_int_dtype(c->dtype)                     ? (bytes < ((c->pitch <= 256u ? 2ull : 4ull) << 29) ? 5u : 2u)
                                                                             : 2u;
     return nq >= threshold;
 }
