@@ -264,6 +264,17 @@ __global__ void __launch_bounds__(512, 2) scan_mfma16_dma_kernel(Batch16Params p
     [[maybe_unused]] uint32_t wcnt = 0;
     constexpr bool L2Q = QSF && METRIC == MVF_METRIC_L2;
     auto rc_of = [&](uint32_t n) __attribute__((always_inline)) { return rc_s + (n & (Cf::NRC - 1)) * 2 * Cf::BR; };
+    // int8 shadow: the rows' factors 1 / m_j replace the shadow scales in tile n's LDS copy, once per row (scan_mfma16_bias.inc:
+    // lane_rows16's PRE form).  Called for a tile whose constants have landed and that no wave reads yet (see the call sites).
+    constexpr bool RC_PRE = BIAS && QSF;
+    auto rc_transform = [&](uint32_t n) __attribute__((always_inline)) {
+        if constexpr (RC_PRE) {
+            if (n < my_tiles) {
+                uint32_t* rc = rc_of(n);
+                for (int r = tid; r < Cf::BR; r += NW * 64) rc[Cf::BR + r] = row_factor_inv16<METRIC>(rc[r], rc[Cf::BR + r]);
+            }
+        }
+    };
     auto read_thr = [&](int i, u32x4& th4, u32x4& sc4, bool transformed) __attribute__((always_inline)) {
         const int ql = wm * WQ + 4 * (lane / SH) + i * SH;
         th4 = *reinterpret_cast<const u32x4*>((L2Q && transformed ? thu_s : thr_s) + ql);
@@ -318,7 +329,7 @@ __global__ void __launch_bounds__(512, 2) scan_mfma16_dma_kernel(Batch16Params p
         slot_tile(n, nt, mt);
         const uint32_t* rc = rc_of(n);
         LaneRows L;
-        lane_rows16<DT, METRIC, XS, SH, WR, Cf::BR, true, true>(p, nt, wn, lane, rc, rc + Cf::BR, umin, thumin, L, br_cur);
+        lane_rows16<DT, METRIC, XS, SH, WR, Cf::BR, true, true, RC_PRE>(p, nt, wn, lane, rc, rc + Cf::BR, umin, thumin, L, br_cur);
         bool ok = thr_ok;
         float kmul = 0.f, xlo_adj = 0.f;
         if constexpr (QSF || METRIC == MVF_METRIC_COSINE) {
@@ -354,6 +365,11 @@ __global__ void __launch_bounds__(512, 2) scan_mfma16_dma_kernel(Batch16Params p
 #define MVF_BIAS_ALL(n) bias_all(n)
 #endif
     if constexpr (BIAS) {
+        if constexpr (RC_PRE) {  // tile 0 (and 1, see below): their constants were requested in front of k-tile 0, which has landed
+            rc_transform(0);
+            if (p.KT == 1) rc_transform(1);
+            __syncthreads();
+        }
         query_prep();
         MVF_BIAS_ALL(0);
     }
@@ -384,8 +400,17 @@ __global__ void __launch_bounds__(512, 2) scan_mfma16_dma_kernel(Batch16Params p
                 __builtin_amdgcn_sched_barrier(0);
             }
         };
-        if (BIAS && c_kt == 0) ktile(std::true_type{});
-        else ktile(std::false_type{});
+        if (BIAS && c_kt == 0) {
+            // The NEXT tile's row constants: requested (set_dma_tile) in front of this tile's first k-tile, which the last wait
+            // has seen land -- the constants are older -- and read at this tile's end, at least one barrier from here when a
+            // tile has two k-tiles or more.  With ONE k-tile per tile the tile after the next is taken instead: the DMA cursor
+            // runs NSTAGE - 1 tiles ahead then, its constants were requested behind the pieces of tile c_n + 1 at the latest,
+            // and those are older than everything the last wait left in flight.
+            rc_transform(c_n + (p.KT == 1 ? 2u : 1u));
+            ktile(std::true_type{});
+        } else {
+            ktile(std::false_type{});
+        }
         dma_advance();
         cs = cs + 1 == NSTAGE ? 0 : cs + 1;
         ds = ds + 1 == NSTAGE ? 0 : ds + 1;
