@@ -6,8 +6,8 @@ race; it shows up as rare run-to-run differences.  For each config: N searches m
 import hashlib, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
-from oracle import mvf_oracle as O
-from metrovector_amd import gpu as G
+import torch
+from metrovector_amd import _lib, gpu as G
 
 REPS = int(sys.argv[1]) if len(sys.argv) > 1 else 25
 CONFIGS = [  # rows, dim, dtype, metric, nq
@@ -25,11 +25,22 @@ CONFIGS = [  # rows, dim, dtype, metric, nq
     (8_000_000, 512, 2, 0, 100),       # int8 L2, two 64-query tiles
     (5_000_000, 768, 3, 1, 33),        # uint8 dot
     (10_000_000, 768, 0, 2, 16),       # f32 cosine through the shadow
+    # round 3
+    (8_000_000, 512, 2, 0, 128),       # the 128-query tile: int8 L2, a full tile
+    (6_000_000, 384, 1, 2, 65),        # f16 cosine, one query past the 64-query tile
+    (10_000_000, 768, 0, 2, 100),      # f32 cosine through the int8 shadow on the 128-query tile
+    (15_000_000, 64, 0, 2, 300),       # one k-tile per tile (the row constants' transform runs two tiles ahead)
+    (10_000_000, 128, 3, 0, 1000),     # SIFT-shaped: uint8 L2, two k-tiles per tile
+    (5_000_000, 64, 2, 1, 1),          # the streaming kernel's long guarded pieces: 64-byte rows, one query
+    (4_000_000, 100, 0, 2, 1),         # 400-byte rows on 32-lane groups
+    (5_000_000, 32, 0, 0, 3),          # the four-query pass on 8-lane groups (reduce-scatter), long pieces
 ]
 if len(sys.argv) > 2 and sys.argv[2] == "extra":
     CONFIGS = CONFIGS[5:]
 if len(sys.argv) > 2 and sys.argv[2] == "tile64":
-    CONFIGS = CONFIGS[10:]
+    CONFIGS = CONFIGS[10:14]
+if len(sys.argv) > 2 and sys.argv[2] == "round3":
+    CONFIGS = CONFIGS[:3] + CONFIGS[14:]
 def digest(r):
     h = hashlib.sha256()
     for a in (r.scores, r.indices, r.raw):
@@ -38,7 +49,9 @@ def digest(r):
 bad = 0
 for (n, dim, dt, metric, nq) in CONFIGS:
     c = G.GpuCorpus.synthetic(n, dim, dt, 0x4D564631)
-    q = O.synth_queries(0x4D564632, nq, dim, dt)
+    dq = torch.empty((nq, dim), dtype={0: torch.float32, 1: torch.float32, 2: torch.int8, 3: torch.uint8}[dt], device="cuda:0")
+    _lib.gpu_check(_lib.gpu().mvfgpu_synth_queries_device(dq.data_ptr(), nq, dim, dt, 0x4D564632, 0, None))
+    q = dq.cpu().numpy()
     t0 = time.time()
     ds = set()
     for i in range(REPS):
