@@ -6,7 +6,7 @@ scan path 2 (exact f32 MFMA); (b) 200 single queries, scan path 4 (K1 on the sha
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
-from oracle import mvf_oracle as O
+import _synth as O  # the library's own generator (scripts/_synth.py)
 from metrovector_amd import gpu as G
 c = G.GpuCorpus.synthetic(10_000_000, 768, 0, 0x4D564631)
 q = O.synth_queries(0x4D564632, 1024, 768, 0)

@@ -2,7 +2,7 @@
 import sys, time, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
-from oracle import mvf_oracle as O
+import _synth as O  # the library's own generator (scripts/_synth.py)
 from metrovector_amd import gpu as G
 for (n, dim, dt, metric, nq) in ((50_000_000, 768, 2, 1, 256), (12_500_000, 1024, 1, 2, 1024), (12_500_000, 1024, 1, 0, 1024)):
     c = G.GpuCorpus.synthetic(n, dim, dt, 0x4D564631)

@@ -4,7 +4,7 @@ on every (query, row) pair, and reports delta / sigma of the score distribution 
 of the k-th best (vs the looser l1 form 0.5|x8|_1 + 0.5|q8|_1 + d/4).  usage: python scripts/model_int8_bound.py [dim]"""
 import numpy as np, sys
 sys.path.insert(0,'/root/repo')
-from oracle import mvf_oracle as O
+import _synth as O  # the library's own generator (scripts/_synth.py)
 n, dim, nq, k = 400_000, int(sys.argv[1]) if len(sys.argv)>1 else 768, 16, 100
 rows = O.synth_rows(0x4D564631, 0, n, dim, 0).astype(np.float64)
 q = O.synth_queries(0x4D564632, nq, dim, 0).astype(np.float64)

@@ -2,7 +2,7 @@
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
-from oracle import mvf_oracle as O
+import _synth as O  # the library's own generator (scripts/_synth.py)
 from metrovector_amd import gpu as G
 os.environ["MVF_DEBUG_REPAIR"] = "1"
 for n, dim, nq in ((20011, 96, 300), (300_000, 96, 300), (3_000_000, 768, 256)):

@@ -1,7 +1,7 @@
 """Two batched searches of cfg3 (10M x 768 f32 cosine, 1024 queries) for profiling (development aid)."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from oracle import mvf_oracle as O
+import _synth as O  # the library's own generator (scripts/_synth.py)
 from metrovector_amd import gpu as G
 path = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 nq = int(sys.argv[2]) if len(sys.argv) > 2 else 1024

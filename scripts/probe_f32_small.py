@@ -1,7 +1,7 @@
 """f32 K2 at small batch sizes: wall vs last-phase kernel time (development aid)."""
 import sys, time, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from oracle import mvf_oracle as O
+import _synth as O  # the library's own generator (scripts/_synth.py)
 from metrovector_amd import gpu as G
 c = G.GpuCorpus.synthetic(10_000_000, 768, 0, 0x4D564631)
 path = int(sys.argv[1]) if len(sys.argv) > 1 else 2

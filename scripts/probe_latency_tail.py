@@ -2,7 +2,7 @@
 import sys, time, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
-from oracle import mvf_oracle as O
+import _synth as O  # the library's own generator (scripts/_synth.py)
 from metrovector_amd import gpu as G
 c = G.GpuCorpus.synthetic(10_000_000, 768, 0, 0x4D564631)
 for nq, reps in ((1, 300), (16, 300), (256, 300), (1024, 100)):

@@ -1,7 +1,7 @@
 """Single-query latency on cfg2 (10M x 768 f32): K1 on the stored rows vs K1 on the f16 shadow, scan path 4 (development aid)."""
 import sys, time, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from oracle import mvf_oracle as O
+import _synth as O  # the library's own generator (scripts/_synth.py)
 from metrovector_amd import gpu as G
 c = G.GpuCorpus.synthetic(10_000_000, 768, 0, 0x4D564631)
 c.set_profiling(True)
