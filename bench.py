@@ -365,9 +365,9 @@ def shardset_leg(args, world):
         "MASTER_PORT", "TORCHELASTIC_RUN_ID", "TORCHELASTIC_RESTART_COUNT", "TORCHELASTIC_MAX_RESTARTS", "OMP_NUM_THREADS")}
     t0 = time.perf_counter()
     try:
-        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240)
     except subprocess.TimeoutExpired:
-        return {"error": "the shard-set child did not finish within 600 s"}
+        return {"error": "the shard-set child did not finish within 240 s"}
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     if r.returncode != 0 or not lines:
         return {"error": f"shard-set child rc={r.returncode}", "stderr_tail": r.stderr[-600:]}
