@@ -21,7 +21,9 @@
 #include <cstdlib>
 #include <algorithm>
 #include <cstring>
+#include <cstdint>
 #include <string>
+#include <thread>
 #include <vector>
 
 namespace {
@@ -88,20 +90,97 @@ uint16_t f32_to_f16(float f) {
 }
 
 // ----------------------------------------------------------------- crc32 ----
-uint32_t crc32_ieee(const uint8_t* p, uint64_t n) {
-    static uint32_t table[256];
-    static bool init = false;
-    if (!init) {
+// crc32fast::hash (src/builder.rs:251) == CRC-32/ISO-HDLC (poly 0xEDB88320, reflected, init / xorout 0xFFFFFFFF).
+// Slicing-by-8 on one core; blocks of 8 MiB and more are cut into one segment per host thread and the segment CRCs
+// are joined with the GF(2) "append len zero bytes" operator (crc(A|B) = shift(crc(A), |B|) ^ crc(B)): a multi-GB
+// vector block is checked at memory speed beside its upload instead of at 0.4 GB/s.
+struct CrcTables {
+    uint32_t t[8][256];
+    CrcTables() {
         for (uint32_t i = 0; i < 256; i++) {
             uint32_t c = i;
             for (int k = 0; k < 8; k++) c = (c & 1) ? 0xEDB88320u ^ (c >> 1) : c >> 1;
-            table[i] = c;
+            t[0][i] = c;
         }
-        init = true;
+        for (uint32_t i = 0; i < 256; i++)
+            for (int k = 1; k < 8; k++) t[k][i] = t[0][t[k - 1][i] & 0xFF] ^ (t[k - 1][i] >> 8);
     }
-    uint32_t c = 0xFFFFFFFFu;
-    for (uint64_t i = 0; i < n; i++) c = table[(c ^ p[i]) & 0xFF] ^ (c >> 8);
-    return c ^ 0xFFFFFFFFu;
+};
+const CrcTables g_crc;  // built at load time: no lazy-init race between the upload and the checksum thread
+
+// raw register update (no init / final xor), so that segments can be chained
+uint32_t crc32_update(uint32_t c, const uint8_t* p, uint64_t n) {
+    const auto& t = g_crc.t;
+    while (n && (reinterpret_cast<uintptr_t>(p) & 7)) {
+        c = t[0][(c ^ *p++) & 0xFF] ^ (c >> 8);
+        n--;
+    }
+    while (n >= 8) {
+        uint64_t w;
+        std::memcpy(&w, p, 8);
+        const uint32_t lo = (uint32_t)w ^ c, hi = (uint32_t)(w >> 32);
+        c = t[7][lo & 0xFF] ^ t[6][(lo >> 8) & 0xFF] ^ t[5][(lo >> 16) & 0xFF] ^ t[4][lo >> 24] ^
+            t[3][hi & 0xFF] ^ t[2][(hi >> 8) & 0xFF] ^ t[1][(hi >> 16) & 0xFF] ^ t[0][hi >> 24];
+        p += 8;
+        n -= 8;
+    }
+    while (n--) c = t[0][(c ^ *p++) & 0xFF] ^ (c >> 8);
+    return c;
+}
+
+uint32_t gf2_times(const uint32_t* mat, uint32_t vec) {
+    uint32_t sum = 0;
+    for (; vec; vec >>= 1, mat++)
+        if (vec & 1) sum ^= *mat;
+    return sum;
+}
+
+void gf2_square(uint32_t* sq, const uint32_t* mat) {
+    for (int n = 0; n < 32; n++) sq[n] = gf2_times(mat, mat[n]);
+}
+
+// CRC of A|B from the finished CRCs of A and B and |B| (the construction zlib's crc32_combine uses: the operator that
+// advances the register over one zero BIT, squared up to |B| zero bytes)
+uint32_t crc32_join(uint32_t crc_a, uint32_t crc_b, uint64_t len_b) {
+    if (len_b == 0) return crc_a;
+    uint32_t even[32], odd[32];
+    odd[0] = 0xEDB88320u;
+    for (int n = 1; n < 32; n++) odd[n] = 1u << (n - 1);
+    gf2_square(even, odd);  // two zero bits
+    gf2_square(odd, even);  // four zero bits
+    do {
+        gf2_square(even, odd);  // first pass: one zero byte
+        if (len_b & 1) crc_a = gf2_times(even, crc_a);
+        len_b >>= 1;
+        if (!len_b) break;
+        gf2_square(odd, even);
+        if (len_b & 1) crc_a = gf2_times(odd, crc_a);
+        len_b >>= 1;
+    } while (len_b);
+    return crc_a ^ crc_b;
+}
+
+uint32_t crc32_ieee(const uint8_t* p, uint64_t n) {
+    unsigned threads = 1;
+    if (n >= ((uint64_t)8 << 20)) {
+        threads = std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+        if (const char* e = std::getenv("MVF_CRC_THREADS")) threads = (unsigned)std::max(1, std::atoi(e));
+    }
+    if (threads <= 1) return crc32_update(0xFFFFFFFFu, p, n) ^ 0xFFFFFFFFu;
+    const uint64_t seg = ((n + threads - 1) / threads + 63) & ~(uint64_t)63;
+    std::vector<uint32_t> part(threads, 0);
+    std::vector<uint64_t> len(threads, 0);
+    std::vector<std::thread> pool;
+    for (unsigned t = 0; t < threads; t++) {
+        const uint64_t o = (uint64_t)t * seg;
+        if (o >= n) break;
+        len[t] = std::min(seg, n - o);
+        pool.emplace_back([&part, &len, p, o, t] { part[t] = crc32_update(0xFFFFFFFFu, p + o, len[t]) ^ 0xFFFFFFFFu; });
+    }
+    for (auto& th : pool) th.join();
+    uint32_t crc = part[0];
+    for (unsigned t = 1; t < threads && len[t]; t++) crc = crc32_join(crc, part[t], len[t]);
+    return crc;
 }
 
 // ------------------------------------------------- FlatBuffers: reading ----
@@ -982,16 +1061,17 @@ int mvf_builder_add_metadata_column(mvf_builder* b, const char* name, uint8_t da
     return MVF_OK;
 }
 
-int mvf_builder_to_bytes(const mvf_builder* b, uint32_t quirks, uint8_t** out, uint64_t* len) {
-    if (!b || !out || !len) return fail(MVF_ERR_INVALID_ARGUMENT, "NULL argument");
-    // build(): one DataBlock per space, then per metadata column (builder.rs:241-285)
-    struct Blk {
-        uint64_t offset, size;
-        uint32_t crc;
-        const std::vector<uint8_t>* bytes;
-    };
-    std::vector<Blk> blks;
-    uint64_t cur = 0;
+struct Blk {
+    uint64_t offset, size;
+    uint32_t crc;
+    const std::vector<uint8_t>* bytes;
+};
+
+// build() + the footer half of to_bytes(): the block layout (one DataBlock per space, then per metadata column,
+// builder.rs:241-285), every block's CRC and the finished FlatBuffers footer (builder.rs:427-547).  `cur` = bytes of
+// the data section.
+static void layout_image(const mvf_builder* b, uint32_t quirks, std::vector<Blk>& blks, uint64_t& cur, std::vector<uint8_t>& footer) {
+    cur = 0;
     std::vector<uint32_t> vec_blk(b->spaces.size(), 0), ids_blk(b->spaces.size(), 0), tomb_blk(b->spaces.size(), 0);
     for (size_t i = 0; i < b->spaces.size(); i++) {
         const auto& s = b->spaces[i];
@@ -1085,8 +1165,16 @@ int mvf_builder_to_bytes(const mvf_builder* b, uint32_t quirks, uint8_t** out, u
     fb.add_scalar<uint16_t>(6, 1, 3);  // compatibility_version: 1 (schema default 3), builder.rs:540
     fb.add_scalar<uint16_t>(0, 1, 3);  // format_version: 1 (schema default 3), builder.rs:531
     uint32_t root = fb.end_table();
-    std::vector<uint8_t> footer = fb.finish_minimal(root);
+    footer = fb.finish_minimal(root);
+}
 
+
+int mvf_builder_to_bytes(const mvf_builder* b, uint32_t quirks, uint8_t** out, uint64_t* len) {
+    if (!b || !out || !len) return fail(MVF_ERR_INVALID_ARGUMENT, "NULL argument");
+    std::vector<Blk> blks;
+    std::vector<uint8_t> footer;
+    uint64_t cur = 0;
+    layout_image(b, quirks, blks, cur, footer);
     // MVF1 | blocks | footer | u32 footer_len | MVF1   (builder.rs:417-557)
     const uint64_t total_len = 4 + cur + footer.size() + 4 + 4;
     uint8_t* img = static_cast<uint8_t*>(std::malloc(total_len));
@@ -1109,23 +1197,39 @@ int mvf_builder_to_bytes(const mvf_builder* b, uint32_t quirks, uint8_t** out, u
     return MVF_OK;
 }
 
+// BuiltMvf::save (builder.rs:408-411 -> MvfWriter, io.rs:29-46).  The reference assembles the whole image in memory
+// (to_bytes) and writes it; here the blocks go to the file as they lie in the builder -- the same bytes without a
+// second copy of a multi-GB vector block.
 int mvf_builder_save(const mvf_builder* b, const char* path, uint32_t quirks) {
-    if (!path) return fail(MVF_ERR_INVALID_ARGUMENT, "NULL argument");
-    uint8_t* img = nullptr;
-    uint64_t len = 0;
-    int rc = mvf_builder_to_bytes(b, quirks, &img, &len);
-    if (rc) return rc;
+    if (!b || !path) return fail(MVF_ERR_INVALID_ARGUMENT, "NULL argument");
+    std::vector<Blk> blks;
+    std::vector<uint8_t> footer;
+    uint64_t cur = 0;
+    layout_image(b, quirks, blks, cur, footer);
     FILE* f = std::fopen(path, "wb");  // MvfWriter::create, io.rs:29-35
-    if (!f) {
-        int e = errno;
-        std::free(img);
-        return fail(MVF_ERR_IO, std::string("I/O error: ") + std::strerror(e));
+    if (!f) return fail(MVF_ERR_IO, std::string("I/O error: ") + std::strerror(errno));
+    bool ok = std::fwrite(kMagic, 1, 4, f) == 4;
+    int e = ok ? 0 : errno;
+    for (size_t i = 0; ok && i < blks.size(); i++) {
+        const uint8_t* p = blks[i].bytes->data();
+        for (uint64_t o = 0; ok && o < blks[i].size;) {  // 1-GiB pieces: a single fwrite of > 2 GiB is not portable
+            const size_t piece = (size_t)std::min<uint64_t>(blks[i].size - o, (uint64_t)1 << 30);
+            ok = std::fwrite(p + o, 1, piece, f) == piece;
+            if (!ok) e = errno;
+            o += piece;
+        }
     }
-    size_t wr = std::fwrite(img, 1, len, f);
-    int e = errno;
-    int cl = std::fclose(f);
-    std::free(img);
-    if (wr != len || cl != 0) return fail(MVF_ERR_IO, std::string("I/O error: ") + std::strerror(e));
+    const uint32_t fl = (uint32_t)footer.size();
+    if (ok) {
+        ok = std::fwrite(footer.data(), 1, footer.size(), f) == footer.size() && std::fwrite(&fl, 1, 4, f) == 4 &&
+             std::fwrite(kMagic, 1, 4, f) == 4;
+        if (!ok) e = errno;
+    }
+    if (std::fclose(f) != 0 && ok) {
+        ok = false;
+        e = errno;
+    }
+    if (!ok) return fail(MVF_ERR_IO, std::string("I/O error: ") + std::strerror(e));
     return MVF_OK;
 }
 

@@ -97,6 +97,16 @@ def lib() -> C.CDLL:
     return _lib
 
 
+def set_threads(n: int) -> int:
+    """Size of the checker's OpenMP team from now on (`omp_set_num_threads` of the libgomp the oracle is linked against).
+    torch.distributed.run exports OMP_NUM_THREADS=1 to its ranks; a rank that checks a whole shard against the oracle
+    asks for its share of the host's cores here.  Returns the size set."""
+    lib()
+    n = max(1, int(n))
+    C.CDLL("libgomp.so.1").omp_set_num_threads(n)
+    return n
+
+
 def _ptr(a: np.ndarray | None):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
 

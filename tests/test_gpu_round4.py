@@ -1,0 +1,147 @@
+"""-m gpu tests added in round 4.
+
+Part 1 — the full-size BASELINE configs anchored to the ORACLE'S top-k over EVERY row of the corpus (not to sampled
+windows): configs[3] (50M x 768 Int8 dot, 256 queries) bit-exact on indices, raw sums and score bits; a configs[4] shard
+(12.5M x 1024 Float16 L2, 1024 queries) and configs[2] (10M x 768 Float32 cosine, 1024 queries; 16 of them, on the three
+selection paths) with the tolerance-aware criterion of tests/_util.py (1e-5; boundary ties at the k-th rank may go either
+way, everything else must be the oracle's list).  Everything goes through the C ABI (libmvf_gpu.so); the oracle is only
+the checker."""
+import numpy as np
+import pytest
+
+from metrovector_amd import gpu as G
+
+from _util import assert_exact, assert_float_topk, oracle_scores_all_rows, oracle_topk_all_rows
+
+pytestmark = pytest.mark.gpu
+SEED = 0x4D564631
+
+
+def test_cfg4_50m_x_768_int8_dot_256_queries_vs_the_oracle_over_all_rows(oracle):
+    """BASELINE.json configs[3].  north_star: "bit-exact for Int8/UInt8 dot".  Four queries against the oracle's top-100
+    over all 50M rows (indices, exact i32 sums, f32 score bits); eight further queries against the streaming kernel K1
+    (another kernel family: v_dot4 lanes + butterfly instead of MFMA tiles + phased candidate lists)."""
+    n, dim, nq, k = 50_000_000, 768, 256, 100
+    q = oracle.synth_queries(SEED + 1, nq, dim, 2)
+    sel = [0, 85, 170, 255]
+    k1 = [1, 31, 64, 99, 128, 191, 222, 254]
+    with G.GpuCorpus.synthetic(n, dim, 2, SEED) as c:
+        res = c.search(q, k, G.INNER_PRODUCT)
+        c.set_scan_path(1)
+        ref = [c.search(q[qi], k, G.INNER_PRODUCT) for qi in k1]
+        c.set_scan_path(0)
+    for qi, r in zip(k1, ref):
+        assert (r.indices[0] == res.indices[qi]).all() and (r.raw[0] == res.raw[qi]).all()
+        assert (r.scores[0].view(np.uint32) == res.scores[qi].view(np.uint32)).all()
+    osc, oidx, oraw = oracle_topk_all_rows(oracle, SEED, 0, n, dim, 2, 1, q[sel], k)
+    assert_exact(G.SearchResult(res.scores[sel], res.indices[sel], res.raw[sel]), osc, oidx, oraw)
+
+
+def test_cfg5_shard_12p5m_x_1024_f16_l2_1024_queries_vs_the_oracle_over_all_rows(oracle):
+    """BASELINE.json configs[4], one GPU's shard (rows [25M, 37.5M) of the 100M-row corpus) at its batch size: four of the
+    1024 queries against the oracle's score of every one of the shard's 12.5M rows."""
+    n, dim, nq, k, row0 = 12_500_000, 1024, 1024, 100, 25_000_000
+    q = oracle.synth_queries(SEED + 1, nq, dim, 1)
+    sel = [0, 341, 700, 1023]
+    with G.GpuCorpus.synthetic(n, dim, 1, SEED, row0=row0) as c:
+        res = c.search(q, k, G.L2)             # default: int8-shadow selection + exact re-scoring
+        c.set_scan_path(3)
+        f16 = c.search(q, k, G.L2)             # the f16 MFMA kernel on the stored rows
+        c.set_scan_path(0)
+    all_sc = oracle_scores_all_rows(oracle, SEED, row0, n, dim, 1, 0, q[sel])
+    for j, qi in enumerate(sel):
+        assert_float_topk(0, res.scores[qi], res.indices[qi], all_sc[j], None, q[qi], k, index_base=row0)
+        assert_float_topk(0, f16.scores[qi], f16.indices[qi], all_sc[j], None, q[qi], k, index_base=row0)
+
+
+def test_cfg3_10m_x_768_f32_cosine_1024_queries_vs_the_oracle_over_all_rows(oracle):
+    """BASELINE.json configs[2]: 16 of the 1024 queries against the oracle's score of every one of the 10M rows, on the
+    default path (int8-shadow selection), scan path 3 (f16-shadow selection) and scan path 2 (exact f32 MFMA)."""
+    n, dim, nq, k = 10_000_000, 768, 1024, 100
+    q = oracle.synth_queries(SEED + 1, nq, dim, 0)
+    sel = [0, 63, 64, 200, 255, 256, 300, 411, 511, 512, 640, 767, 768, 900, 1000, 1023]
+    got = {}
+    with G.GpuCorpus.synthetic(n, dim, 0, SEED) as c:
+        for path in (0, 3, 2):
+            c.set_scan_path(path)
+            got[path] = c.search(q, k, G.COSINE)
+        c.set_scan_path(0)
+        one = c.search(q[sel[5]], k, G.COSINE)  # the headline's kernel (K1 on the stored rows) on one of them
+    all_sc = oracle_scores_all_rows(oracle, SEED, 0, n, dim, 0, 2, q[sel])
+    for j, qi in enumerate(sel):
+        for path, res in got.items():
+            assert_float_topk(2, res.scores[qi], res.indices[qi], all_sc[j], None, q[qi], k)
+    assert_float_topk(2, one.scores[0], one.indices[0], all_sc[5], None, q[sel[5]], k)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Part 2 -- the drop-in on a REAL multi-GB file:
+# MvfReader::open is O(footer) for any size (src/reader.rs:45-79), map_vector_range(0, total) hands the whole space over
+# (src/vectors/vector_space.rs:155-188).  A two-space file whose first block is > 4 GiB, so that the second block lies at
+# an offset beyond 2^32: written by the C++ builder (streamed save), opened, checksum-validated beside the upload,
+# searched single and batched.  The rows are the library generator's, so the answers must equal a
+# GpuCorpus.synthetic search bit for bit.
+# ---------------------------------------------------------------------------------------------------------------------
+
+def _scratch_dir_with(free_bytes, tmp_path):
+    """A directory with room for the file: $MVF_TEST_BIGFILE_DIR, pytest's tmp_path, else /dev/shm."""
+    import os
+    import shutil
+    for d in (os.environ.get("MVF_TEST_BIGFILE_DIR"), str(tmp_path), "/dev/shm"):
+        if d and os.path.isdir(d) and shutil.disk_usage(d).free >= free_bytes:
+            return d
+    pytest.skip(f"no scratch directory with {free_bytes / 2**30:.1f} GiB free for the multi-GB .mvf")
+
+
+def test_multi_gb_mvf_file_open_upload_search(oracle, tmp_path):
+    import os
+    from metrovector_amd.builder import MvfBuilder
+    from metrovector_amd.reader import DataType, DistanceMetric, MvfReader, VectorType
+    from metrovector_amd.search import find_top_k_similar, find_top_k_similar_batch, upload_space
+    n, dim, k = 1_500_000, 768, 100                      # 4 608 000 000 B of Float32 rows > 2^32
+    n8, dim8 = 20_000, 64
+    path = os.path.join(_scratch_dir_with(6 << 30, tmp_path), f"mvf_big_{os.getpid()}.mvf")
+    try:
+        b = MvfBuilder()
+        b.add_vector_space("big", dim, VectorType.Dense, DistanceMetric.Cosine, DataType.Float32)
+        b.add_vector_space("small_i8", dim8, VectorType.Dense, DistanceMetric.InnerProduct, DataType.Int8)
+        for r0 in range(0, n, 250_000):
+            b.add_vectors_raw("big", oracle.synth_rows(SEED, r0, min(250_000, n - r0), dim, 0))
+        rows8 = oracle.synth_rows(SEED + 7, 0, n8, dim8, 2)
+        b.add_vectors_raw("small_i8", rows8)
+        b.build().save(path)
+        del b
+        assert os.path.getsize(path) > (1 << 32)
+        q = oracle.synth_queries(SEED + 1, 64, dim, 0)
+        q8 = oracle.synth_queries(SEED + 8, 5, dim8, 2)
+        with MvfReader.open(path) as r:
+            assert r.file_size() == os.path.getsize(path) and r.num_vector_spaces() == 2
+            blocks = r.blocks()
+            assert blocks[0].size == n * dim * 4 and blocks[1].offset == n * dim * 4 > (1 << 32)
+            big, small = r.vector_space("big"), r.vector_space("small_i8")
+            assert big.total_vectors() == n and small.total_vectors() == n8
+            # R4 addressing beyond 4 GiB: the last Float32 row and an Int8 row behind it, byte for byte
+            assert big.get_vector(n - 1).as_bytes() == oracle.synth_rows(SEED, n - 1, 1, dim, 0).tobytes()
+            assert small.get_vector(n8 - 1).as_bytes() == rows8[n8 - 1].tobytes()
+            with upload_space(big, verify_checksum=True) as c, G.GpuCorpus.synthetic(n, dim, 0, SEED) as ref:
+                assert (c.read_rows(n - 3, 3) == ref.read_rows(n - 3, 3)).all()
+                one = find_top_k_similar(big, q[0], k, corpus=c)
+                want1 = ref.search(q[0], k, G.COSINE)
+                assert [h.index for h in one] == want1.indices[0].tolist()
+                assert np.array([h.score for h in one], np.float32).tobytes() == want1.scores[0].tobytes()
+                assert (one[0].vector == oracle.synth_rows(SEED, one[0].index, 1, dim, 0)[0]).all()
+                many = find_top_k_similar_batch(big, q, k, corpus=c)
+                wantb = ref.search(q, k, G.COSINE)
+                for qi in range(q.shape[0]):
+                    assert [h.index for h in many[qi]] == wantb.indices[qi].tolist()
+                    assert np.array([h.score for h in many[qi]], np.float32).tobytes() == wantb.scores[qi].tobytes()
+                # and against the oracle over ALL rows, two of the queries
+                all_sc = oracle_scores_all_rows(oracle, SEED, 0, n, dim, 0, 2, q[[0, 63]])
+                assert_float_topk(2, want1.scores[0], want1.indices[0], all_sc[0], None, q[0], k)
+                assert_float_topk(2, wantb.scores[63], wantb.indices[63], all_sc[1], None, q[63], k)
+            with upload_space(small, verify_checksum=True) as c8:   # the block at an offset beyond 2^32
+                res8 = c8.search(q8, 10, G.INNER_PRODUCT)
+            assert_exact(res8, *oracle.search(rows8, 2, 1, q8, 10))
+    finally:
+        if os.path.exists(path):
+            os.remove(path)
