@@ -109,6 +109,8 @@ def parse_args():
     ap.add_argument("--no-shardset", action="store_true", help="skip the single-process shard-set leg")
     ap.add_argument("--no-cfg4", action="store_true", help="skip the cfg4_int8 leg (N = 1)")
     ap.add_argument("--no-cfg1", action="store_true", help="skip the cfg1 block (N = 1)")
+    ap.add_argument("--no-file", action="store_true", help="skip the mvf_file_e2e leg (N = 1)")
+    ap.add_argument("--file-rows", type=int, default=1_500_000, help="rows of the 768-dim f32 space of the mvf_file_e2e leg")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-baseline budget per leg")
     ap.add_argument("--shardset-only", action="store_true",
                     help="internal: run ONLY the single-process shard-set leg over --gpus devices and print its JSON")
@@ -232,13 +234,28 @@ def max_over_ranks(x, world, dist, torch, device):
     return float(t.item())
 
 
-def cfg5_sharded_leg(args, rank, local_rank, world, backend, dist, torch, G, ShardedSearcher, _lib):
-    """BASELINE.json configs[4] per rank: 12.5M x 1024 f16 L2, 1024 batched queries, top-100; N = 8 is the 100M-row
-    corpus north_star names.  Returns the leg's dict on rank 0 (None elsewhere)."""
-    rows, dim, dtype, metric, nq, k = 12_500_000, 1024, 1, 0, 1024, args.k
+def cfg5_sharded_leg(args, rank, local_rank, world, backend, dist, torch, G, ShardedSearcher, _lib, total_rows=None):
+    """BASELINE.json configs[4]: 1024 f16 dimensions, L2, 1024 batched queries, top-100, row-range sharded over the ranks.
+    WEAK (total_rows None): every rank holds 12.5M rows, N = 8 is the 100M-row corpus north_star names.
+    STRONG (total_rows given): ONE fixed corpus of total_rows rows split by shard_range over the N ranks -- the
+    reference's serial loop over one corpus (examples/similarity_search.rs:147) sharded by row range; value =
+    nq * total_rows / t at every N, so value(N) / value(1) is the speed-up north_star's ">= 6x at 8 GPUs" asks for.
+    The selection path a shard takes depends on what fits beside it in HBM (the int8 shadow is +50 % of Float16 rows: a
+    204.8 GB shard cannot hold one and selects on the stored f16 rows), so the strong leg ALSO runs with the f16
+    selection forced (scan path 3) at every N: that pair of numbers compares like with like.
+    Returns the leg's dict on rank 0 (None elsewhere)."""
+    from metrovector_amd.sharded import shard_range
+    dim, dtype, metric, nq, k = 1024, 1, 0, 1024, args.k
+    strong = total_rows is not None
+    if strong:
+        lo, hi = shard_range(total_rows, world, rank)
+    else:
+        lo, hi = rank * 12_500_000, (rank + 1) * 12_500_000
+        total_rows = world * 12_500_000
+    rows = hi - lo
     steps, warmup = max(3, args.steps // 5), 2
     dev = f"cuda:{local_rank}"
-    corpus = G.GpuCorpus.synthetic(rows, dim, dtype, SEED, row0=rank * rows, device=local_rank)
+    corpus = G.GpuCorpus.synthetic(rows, dim, dtype, SEED, row0=lo, device=local_rank)
     searcher = ShardedSearcher(corpus)
     dq = torch.empty((nq, dim), dtype=torch.float32, device=dev)
     _lib.gpu_check(_lib.gpu().mvfgpu_synth_queries_device(dq.data_ptr(), nq, dim, dtype, SEED + 1, local_rank, None))
@@ -247,23 +264,38 @@ def cfg5_sharded_leg(args, rank, local_rank, world, backend, dist, torch, G, Sha
     def step():
         return searcher.search(dq, k, metric)
 
-    for _ in range(warmup):
-        step()
-    corpus.set_profiling(True)
-    searcher.timing = True
-    elapsed, out = timed_steps(step, 0, steps, world, dist, torch)
-    tm = corpus.last_timing()
-    corpus.set_profiling(False)
-    scan_ms, exch_ms = searcher.take_timings()
-    searcher.timing = False
-    elapsed = max_over_ranks(elapsed, world, dist, torch, dev if backend == "nccl" else "cpu")
-    per_rank = [(scan_ms, exch_ms, tm.scan_ms_avg, tm.search_ms_avg)]
-    if world > 1:
-        gathered = [None] * world
-        dist.all_gather_object(gathered, per_rank[0])
-        per_rank = gathered
-    # recall@k against the oracle's top-k over ALL rows of the (N x 12.5M)-row corpus, four of the 1024 queries: every rank
-    # runs the oracle over ITS shard on its share of the host's cores, the lists are gathered and merged on rank 0
+    def timed(path):
+        corpus.set_scan_path(path)
+        for _ in range(warmup):
+            step()
+        corpus.set_profiling(True)
+        searcher.timing = True
+        elapsed, out = timed_steps(step, 0, steps, world, dist, torch)
+        tm = corpus.last_timing()
+        corpus.set_profiling(False)
+        scan_ms, exch_ms = searcher.take_timings()
+        searcher.timing = False
+        elapsed = max_over_ranks(elapsed, world, dist, torch, dev if backend == "nccl" else "cpu")
+        mine = (scan_ms, exch_ms, tm.scan_ms_avg, tm.search_ms_avg, int(tm.scan_kernel), rows)
+        per_rank = [mine]
+        if world > 1:
+            per_rank = [None] * world
+            dist.all_gather_object(per_rank, mine)
+        corpus.set_scan_path(0)
+        return elapsed, out, tm, per_rank
+
+    elapsed, out, tm, per_rank = timed(0)
+    forced = None
+    if strong:
+        e3, out3, tm3, pr3 = timed(3)
+        same = bool((out3[1] == out[1]).all().item())
+        forced = {"scan_path": "3 (f16 MFMA selection on the stored rows, forced on every rank)",
+                  "value": float(nq) * total_rows * steps / e3, "unit": "distance-ops/s", "ms_per_step": e3 / steps * 1e3,
+                  "indices_identical_to_default_path": same,
+                  "per_rank": [{"rank": r, "rows": p[5], "local_search_ms": p[0], "exchange_merge_ms": p[1], "scan_kernel": p[4]}
+                               for r, p in enumerate(pr3)]}
+    # recall@k against the oracle's top-k over ALL rows of the corpus, four of the 1024 queries: every rank runs the
+    # oracle over ITS shard on its share of the host's cores, the lists are gathered and merged on rank 0
     recall = None
     if not args.no_recall:
         from oracle import mvf_oracle as oracle
@@ -272,10 +304,10 @@ def cfg5_sharded_leg(args, rank, local_rank, world, backend, dist, torch, G, Sha
         if world > 1:
             dist.barrier()
         threads = oracle.set_threads(max(1, min(16, oracle.cpus_granted()["granted"] // world)))
-        if world == 1 or threads >= 8:
+        if rows <= 12_500_000 and (world == 1 or threads >= 8):
             t1 = time.perf_counter()
             sel = [0, nq // 3, 2 * nq // 3, nq - 1]
-            mine = oracle_topk_rows(oracle, rank * rows, rows, dim, dtype, metric, dq.cpu().numpy()[sel], k)
+            mine = oracle_topk_rows(oracle, lo, rows, dim, dtype, metric, dq.cpu().numpy()[sel], k)
             parts = [mine]
             if world > 1:
                 parts = [None] * world
@@ -287,25 +319,35 @@ def cfg5_sharded_leg(args, rank, local_rank, world, backend, dist, torch, G, Sha
                 gs = out[0].cpu().numpy()[sel]
                 same = gi == oidx
                 recall = {"recall_at_k": recall_of(gi, oidx), "recall_queries_checked": len(sel),
-                          "recall_vs": f"the oracle's exact top-k over ALL {world * rows / 1e6:g}M rows (every rank its shard, "
+                          "recall_vs": f"the oracle's exact top-k over ALL {total_rows / 1e6:g}M rows (every rank its shard, "
                                        f"{threads} threads each, merged on rank 0)",
                           "max_rel_score_diff_on_identical_ranks": float(np.max(np.abs(gs - osc)[same] / np.maximum(osc[same], 1e-30))) if same.any() else None,
                           "recall_oracle_s": time.perf_counter() - t1}
         elif rank == 0:
-            recall = {"recall_at_k": None, "skipped": f"{threads} host threads per rank: the oracle over a 12.5M x 1024 shard would take minutes"}
+            recall = {"recall_at_k": None, "recall_skipped": (
+                f"{rows / 1e6:g}M rows per rank on {threads} host threads: the strict-order oracle over the shard would take minutes "
+                "(the 12.5M-row shards of N = 8 and of the weak leg are checked)")}
     leg = None
     if rank == 0:
         idx = out[1].cpu().numpy().view(np.uint64)
-        leg = {"workload": f"{world} x (12.5M x 1024 f16) rows = {world * rows / 1e6:g}M x 1024 f16 L2, {nq} batched queries, "
-                           f"top-{k}, row-range sharded x{world} (BASELINE.json configs[4]{'' if world == 8 else ': its per-GPU shard at every N'})",
-               "value": float(nq) * rows * world * steps / elapsed, "unit": "distance-ops/s", "n_gpus": world, "steps": steps,
-               "warmup": warmup, "ms_per_step": elapsed / steps * 1e3, "scaling": "weak", "dtype": "f16",
+        what = (f"ONE fixed corpus of {total_rows / 1e6:g}M x 1024 f16 rows split by row range over {world} GPU(s) "
+                f"({rows / 1e6:g}M rows on rank 0)") if strong else \
+               f"{world} x (12.5M x 1024 f16) rows = {total_rows / 1e6:g}M x 1024 f16"
+        leg = {"workload": f"{what}, L2, {nq} batched queries, top-{k}, row-range sharded x{world} "
+                           f"(BASELINE.json configs[4]{'' if world == 8 or strong else ': its per-GPU shard at every N'})",
+               "value": float(nq) * total_rows * steps / elapsed, "unit": "distance-ops/s", "n_gpus": world, "steps": steps,
+               "warmup": warmup, "ms_per_step": elapsed / steps * 1e3, "scaling": "strong" if strong else "weak", "dtype": "f16",
+               "total_rows": total_rows,
                "rccl_ranks": (dist.get_world_size() if world > 1 and backend == "nccl" else 0),
                "process_group_backend": (dist.get_backend() if world > 1 else None),
-               "per_rank": [{"rank": r, "local_search_ms": a, "exchange_merge_ms": b, "last_phase_scan_ms": c_, "search_device_ms": d}
-                            for r, (a, b, c_, d) in enumerate(per_rank)],
-               "result_check": {"indices_in_range": bool(idx.max() < world * rows), "unique_per_query": bool(
+               "selection_path": {3: "f16 MFMA kernel on the stored rows (no room or no use for an int8 shadow)",
+                                  6: "int8 MFMA kernel on the int8 shadow + exact re-scoring"}.get(int(tm.scan_kernel), int(tm.scan_kernel)),
+               "per_rank": [{"rank": r, "rows": p[5], "local_search_ms": p[0], "exchange_merge_ms": p[1], "last_phase_scan_ms": p[2],
+                             "search_device_ms": p[3], "scan_kernel": p[4]} for r, p in enumerate(per_rank)],
+               "result_check": {"indices_in_range": bool(idx.max() < total_rows), "unique_per_query": bool(
                    all(len(set(r.tolist())) == k for r in idx[:8]))}}
+        if forced:
+            leg["f16_selection_at_every_n"] = forced
         if tm.samples and tm.scan_ms_avg > 0 and tm.scan_kernel >= 2:
             leg["roofline"] = mfma_roofline(tm, dtype)
         if recall:
@@ -536,6 +578,133 @@ def cfg1_block(args, torch, G, oracle, local_rank):
                              "what": "mvfgpu_search: query H2D + scan + top-k + results D2H, blocking (latency-bound at this size)"},
             "gpu_device_ms": {"search_ms_avg": tm.search_ms_avg, "scan_kernel_ms_avg": tm.scan_ms_avg, "select_ms_avg": tm.select_ms_avg},
             "gpu_matches_cpu": {"indices_identical": same, "max_rel_score_diff": rel, "tolerance": 1e-5}}
+
+
+def mvf_file_leg(args, G, oracle, local_rank):
+    """The drop-in on a REAL multi-GB file: a two-space .mvf whose first block
+    is > 4 GiB is written by the C++ builder, then MvfReader::open (O(footer), src/reader.rs:45-79) ->
+    map_vector_range(0, total) (src/vectors/vector_space.rs:155-188) -> upload straight off the mmap (page cache cold,
+    then warm) -> find_top_k_similar{,_batch}; CRC32 validation alone and beside the upload.  Rows come from the
+    library's device generator (read back), so the answers must equal a synthetic corpus' bit for bit."""
+    import shutil
+    from metrovector_amd.builder import MvfBuilder
+    from metrovector_amd.reader import MvfReader
+    from metrovector_amd.search import upload_space
+    n, dim, k, n8, dim8 = args.file_rows, 768, 100, 20_000, 64
+    nbytes = n * dim * 4
+    scratch = None
+    for d in (os.environ.get("MVF_BENCH_FILE_DIR"), "/tmp", "/dev/shm"):
+        if d and os.path.isdir(d) and shutil.disk_usage(d).free >= nbytes + (2 << 30):
+            scratch = d
+            break
+    if scratch is None:
+        return {"skipped": f"no scratch directory with {(nbytes + (2 << 30)) / 2**30:.1f} GiB free"}
+    path = os.path.join(scratch, f"mvf_bench_{os.getpid()}.mvf")
+    leg = {"workload": f"{n / 1e6:g}M x {dim} f32 cosine space ({nbytes / 1e9:.2f} GB block) + a {n8} x {dim8} int8 space behind it "
+                       f"(block offset > 2^32) in one .mvf; open -> map_vector_range -> upload -> search",
+           "scratch_dir": scratch, "scratch_fs": "tmpfs (memory)" if scratch.startswith("/dev/shm") else "disk"}
+    ref = G.GpuCorpus.synthetic(n, dim, 0, SEED, device=local_rank)
+    try:
+        t0 = time.perf_counter()
+        b = MvfBuilder()
+        b.add_vector_space("big", dim, 0, 2, 0)
+        b.add_vector_space("small_i8", dim8, 0, 1, 2)
+        b.reserve_vectors("big", n)
+        for r0 in range(0, n, 250_000):
+            b.add_vectors_raw("big", ref.read_rows(r0, min(250_000, n - r0)))
+        with G.GpuCorpus.synthetic(n8, dim8, 2, SEED + 7, device=local_rank) as c8:
+            rows8 = c8.read_rows(0, n8)
+        b.add_vectors_raw("small_i8", rows8)
+        t1 = time.perf_counter()
+        b.build().save(path)
+        t2 = time.perf_counter()
+        del b
+        fd = os.open(path, os.O_RDONLY)
+        os.fsync(fd)
+        evicted = True
+        try:
+            os.posix_fadvise(fd, 0, 0, os.POSIX_FADV_DONTNEED)  # clean pages leave the page cache: the next read is cold
+        except OSError:
+            evicted = False
+        os.close(fd)
+        size = os.path.getsize(path)
+        leg["file_bytes"] = size
+        leg["write"] = {"build_in_memory_s": t1 - t0, "crc_and_save_s": t2 - t1, "save_gb_per_s": size / (t2 - t1) / 1e9}
+
+        def timed_open():
+            t = time.perf_counter()
+            r = MvfReader.open(path)
+            return r, (time.perf_counter() - t) * 1e3
+
+        r, open_cold_ms = timed_open()
+        r.close()
+        opens = []
+        for _ in range(20):
+            r, ms = timed_open()
+            opens.append(ms)
+            r.close()
+        opens.sort()
+        leg["open_ms"] = {"first": open_cold_ms, "median_of_20": opens[10],
+                          "what": "mvf_reader_open: mmap + magic / footer-length checks + footer parse; independent of the file size"}
+        r = MvfReader.open(path)
+        big, small = r.vector_space("big"), r.vector_space("small_i8")
+        ups = {}
+        for name, kw in (("cold_page_cache" if evicted and not scratch.startswith("/dev/shm") else "first", {}),
+                         ("warm_page_cache", {}), ("warm_with_checksum_thread", {"verify_checksum": True}),
+                         ("warm_prepare_batched", {"prepare_batched": True})):
+            t = time.perf_counter()
+            c = upload_space(big, device=local_rank, **kw)
+            dt = time.perf_counter() - t
+            ups[name] = {"s": dt, "gb_per_s": nbytes / dt / 1e9}
+            if name != "warm_prepare_batched":
+                c.close()
+        leg["upload_from_mmap"] = ups
+        t = time.perf_counter()
+        r.validate_with_checksum()
+        dt = time.perf_counter() - t
+        leg["checksum"] = {"s": dt, "gb_per_s": size / dt / 1e9, "what": "mvf_reader_validate_with_checksum over both blocks (CRC-32, threaded slicing-by-8), page cache warm"}
+        anon = np.empty((n, dim), np.float32)
+        for r0 in range(0, n, 250_000):
+            anon[r0:r0 + 250_000] = ref.read_rows(r0, min(250_000, n - r0))
+        t = time.perf_counter()
+        with G.GpuCorpus.from_array(anon, device=local_rank):
+            dt = time.perf_counter() - t
+        del anon
+        leg["upload_from_anonymous_memory"] = {"s": dt, "gb_per_s": nbytes / dt / 1e9}
+        # searches on the uploaded space: one query and 64, host-buffer API; answers against the synthetic corpus' own
+        from metrovector_amd import _lib
+        import torch
+        dq = torch.empty((64, dim), dtype=torch.float32, device=f"cuda:{local_rank}")
+        _lib.gpu_check(_lib.gpu().mvfgpu_synth_queries_device(dq.data_ptr(), 64, dim, 0, SEED + 1, local_rank, None))
+        hq = dq.cpu().numpy()
+        res = {}
+        for nm, q in (("q1", hq[:1]), ("q64", hq)):
+            for _ in range(3):
+                got = c.search(q, k, G.COSINE)
+            t = time.perf_counter()
+            for _ in range(10):
+                got = c.search(q, k, G.COSINE)
+            ms = (time.perf_counter() - t) / 10 * 1e3
+            want = ref.search(q, k, G.COSINE)
+            res[nm] = {"ms_per_search": ms, "identical_to_synthetic_corpus": bool(
+                (got.indices == want.indices).all() and (got.scores.view(np.uint32) == want.scores.view(np.uint32)).all())}
+            if oracle is not None and nm == "q64":
+                sel = [0, 21, 42, 63]
+                _, oidx, _ = oracle_topk_rows(oracle, 0, n, dim, 0, 2, q[sel], k)
+                res[nm]["recall_at_k"] = recall_of(got.indices[sel], oidx)
+                res[nm]["recall_queries_checked"] = len(sel)
+        c.close()
+        with upload_space(small, device=local_rank, verify_checksum=True) as c8:
+            got8 = c8.search(rows8[:4], 10, G.INNER_PRODUCT)  # rows as queries: each finds itself or a larger-norm row
+        res["small_i8_space_behind_4gib"] = {"rows": n8, "block_offset": int(r.blocks()[1].offset),
+                                             "searched": bool((got8.raw[:, 0] >= (rows8[:4].astype(np.int64) ** 2).sum(1)).all())}
+        leg["search"] = res
+        r.close()
+    finally:
+        ref.close()
+        if os.path.exists(path):
+            os.remove(path)
+    return leg
 
 
 def vendor_gemm_reference(torch, dev):
@@ -855,6 +1024,12 @@ def main():
             result["cfg4_int8"] = cfg4_leg(args, torch, G, _lib, None if args.no_recall else oracle, local_rank)
         if not args.no_cfg1:
             result["cfg1"] = cfg1_block(args, torch, G, oracle, local_rank)
+        if not args.no_file:
+            torch.cuda.empty_cache()
+            try:
+                result["mvf_file_e2e"] = mvf_file_leg(args, G, None if args.no_recall else oracle, local_rank)
+            except Exception as e:  # a full disk must not cost the line its other legs
+                result["mvf_file_e2e"] = {"error": f"{type(e).__name__}: {e}"[:400]}
 
     # every rank has released its corpora: the process group is done; rank 0 goes on alone
     torch.cuda.empty_cache()

@@ -132,6 +132,9 @@ int mvf_builder_add_vectors_f32(mvf_builder* b, const char* space_name, const fl
  * the space's storage type — the only way to write Int8/UInt8 spaces. */
 int mvf_builder_add_vectors_raw(mvf_builder* b, const char* space_name, const void* rows, uint64_t n_vectors,
                                 uint32_t dimension);
+/* EXTENSION: reserve room for n_vectors rows of the space (its dimension must be known) before appending a multi-GB
+ * block in pieces: no re-copying on the way up, transparent huge pages requested. */
+int mvf_builder_reserve_vectors(mvf_builder* b, const char* space_name, uint64_t n_vectors);
 /* EXTENSION: the reference's builder has the fields (builder.rs:61-63) but no setter. */
 int mvf_builder_set_vector_ids(mvf_builder* b, const char* space_name, const uint64_t* ids, uint64_t n);
 int mvf_builder_set_tombstones(mvf_builder* b, const char* space_name, uint8_t format, const void* data, uint64_t len,

@@ -74,7 +74,8 @@ typedef struct mvfgpu_corpus_info {
     uint8_t data_type;    /* enum mvf_data_type */
     uint8_t has_vector_ids; /* 1 when vector ids are attached (searches then report ids, not positions) */
     uint8_t shadows;      /* bit 0: the int8 selection shadow is resident, bit 1: the scaled-f16 one */
-    uint8_t reserved;
+    uint8_t selection_state; /* bit 0: the repair feedback has switched the int8-shadow selection off for this corpus,
+                                bit 1: it has switched the folded pre-filter of the int8 kernels off */
     uint32_t reserved2;
     uint64_t device_bytes; /* HBM held by the handle: rows, deletion bitmap, ids, norms, every scratch buffer and the
                               selection shadows (int8: +dimension bytes per row; scaled f16: +2*dimension) with their
@@ -394,6 +395,32 @@ int mvfgpu_last_timing(const mvfgpu_corpus* corpus, mvfgpu_timing* out);
  * arithmetic differs.  mvfgpu_corpus_get_info reports which shadows a handle
  * holds (`shadows`) and counts them in `device_bytes`. */
 int mvfgpu_set_scan_path(mvfgpu_corpus* corpus, int path);
+
+/*
+ * The tuning switches of the environment (MVF_K1_G, MVF_K2_*, MVF_I8_SHADOW, MVF_F16_SHADOW, MVF_QS_REFINE,
+ * MVF_STREAM_*, MVF_REPAIR_WINDOW, MVF_UPLOAD_THREADS, MVF_DEBUG_REPAIR; INTEGRATION.md lists them) are read ONCE per
+ * handle, when it is created: a search never calls getenv.  An A/B script that changes the environment of a live handle
+ * calls this to have it read again.
+ */
+int mvfgpu_corpus_reload_tuning(mvfgpu_corpus* corpus);
+
+/*
+ * ABI version of the library: bumped whenever a struct layout or a function signature of this header changes in a way
+ * an older caller would misread (2: every out-struct starts with struct_size, round 3; 3: corpus_info.selection_state,
+ * reload_tuning, k up to MVFGPU_MAX_K = 16384).  A binding compares it with the MVFGPU_ABI_VERSION it was built against
+ * at load time.
+ */
+#define MVFGPU_ABI_VERSION 3u
+uint32_t mvfgpu_abi_version(void);
+
+/*
+ * Self-test of the automatic path choice (no GPU needed).  Batched searches watch how many of their queries the repair
+ * pass had to redo and switch a corpus whose data defeats the cheap bounds back to slower selections: first the folded
+ * pre-filter of the int8 kernels goes, then the int8-shadow selection.  `samples` holds n_samples records of four u32
+ * {queries of the search, queries repaired, ran with the folded pre-filter, selected on the int8 shadow} in the order
+ * the searches were consumed; out_state receives {queries counted, repairs counted, pre-filter off, int8 selection off}.
+ */
+int mvfgpu_selftest_feedback(const uint32_t* samples, uint32_t n_samples, uint32_t* out_state);
 
 #ifdef __cplusplus
 }

@@ -31,7 +31,7 @@ class _OutStruct(C.Structure):
 class CorpusInfo(_OutStruct):
     _fields_ = [("struct_size", C.c_uint32), ("device", C.c_int32), ("rows", C.c_uint64), ("index_base", C.c_uint64),
                 ("dimension", C.c_uint32), ("pitch_bytes", C.c_uint32), ("data_type", C.c_uint8),
-                ("has_vector_ids", C.c_uint8), ("shadows", C.c_uint8), ("reserved", C.c_uint8), ("reserved2", C.c_uint32),
+                ("has_vector_ids", C.c_uint8), ("shadows", C.c_uint8), ("selection_state", C.c_uint8), ("reserved2", C.c_uint32),
                 ("device_bytes", C.c_uint64), ("deleted_rows", C.c_uint64)]
 
 
@@ -62,6 +62,9 @@ class Timing(_OutStruct):
                 ("scan_kernel", C.c_uint32), ("scan_launches", C.c_uint32), ("scan_bytes", C.c_uint64),
                 ("scan_flops", C.c_uint64), ("search_ms", C.c_float), ("search_ms_avg", C.c_float),
                 ("search_flops", C.c_uint64), ("repaired_queries", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+ABI_VERSION = 3  # include/mvf_gpu.h MVFGPU_ABI_VERSION
 
 
 def _preload_torch_hip() -> None:
@@ -118,13 +121,21 @@ def gpu() -> C.CDLL:
     lib.mvfgpu_set_profiling.argtypes = [vp, i32]
     lib.mvfgpu_last_timing.argtypes = [vp, C.POINTER(Timing)]
     lib.mvfgpu_set_scan_path.argtypes = [vp, i32]
+    lib.mvfgpu_corpus_reload_tuning.argtypes = [vp]
+    lib.mvfgpu_selftest_feedback.argtypes = [vp, u32, vp]
+    lib.mvfgpu_abi_version.restype = u32
+    lib.mvfgpu_abi_version.argtypes = []
+    if lib.mvfgpu_abi_version() != ABI_VERSION:
+        raise ImportError(f"{GPU_LIB_PATH} speaks ABI version {lib.mvfgpu_abi_version()}, this binding was written against "
+                          f"{ABI_VERSION} (include/mvf_gpu.h MVFGPU_ABI_VERSION): rebuild the library")
     for name in ("mvfgpu_device_count", "mvfgpu_corpus_create", "mvfgpu_corpus_create_ex", "mvfgpu_corpus_create_synthetic",
                  "mvfgpu_corpus_set_tombstones", "mvfgpu_corpus_set_vector_ids", "mvfgpu_shardset_create",
                  "mvfgpu_shardset_get_info", "mvfgpu_shardset_search", "mvfgpu_shardset_last_timing",
                  "mvfgpu_corpus_get_info", "mvfgpu_corpus_read_rows", "mvfgpu_corpus_gather_rows", "mvfgpu_search", "mvfgpu_search_device",
                  "mvfgpu_merge_topk_host", "mvfgpu_merge_topk_device", "mvfgpu_merge_topk_packed_device",
                  "mvfgpu_synth_queries_device",
-                 "mvfgpu_set_profiling", "mvfgpu_last_timing", "mvfgpu_set_scan_path"):
+                 "mvfgpu_set_profiling", "mvfgpu_last_timing", "mvfgpu_set_scan_path", "mvfgpu_corpus_reload_tuning",
+                 "mvfgpu_selftest_feedback"):
         getattr(lib, name).restype = C.c_int
     _gpu = lib
     return lib
@@ -192,6 +203,7 @@ def host() -> C.CDLL:
     lib.mvf_builder_add_vector_space.argtypes = [vp, C.c_char_p, u32, u8, u8, u8, C.POINTER(u64)]
     lib.mvf_builder_add_vectors_f32.argtypes = [vp, C.c_char_p, vp, u64, u32]
     lib.mvf_builder_add_vectors_raw.argtypes = [vp, C.c_char_p, vp, u64, u32]
+    lib.mvf_builder_reserve_vectors.argtypes = [vp, C.c_char_p, u64]
     lib.mvf_builder_add_metadata_column.argtypes = [vp, C.c_char_p, u8, vp, u64]
     lib.mvf_builder_to_bytes.argtypes = [vp, u32, pp, C.POINTER(u64)]
     lib.mvf_builder_save.argtypes = [vp, C.c_char_p, u32]

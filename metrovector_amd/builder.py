@@ -78,6 +78,10 @@ class MvfBuilder:
         _lib.host_check(_lib.host().mvf_builder_add_vectors_raw(self._h, space_name.encode(), a.ctypes.data_as(C.c_void_p),
                                                                 a.shape[0], a.shape[1]))
 
+    def reserve_vectors(self, space_name: str, n_vectors: int) -> None:
+        """EXTENSION: room for n_vectors rows up front (a multi-GB block appended in pieces is not re-copied)."""
+        _lib.host_check(_lib.host().mvf_builder_reserve_vectors(self._h, space_name.encode(), int(n_vectors)))
+
     def set_vector_ids(self, space_name: str, ids) -> None:
         """EXTENSION: one u64 id per row (the reference's builder has the field, builder.rs:61, but no setter)."""
         a = np.ascontiguousarray(ids, dtype=np.uint64)

@@ -18,6 +18,7 @@
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <sys/mman.h>
 #include <thread>
 #include <vector>
 
@@ -74,6 +75,40 @@ struct DevBuf {
 
 namespace mvf {
 int set_fail(int status, const std::string& msg) { return fail(status, msg); }
+
+Tuning read_tuning() {
+    Tuning t;
+    auto num = [](const char* name, long dflt) {
+        const char* e = getenv(name);
+        return e ? atol(e) : dflt;
+    };
+    auto flag = [](const char* name, bool dflt) {
+        const char* e = getenv(name);
+        return e ? atoi(e) != 0 : dflt;
+    };
+    const long g = num("MVF_K1_G", 0);
+    t.k1_g = (g == 64 || g == 32 || g == 16 || g == 8 || g == 4 || g == 1) ? (int)g : 0;
+    t.k2_dma = flag("MVF_K2_DMA", true);
+    t.k2_sb = flag("MVF_K2_SB", true);
+    t.k2_pp = getenv("MVF_K2_PP") ? (int)flag("MVF_K2_PP", false) : -1;
+    t.k2_growth = (uint32_t)std::max(2l, num("MVF_K2_GROWTH", 4));
+    t.k2_bias = flag("MVF_K2_BIAS", true);
+    t.k2_persistent = getenv("MVF_K2_PERSISTENT") ? (int)flag("MVF_K2_PERSISTENT", false) : -1;
+    t.k2_persistent16 = getenv("MVF_K2_PERSISTENT16") ? (int)flag("MVF_K2_PERSISTENT16", true) : -1;
+    const long tile = num("MVF_K2_TILE", 0);
+    t.k2_tile = tile == 0 ? 0 : tile == 64 ? 64 : tile == 128 ? 128 : 256;
+    t.f16_shadow = flag("MVF_F16_SHADOW", true);
+    t.i8_shadow = flag("MVF_I8_SHADOW", true);
+    t.qs_refine = flag("MVF_QS_REFINE", true);
+    t.debug_repair = getenv("MVF_DEBUG_REPAIR") != nullptr;
+    t.repair_window = (uint32_t)std::max(0l, num("MVF_REPAIR_WINDOW", 0));
+    if (const char* e = getenv("MVF_K2_REGION_RECORDS")) t.region_records = strtoull(e, nullptr, 10);
+    t.stream_i8 = flag("MVF_STREAM_I8", false);
+    t.stream_shadow = flag("MVF_STREAM_SHADOW", false);
+    t.upload_threads = (unsigned)std::max(0l, num("MVF_UPLOAD_THREADS", 0));
+    t.upload_advise = flag("MVF_UPLOAD_ADVISE", true);
+    return t;
+}
 }  // namespace mvf
 
 struct mvfgpu_corpus {
@@ -131,6 +166,7 @@ struct mvfgpu_corpus {
 
     bool profiling = false;
     int scan_path = 0;
+    mvf::Tuning tune;  // the environment's tuning switches as they were when the handle was created
     struct ProfSlot {
         hipEvent_t e[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // [0,1] the timed scan launch, [2] end of its select; [3,4] the whole search
         bool scanned = false, whole = false;
@@ -152,7 +188,7 @@ namespace {
 //   Four queries per pass (NQ = 4) carry 16 sums per lane group: 16 lanes stay ahead up to 8 KiB rows.
 // round 1 picked "the widest group within 80 % of the best lane utilisation": up to 46 % off the best width on the
 // shapes it had not been measured on (dim 100 / 200 f32, 512 f16, 384 / 1024 int8).  MVF_K1_G forces a width (sweeps).
-void choose_group(uint32_t V, int nqv, int* G_out, uint32_t* J_out) {
+void choose_group(uint32_t V, int nqv, int* G_out, uint32_t* J_out, int forced = 0) {
     // round 3: 5..8 vectors (65..128 B) take 8 lanes -- with 4 a row took two steps and every 128-byte line two separate
     // wave-loads.
     int g = V <= 1 ? 1 : V <= 4 ? 4 : V <= 8 ? 8 : (V < 192 || (nqv == 4 && V < 512)) ? 16 : 64;
@@ -162,15 +198,13 @@ void choose_group(uint32_t V, int nqv, int* G_out, uint32_t* J_out) {
     // 64 lanes from 33 vectors on (800-B rows 4.2 -> 5.1 TB/s, 1600-B 4.8 -> 5.6), 32 lanes for 17..31 (two adjacent rows
     // per wave-load); 32-B rows take 4 lanes, half of them idle, instead of one lane per row (3.4 -> 4.6 TB/s).
     if (nqv == 1 && V % 8 != 0 && V > 16 && V < 192) g = V > 32 ? 64 : 32;
-    if (const char* e = getenv("MVF_K1_G")) {
-        const int f = atoi(e);
-        if (f == 64 || f == 32 || f == 16 || f == 8 || f == 4 || f == 1) g = f;
-    }
+    if (forced) g = forced;  // MVF_K1_G (sweeps)
     *G_out = g;
     *J_out = (V + g - 1) / g;
 }
 
 int init_common(mvfgpu_corpus* c) {
+    c->tune = mvf::read_tuning();
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, c->device));
     c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
@@ -194,7 +228,7 @@ int validate_shape(uint64_t n, uint32_t dim, uint8_t dtype) {
 int alloc_rows(mvfgpu_corpus* c) {
     c->pitch = (c->dim * elem_size(c->dtype) + 15u) & ~15u;
     c->V = c->pitch / 16;
-    choose_group(c->V, 1, &c->G, &c->J);
+    choose_group(c->V, 1, &c->G, &c->J, c->tune.k1_g);
     c->rows_bytes = (size_t)c->n * c->pitch;
     if (c->rows_bytes) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_rows), c->rows_bytes));
     return MVF_OK;
@@ -263,12 +297,12 @@ int search_stream_path(const mvfgpu_corpus* c, uint8_t metric, const void* d_que
         int nqv = (nq - q0) >= 2 && (!alt || alt8) ? 4 : 1;
         int G;
         uint32_t J;
-        choose_group(kV, nqv, &G, &J);  // the lane-group width depends on the queries per pass
+        choose_group(kV, nqv, &G, &J, c->tune.k1_g);  // the lane-group width depends on the queries per pass
         uint32_t chunk_rows = scan_chunk_rows(G, J, nqv), pmax = next_pow2(k + scan_chunk_safe(G));
         size_t lds = scan_lds_bytes(kdtype, G, J, nqv, pmax);
         if (nqv == 4 && lds > 150 * 1024) {
             nqv = 1;
-            choose_group(kV, nqv, &G, &J);
+            choose_group(kV, nqv, &G, &J, c->tune.k1_g);
             chunk_rows = scan_chunk_rows(G, J, nqv);
             pmax = next_pow2(k + scan_chunk_safe(G));
             lds = scan_lds_bytes(kdtype, G, J, nqv, pmax);
@@ -397,24 +431,18 @@ int search_stream_path(const mvfgpu_corpus* c, uint8_t metric, const void* d_que
 
 // The f16/int8 MFMA kernel: scan_mfma16_dma.hip (LDS-DMA ring, 16x16 MFMA shape) by default; MVF_K2_DMA=0 selects the
 // register-staged scan_mfma16.hip (kept as the A/B reference: same results, ~7 % slower).
-bool k2_dma_enabled() {
-    const char* e = getenv("MVF_K2_DMA");
-    return !e || atoi(e) != 0;
-}
+bool k2_dma_enabled(const mvfgpu_corpus* c) { return c->tune.k2_dma; }
 
 // One tile of at most 64 queries: the streaming MFMA kernel (scan_mfma16_sb.hip) instead of the 64-query shape of the
 // LDS-DMA tile kernel; MVF_K2_SB=0 goes back (A/B runs).
-bool k2_sb_enabled() {
-    const char* e = getenv("MVF_K2_SB");
-    return !e || atoi(e) != 0;
-}
+bool k2_sb_enabled(const mvfgpu_corpus* c) { return c->tune.k2_sb; }
 
 // 256-query tile: the ping-pong schedule (scan_mfma16_pp.hip) or the lockstep LDS-DMA kernel.  Measured (MI355X,
 // profiles/r02_k2_ab.txt): Float16 rows / the f16 shadow 5 % faster on the ping-pong kernel once a block walks several
 // tiles (cfg5 last phase 20.7 -> 19.7 ms), short phases and Int8 rows a few percent slower (its longer prologue; cfg4
 // 6.94 vs 7.02 ms).  MVF_K2_PP=0|1 forces one of them (A/B runs).
-bool k2_pp_wanted(uint8_t kdtype, uint32_t ntiles, uint32_t mtiles, int num_cus) {
-    if (const char* e = getenv("MVF_K2_PP")) return atoi(e) != 0;
+bool k2_pp_wanted(const mvfgpu_corpus* c, uint8_t kdtype, uint32_t ntiles, uint32_t mtiles, int num_cus) {
+    if (c->tune.k2_pp >= 0) return c->tune.k2_pp != 0;
     return kdtype == MVF_DTYPE_FLOAT16 && (uint64_t)ntiles * mtiles >= 8ull * (uint64_t)num_cus;
 }
 
@@ -423,29 +451,21 @@ bool k2_pp_wanted(uint8_t kdtype, uint32_t ntiles, uint32_t mtiles, int num_cus)
 // several per 256 x 256 tile at g = 8, and every candidate sends its wave through the epilogue's second stage.  g = 4
 // costs one or two more (small) launches and measured 2-3 % faster on cfg3 / cfg5 / cfg4 (profiles/r02_k2_ab.txt); g = 16
 // and 32 were 4 % slower in round 1.
-uint32_t k2_growth_cap() {
-    if (const char* e = getenv("MVF_K2_GROWTH")) return (uint32_t)std::max(2, atoi(e));
-    return 4u;
-}
+uint32_t k2_growth_cap(const mvfgpu_corpus* c) { return c->tune.k2_growth; }
 
 // The folded pre-filter of the LDS-DMA kernel's i32-accumulator flavours (scan_mfma16_bias.inc); MVF_K2_BIAS=0 keeps
 // round 2's epilogue (A/B runs).
-bool k2_bias_enabled() {
-    const char* e = getenv("MVF_K2_BIAS");
-    return !e || atoi(e) != 0;
-}
+bool k2_bias_enabled(const mvfgpu_corpus* c) { return c->tune.k2_bias; }
 
-bool k2_dma_persistent(uint8_t) {  // measured: int8 15 % and f16 5 % faster with one persistent block per CU
-    if (const char* e = getenv("MVF_K2_PERSISTENT16")) return atoi(e) != 0;
-    return true;
+bool k2_dma_persistent(const mvfgpu_corpus* c) {  // measured: int8 15 % and f16 5 % faster with one persistent block per CU
+    return c->tune.k2_persistent16 < 0 ? true : c->tune.k2_persistent16 != 0;
 }
 
 // ---- scaled-f16 shadow of a Float32 corpus (selection only) -----------------------------------------------------
 uint32_t shadow_pitch(uint32_t dim) { return (dim * 2u + 15u) & ~15u; }
 
-bool shadow_enabled() {  // MVF_F16_SHADOW=0 keeps Float32 corpora on the exact f32 MFMA kernel (scan path 3 overrides)
-    const char* e = getenv("MVF_F16_SHADOW");
-    return !e || atoi(e) != 0;
+bool shadow_enabled(const mvfgpu_corpus* c) {  // MVF_F16_SHADOW=0 keeps Float32 corpora on the exact f32 MFMA kernel (scan path 3 overrides)
+    return c->tune.f16_shadow;
 }
 
 // Built on the first search that wants it (like the row norms): +50 % of the corpus' HBM.  Unless the caller insists
@@ -493,13 +513,37 @@ constexpr uint32_t kQsStreamMaxK = kBatchCap / 2 / 10;    // streamed (select_fi
 bool qs_wanted(const mvfgpu_corpus* c, uint32_t k = 0) {
     if (is_int_dtype(c->dtype) || c->n == 0) return false;
     if (k > kQsMaxK) return false;
-    if (!k2_dma_enabled()) return false;  // the register-staged A/B kernel (MVF_K2_DMA=0) has no int8-shadow flavour
+    if (!k2_dma_enabled(c)) return false;  // the register-staged A/B kernel (MVF_K2_DMA=0) has no int8-shadow flavour
     if ((size_t)((c->dim + 7u) & ~7u) * 4 + kBatchCapQS * 4 > 64 * 1024) return false;  // re-scoring: query + candidates in LDS
     if (c->scan_path == 5 || c->scan_path == 6) return true;
     if (c->scan_path != 0 && c->scan_path != 4) return false;
     if (c->qs_disabled || c->shadow8_state < 0) return false;
-    const char* e = getenv("MVF_I8_SHADOW");
-    return !e || atoi(e) != 0;
+    return c->tune.i8_shadow;
+}
+
+// The decision itself, a pure function of the sequence of samples (mvfgpu_selftest_feedback runs it without a GPU).
+// A sample = (queries of the search, queries its repair pass redid, whether it ran with the folded pre-filter, whether it
+// selected on the int8 shadow).  Running totals (a single streamed query says little by itself), halved now and then so
+// that old history fades.  Too many repairs blame the folded pre-filter first (its per-lane bounds), the int8 selection
+// second.  A sample of a search that still RAN WITH the pre-filter, consumed after the pre-filter has been switched off
+// (two searches are in flight), is dropped: its repairs are the suspect's, and counted against the fresh totals they
+// would switch the int8 selection off one search later, for good.
+void feedback_consume(uint32_t& seen, uint32_t& redone, bool& bias_disabled, bool& qs_disabled, uint32_t nq, uint32_t redo,
+                      bool used_bias, bool used_qs) {
+    if (used_bias && bias_disabled) return;
+    seen += nq;
+    redone += std::min(redo, nq);
+    if (redone >= 4 && (uint64_t)redone * 8 > seen) {
+        if (used_bias && !bias_disabled) {
+            bias_disabled = true;
+            seen = redone = 0;
+        } else if (used_qs) {
+            qs_disabled = true;
+        }
+    } else if (seen >= 8192) {
+        seen /= 2;
+        redone /= 2;
+    }
 }
 
 // What the search before the previous one had to repair (its count was copied to pinned memory behind it; waited for
@@ -512,26 +556,12 @@ void qs_feedback_poll(const mvfgpu_corpus* c) {
         return;
     }
     c->qs_redo_pending[sl] = false;
-    // running totals (a single streamed query says little by itself), halved now and then so that old history fades
-    c->qs_seen += c->qs_redo_nq[sl];
-    c->qs_redone += std::min(c->qs_redo_host[sl], c->qs_redo_nq[sl]);
-    if (c->qs_redone >= 4 && (uint64_t)c->qs_redone * 8 > c->qs_seen) {
-        if (c->fb_bias[sl] && !c->bias_disabled) {  // first suspect: the folded pre-filter's per-lane bounds
-            c->bias_disabled = true;
-            if (getenv("MVF_DEBUG_REPAIR"))
-                fprintf(stderr, "[mvfgpu] folded pre-filter switched off for this corpus: %u of %u queries needed the repair path\n",
-                        c->qs_redone, c->qs_seen);
-            c->qs_seen = c->qs_redone = 0;
-        } else if (c->fb_qs[sl]) {
-            c->qs_disabled = true;
-            if (getenv("MVF_DEBUG_REPAIR"))
-                fprintf(stderr, "[mvfgpu] int8-shadow selection switched off for this corpus: %u of %u queries needed the repair path\n",
-                        c->qs_redone, c->qs_seen);
-        }
-    } else if (c->qs_seen >= 8192) {
-        c->qs_seen /= 2;
-        c->qs_redone /= 2;
-    }
+    const bool bias_was = c->bias_disabled, qs_was = c->qs_disabled;
+    feedback_consume(c->qs_seen, c->qs_redone, c->bias_disabled, c->qs_disabled, c->qs_redo_nq[sl], c->qs_redo_host[sl],
+                     c->fb_bias[sl], c->fb_qs[sl]);
+    if (c->tune.debug_repair && (bias_was != c->bias_disabled || qs_was != c->qs_disabled))
+        fprintf(stderr, "[mvfgpu] %s switched off for this corpus: too many queries needed the repair path\n",
+                bias_was != c->bias_disabled ? "folded pre-filter" : "int8-shadow selection");
 }
 
 // ... and the request for it: the repair count of the search just enqueued, copied to pinned memory behind an event.
@@ -584,10 +614,7 @@ hipError_t ensure_shadow8(const mvfgpu_corpus* c, hipStream_t s, bool insist) {
 // the corpus -- when that is at least this many rows (in front of the second largest phase too it cost what it saved);
 // MVF_QS_REFINE=0 switches it off (A/B runs).
 constexpr uint64_t kRefineMinRows = 200000;
-bool qs_refine_enabled() {
-    const char* e = getenv("MVF_QS_REFINE");
-    return !e || atoi(e) != 0;
-}
+bool qs_refine_enabled(const mvfgpu_corpus* c) { return c->tune.qs_refine; }
 
 // K2 per-query state (threshold key, candidate count, overflow flag; for the refinement the number of best candidates
 // at the head of the list and the worst exact key among them), armed once and re-armed by the kernels that end a search.
@@ -639,12 +666,12 @@ int repair_flagged_queries(const mvfgpu_corpus* c, uint8_t metric, const void* d
     const uint32_t kcap = next_pow2(k);
     int nqv = 4, G;
     uint32_t J;
-    choose_group(c->V, nqv, &G, &J);
+    choose_group(c->V, nqv, &G, &J, c->tune.k1_g);
     uint32_t chunk_rows = scan_chunk_rows(G, J, nqv), pmax = next_pow2(k + scan_chunk_safe(G));
     size_t lds = scan_lds_bytes(c->dtype, G, J, nqv, pmax);
     if (lds > 150 * 1024) {
         nqv = 1;
-        choose_group(c->V, nqv, &G, &J);
+        choose_group(c->V, nqv, &G, &J, c->tune.k1_g);
         chunk_rows = scan_chunk_rows(G, J, nqv);
         pmax = next_pow2(k + scan_chunk_safe(G));
         lds = scan_lds_bytes(c->dtype, G, J, nqv, pmax);
@@ -664,7 +691,7 @@ int repair_flagged_queries(const mvfgpu_corpus* c, uint8_t metric, const void* d
     const uint32_t nblocks = std::min<uint32_t>(nchunks, (uint32_t)std::min(occ, 2) * (uint32_t)c->num_cus);
     const size_t per_query = (size_t)nblocks * kcap * 8;
     uint32_t R = (uint32_t)std::min<size_t>(4096, std::max<size_t>(4, ((size_t)256 << 20) / per_query));
-    if (const char* e = getenv("MVF_REPAIR_WINDOW")) R = std::min<uint32_t>(R, std::max(4, atoi(e)));  // tests: several windows on small batches
+    if (c->tune.repair_window) R = std::min<uint32_t>(R, std::max<uint32_t>(4, c->tune.repair_window));  // tests: several windows on small batches
     HIP_TRY(c->repair.reserve((size_t)R * per_query + (size_t)nq * 4 + 16));
     uint64_t* lists = static_cast<uint64_t*>(c->repair.p);
     uint32_t* redo_cnt = reinterpret_cast<uint32_t*>(static_cast<unsigned char*>(c->repair.p) + (size_t)R * per_query);
@@ -714,7 +741,7 @@ int repair_flagged_queries(const mvfgpu_corpus* c, uint8_t metric, const void* d
         fp.redo_base = base;
         HIP_TRY(launch_select_final(fp, std::min(R, nq - base), s));
     }
-    if (getenv("MVF_DEBUG_REPAIR")) {  // diagnostics only: how many queries took the repair path (synchronises)
+    if (c->tune.debug_repair) {  // diagnostics only: how many queries took the repair path (synchronises)
         uint32_t n = 0;
         HIP_TRY(hipMemcpyAsync(&n, redo_cnt, 4, hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
@@ -741,7 +768,7 @@ int search_batched_path(const mvfgpu_corpus* c, uint8_t metric, const void* d_qu
         HIP_TRY(ensure_shadow8(c, s, c->scan_path == 5 || c->scan_path == 6));
         use_qs = c->shadow8_state == 1;
     }
-    if (!use_qs && c->dtype == MVF_DTYPE_FLOAT32 && c->scan_path != 2 && (c->scan_path == 3 || shadow_enabled()) && rescore_fits) {
+    if (!use_qs && c->dtype == MVF_DTYPE_FLOAT32 && c->scan_path != 2 && (c->scan_path == 3 || shadow_enabled(c)) && rescore_fits) {
         HIP_TRY(ensure_shadow(c, s, c->scan_path == 3));
         use_shadow = c->shadow_state == 1;
     }
@@ -751,8 +778,8 @@ int search_batched_path(const mvfgpu_corpus* c, uint8_t metric, const void* d_qu
                                  : use_shadow ? static_cast<const unsigned char*>(c->shadow.p)
                                               : c->d_rows;
     const uint32_t kpitch = use_qs ? shadow8_pitch(c->dim) : use_shadow ? shadow_pitch(c->dim) : c->pitch;
-    const bool dma = !wide && k2_dma_enabled();            // LDS-DMA kernel (default) or the register-staged one
-    const uint32_t qpb = wide ? 128u : dma ? scan_mfma16_dma_queries_per_block(nq) : scan_mfma16_queries_per_block(kdtype);
+    const bool dma = !wide && k2_dma_enabled(c);            // LDS-DMA kernel (default) or the register-staged one
+    const uint32_t qpb = wide ? 128u : dma ? scan_mfma16_dma_queries_per_block(nq, c->tune.k2_tile) : scan_mfma16_queries_per_block(kdtype);
     const uint32_t tile_rows = wide ? 128u : dma ? scan_mfma16_dma_tile_rows(qpb) : 256u;
     const uint32_t nq_pad = (nq + qpb - 1u) / qpb * qpb;
     const uint32_t ktb = dma ? 64u : 128u;                  // k-tile bytes of the f16/int8 kernel in use
@@ -848,8 +875,8 @@ int search_batched_path(const mvfgpu_corpus* c, uint8_t metric, const void* d_qu
     uint64_t blk_records = 0;
     if (dma) {
         blk_records = std::min<uint64_t>(std::max<uint64_t>((uint64_t)kBlkMaxBlocks * kBlkCap, 2ull * nq_pad * cap), 32ull << 20);
-        if (const char* e = getenv("MVF_K2_REGION_RECORDS"))  // tests: force the regions to overflow
-            blk_records = std::max<uint64_t>((uint64_t)kBlkMaxBlocks * kBlkWaves, strtoull(e, nullptr, 10));
+        if (c->tune.region_records)  // MVF_K2_REGION_RECORDS (tests: force the regions to overflow)
+            blk_records = std::max<uint64_t>((uint64_t)kBlkMaxBlocks * kBlkWaves, c->tune.region_records);
         blk_records -= blk_records % ((uint64_t)kBlkMaxBlocks * kBlkWaves);
         HIP_TRY(c->blk.reserve((size_t)blk_records * 16 + (size_t)kBlkMaxBlocks * kBlkWaves * 4));
         hp.blk_cand = static_cast<uint4*>(c->blk.p);
@@ -883,7 +910,7 @@ int search_batched_path(const mvfgpu_corpus* c, uint8_t metric, const void* d_qu
     // int8 selection: between the large phases the threshold is refined with exact scores of the k best (scan_mfma.h)
     uint32_t* ntop = overflow + c->bstate_slots;
     uint32_t* lkey = ntop + c->bstate_slots;
-    const bool refine = use_qs && qs_refine_enabled();
+    const bool refine = use_qs && qs_refine_enabled(c);
     cp.ntop = refine ? ntop : nullptr;
 
     mvfgpu_timing tm{};
@@ -902,7 +929,7 @@ int search_batched_path(const mvfgpu_corpus* c, uint8_t metric, const void* d_qu
     // phase, the last one included, scans (g - 1) times what its threshold has seen, and the last phase is always the
     // largest ((1 - 1/g) of the rows: the launch bench.py times and prices).  Round 1 grew forwards from cap rows, which
     // left a small odd phase at the end (and the one before it carrying most of the corpus).
-    const uint32_t g = std::min(k2_growth_cap(), std::max(2u, cap / (2u * k)));
+    const uint32_t g = std::min(k2_growth_cap(c), std::max(2u, cap / (2u * k)));
     std::vector<uint64_t> bounds;  // R_1 .. R_{P+1} = n
     {
         uint32_t P = 0;
@@ -929,12 +956,12 @@ int search_batched_path(const mvfgpu_corpus* c, uint8_t metric, const void* d_qu
             bp.direct = hp.direct = (begin == 0 && end - begin <= cap) ? 1u : 0u;
             const bool regions = hp.blk_cand && !hp.direct;
             // which kernel takes the phase
-            const bool use_pp = !wide && dma && qpb == 256u && k2_pp_wanted(kdtype, hp.ntiles, hp.mtiles, c->num_cus) &&
+            const bool use_pp = !wide && dma && qpb == 256u && k2_pp_wanted(c, kdtype, hp.ntiles, hp.mtiles, c->num_cus) &&
                                 scan_mfma16_pp_usable(hp.mtiles, c->num_cus, KT);
-            const bool use_sb = !wide && !use_pp && dma && qpb == 64u && k2_sb_enabled() && scan_mfma16_sb_usable(nq_pad, KT, nq);
-            const bool persistent = k2_dma_persistent(kdtype);
+            const bool use_sb = !wide && !use_pp && dma && qpb == 64u && k2_sb_enabled(c) && scan_mfma16_sb_usable(nq_pad, KT, nq);
+            const bool persistent = k2_dma_persistent(c);
             // per-wave regions of raw records (scan_mfma16_bias.inc): the persistent LDS-DMA kernel on i32 accumulators
-            const bool wave_regions = !wide && dma && !use_pp && !use_sb && persistent && !c->bias_disabled && k2_bias_enabled() &&
+            const bool wave_regions = !wide && dma && !use_pp && !use_sb && persistent && !c->bias_disabled && k2_bias_enabled(c) &&
                                       scan_mfma16_dma_wave_regions(kdtype, qpb, hp.direct != 0, regions, c->dim);
             hp.wave_regions = wave_regions ? 1u : 0u;
             used_bias |= wave_regions;
@@ -946,11 +973,11 @@ int search_batched_path(const mvfgpu_corpus* c, uint8_t metric, const void* d_qu
                 regions_armed = true;
             }
             if (ps && last) HIP_TRY(hipEventRecord(ps->e[0], s));
-            if (wide) HIP_TRY(launch_scan_mfma_f32(bp, metric, c->num_cus, s));
+            if (wide) HIP_TRY(launch_scan_mfma_f32(bp, metric, c->num_cus, c->tune.k2_persistent, s));
             else if (use_pp) HIP_TRY(launch_scan_mfma16_pp(hp, kdtype, metric, c->num_cus, s));
             else if (use_sb) HIP_TRY(launch_scan_mfma16_sb(hp, kdtype, metric, c->num_cus, s));
             else if (dma) HIP_TRY(launch_scan_mfma16_dma(hp, kdtype, metric, c->num_cus, qpb, persistent, s));
-            else HIP_TRY(launch_scan_mfma16(hp, kdtype, metric, c->num_cus, s));
+            else HIP_TRY(launch_scan_mfma16(hp, kdtype, metric, c->num_cus, c->tune.k2_persistent16, s));
             if (ps && last) {
                 HIP_TRY(hipEventRecord(ps->e[1], s));
                 ps->scanned = true;
@@ -1064,7 +1091,7 @@ int search_stream_shadow_path(const mvfgpu_corpus* c, uint8_t metric, const void
     alt.xscale = static_cast<const float*>(c->xscale.p);
     alt.pitch = shadow_pitch(c->dim);
     alt.V = alt.pitch / 16;
-    choose_group(alt.V, 1, &alt.G, &alt.J);
+    choose_group(alt.V, 1, &alt.G, &alt.J, c->tune.k1_g);
     alt.cand = static_cast<uint64_t*>(c->bcand.p);
     alt.cnt = cnt;
     alt.cand_cap = cap;
@@ -1204,15 +1231,13 @@ bool stream_qs_wanted(const mvfgpu_corpus* c, uint32_t nq, uint32_t k) {
     // kernel's -- depending on whether an earlier batched search had built the shadow.  An automatic path must not
     // depend on the handle's history.)
     if (c->scan_path != 0 || nq != 1 || c->shadow8_state != 1) return false;
-    const char* e = getenv("MVF_STREAM_I8");
-    return e && atoi(e) != 0;
+    return c->tune.stream_i8;
 }
 
 // Scan path 4 applies to one or two queries on a Float32 corpus whose shadow exists (or can be built now).
 bool stream_shadow_wanted(const mvfgpu_corpus* c, uint32_t nq) {
     if (c->dtype != MVF_DTYPE_FLOAT32 || nq > 2 || c->n == 0) return false;
-    const char* e = getenv("MVF_STREAM_SHADOW");
-    if (c->scan_path != 4 && !(c->scan_path == 0 && e && atoi(e) != 0)) return false;
+    if (c->scan_path != 4 && !(c->scan_path == 0 && c->tune.stream_shadow)) return false;
     return (size_t)((c->dim + 7u) & ~7u) * 4 + kBatchCap * 4 <= 64 * 1024;  // the re-scoring kernel keeps the query in LDS
 }
 
@@ -1239,7 +1264,7 @@ bool use_batched_path(const mvfgpu_corpus* c, uint8_t metric, uint32_t nq) {
     // (128 MiB of candidate regions per handle) would dwarf them.
     const uint64_t bytes = c->n * (uint64_t)c->dim * elem_size(c->dtype);
     const bool shadowed = qs_wanted(c) ||  // int8 selection, else the f16 shadow (runs as Float16)
-                          (c->dtype == MVF_DTYPE_FLOAT32 && (c->scan_path == 3 || shadow_enabled()) && c->shadow_state >= 0 &&
+                          (c->dtype == MVF_DTYPE_FLOAT32 && (c->scan_path == 3 || shadow_enabled(c)) && c->shadow_state >= 0 &&
                            (size_t)((c->dim + 7u) & ~7u) * 4 + kBatchCap * 4 <= 64 * 1024);
     const uint32_t threshold = bytes < (16ull << 20)                          ? 32u
                                : c->dtype == MVF_DTYPE_FLOAT32 && !shadowed ? (bytes < (1ull << 30) ? 32u : 9u)
@@ -1320,7 +1345,7 @@ int upload_rows(mvfgpu_corpus* c, const void* rows, uint64_t stride, const mvfgp
     // which selection copy the batched searches of this corpus will use: the int8 shadow (Float32 and Float16 rows; the
     // default) or, with MVF_I8_SHADOW=0, the f16 shadow of Float32 rows
     bool want_shadow8 = (o.flags & MVFGPU_UPLOAD_EAGER_SHADOW) != 0 && qs_wanted(c);
-    bool want_shadow = (o.flags & MVFGPU_UPLOAD_EAGER_SHADOW) != 0 && !want_shadow8 && c->dtype == MVF_DTYPE_FLOAT32 && shadow_enabled();
+    bool want_shadow = (o.flags & MVFGPU_UPLOAD_EAGER_SHADOW) != 0 && !want_shadow8 && c->dtype == MVF_DTYPE_FLOAT32 && shadow_enabled(c);
     float* xn = nullptr;
     const size_t nn = norm_stride(n);
     if (want_norms) {
@@ -1366,11 +1391,27 @@ int upload_rows(mvfgpu_corpus* c, const void* rows, uint64_t stride, const mvfgp
         for (auto& q : pin.p) HIP_TRY(hipHostMalloc(&q, span_max, hipHostMallocDefault));
     if (sparse && c->pitch != row_bytes) HIP_TRY(hipMemsetAsync(c->d_rows, 0, c->rows_bytes, s_copy));  // the 16-B padding
     unsigned threads = std::min(8u, std::max(1u, std::thread::hardware_concurrency()));
-    if (const char* e = getenv("MVF_UPLOAD_THREADS")) threads = (unsigned)std::max(1, atoi(e));
+    if (c->tune.upload_threads) threads = c->tune.upload_threads;
+
+    // Rows handed over straight off an mmap'd .mvf (VectorSpace::map_vector_range, src/vectors/vector_space.rs:155-188): with
+    // a cold page cache the copy threads' page faults read the file in readahead-sized pieces, one synchronous read per
+    // fault.  MADV_WILLNEED on the chunks AHEAD of the copy queues those reads as large asynchronous ones (advice only:
+    // harmless on anonymous memory, and errors are ignored).  MVF_UPLOAD_ADVISE=0 switches it off (A/B runs).
+    const uint64_t advise_ahead = (pinned && c->tune.upload_advise) ? 3 : 0;
+    auto advise = [&](uint64_t chunk) {
+        const uint64_t r0 = chunk * chunk_rows;
+        if (r0 >= n) return;
+        const uint64_t h = std::min(chunk_rows, n - r0);
+        const uintptr_t lo = reinterpret_cast<uintptr_t>(src + r0 * stride) & ~(uintptr_t)4095;
+        const uintptr_t hi = (reinterpret_cast<uintptr_t>(src + r0 * stride) + (h - 1) * stride + row_bytes + 4095) & ~(uintptr_t)4095;
+        (void)madvise(reinterpret_cast<void*>(lo), hi - lo, MADV_WILLNEED);
+    };
+    for (uint64_t a = 0; a < advise_ahead; a++) advise(a);
 
     uint64_t i = 0;
     for (uint64_t r0 = 0; r0 < n; r0 += chunk_rows, i++) {
         const int b = (int)(i & 1);
+        if (advise_ahead) advise(i + advise_ahead);
         const uint64_t h = std::min(chunk_rows, n - r0);
         const uint64_t span = (h - 1) * stride + row_bytes;
         unsigned char* place = c->d_rows + r0 * c->pitch;
@@ -1604,6 +1645,7 @@ int mvfgpu_corpus_get_info(const mvfgpu_corpus* c, mvfgpu_corpus_info* out) {
         std::lock_guard<std::mutex> lk(c->mu);
         inf.has_vector_ids = c->ids.p ? 1 : 0;
         inf.shadows = (uint8_t)((c->shadow8_state == 1 ? 1 : 0) | (c->shadow_state == 1 ? 2 : 0));
+        inf.selection_state = (uint8_t)((c->qs_disabled ? 1 : 0) | (c->bias_disabled ? 2 : 0));
         inf.device_bytes = c->tomb.bytes + c->ids.bytes + c->rows_bytes + c->cand.bytes + c->bq.bytes + c->bstate.bytes + c->bcand.bytes +
                            c->xnorm.bytes + c->repair.bytes + c->blk.bytes + c->shadow8.bytes + c->xscale8.bytes + c->qs_stats.bytes +
                            c->shadow.bytes + c->xscale.bytes + c->h_q.bytes + c->h_s.bytes + c->h_i.bytes + c->h_r.bytes;
@@ -2000,6 +2042,29 @@ int mvfgpu_set_scan_path(mvfgpu_corpus* c, int path) {
     if (path < 0 || path > 6) return fail(MVF_ERR_INVALID_ARGUMENT, "path must be 0..6");
     std::lock_guard<std::mutex> lk(c->mu);
     c->scan_path = path;
+    return MVF_OK;
+}
+
+int mvfgpu_corpus_reload_tuning(mvfgpu_corpus* c) {
+    if (!c) return fail(MVF_ERR_INVALID_ARGUMENT, "corpus is NULL");
+    std::lock_guard<std::mutex> lk(c->mu);
+    c->tune = mvf::read_tuning();
+    choose_group(c->V, 1, &c->G, &c->J, c->tune.k1_g);
+    return MVF_OK;
+}
+
+uint32_t mvfgpu_abi_version(void) { return MVFGPU_ABI_VERSION; }
+
+int mvfgpu_selftest_feedback(const uint32_t* samples, uint32_t n_samples, uint32_t* out_state) {
+    if ((!samples && n_samples) || !out_state) return fail(MVF_ERR_INVALID_ARGUMENT, "NULL buffer");
+    uint32_t seen = 0, redone = 0;
+    bool bias_off = false, qs_off = false;
+    for (uint32_t i = 0; i < n_samples; i++)
+        feedback_consume(seen, redone, bias_off, qs_off, samples[4 * i], samples[4 * i + 1], samples[4 * i + 2] != 0, samples[4 * i + 3] != 0);
+    out_state[0] = seen;
+    out_state[1] = redone;
+    out_state[2] = bias_off;
+    out_state[3] = qs_off;
     return MVF_OK;
 }
 

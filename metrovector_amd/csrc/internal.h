@@ -24,4 +24,30 @@ int copy_out_struct(T* out, T full) {
     return 0;
 }
 
+// Tuning switches of the environment (INTEGRATION.md lists them).  Read ONCE per handle, when it is created
+// (mvfgpu_corpus_reload_tuning re-reads them for A/B scripts): nothing on the per-search path calls getenv.
+// -1 / 0 = "not set: the library's own rule".
+struct Tuning {
+    int k1_g = 0;               // MVF_K1_G: lanes per row of the streaming kernel (sweeps)
+    bool k2_dma = true;         // MVF_K2_DMA=0: the register-staged A/B kernel instead of the LDS-DMA ones
+    bool k2_sb = true;          // MVF_K2_SB=0: the 64-query tile shape instead of the streaming MFMA kernel
+    int k2_pp = -1;             // MVF_K2_PP=0|1: force the lockstep / ping-pong schedule on 256-query tiles
+    uint32_t k2_growth = 4;     // MVF_K2_GROWTH: largest phase-to-phase growth of the batched scan
+    bool k2_bias = true;        // MVF_K2_BIAS=0: round 2's epilogue instead of the folded pre-filter
+    int k2_persistent = -1;     // MVF_K2_PERSISTENT: the f32 MFMA kernel's grid
+    int k2_persistent16 = -1;   // MVF_K2_PERSISTENT16: the narrow-type kernels' grid
+    int k2_tile = 0;            // MVF_K2_TILE=64|128|256: force a query-tile shape
+    bool f16_shadow = true;     // MVF_F16_SHADOW=0
+    bool i8_shadow = true;      // MVF_I8_SHADOW=0
+    bool qs_refine = true;      // MVF_QS_REFINE=0
+    bool debug_repair = false;  // MVF_DEBUG_REPAIR: report repaired queries on stderr (synchronises inside a search)
+    uint32_t repair_window = 0; // MVF_REPAIR_WINDOW: queries per repair launch pair (tests: several windows)
+    uint64_t region_records = 0;  // MVF_K2_REGION_RECORDS: size of the candidate regions (tests: force overflows)
+    bool stream_i8 = false;     // MVF_STREAM_I8=1
+    bool stream_shadow = false; // MVF_STREAM_SHADOW=1
+    unsigned upload_threads = 0;  // MVF_UPLOAD_THREADS
+    bool upload_advise = true;    // MVF_UPLOAD_ADVISE=0: no MADV_WILLNEED ahead of the upload's copy threads
+};
+Tuning read_tuning();
+
 }  // namespace mvf

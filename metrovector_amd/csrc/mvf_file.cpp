@@ -22,6 +22,7 @@
 #include <algorithm>
 #include <cstring>
 #include <cstdint>
+#include <stdexcept>
 #include <string>
 #include <thread>
 #include <vector>
@@ -1026,6 +1027,29 @@ int mvf_builder_add_vectors_raw(mvf_builder* b, const char* space_name, const vo
     uint64_t nbytes = 0;
     if (__builtin_mul_overflow(n_vectors, (uint64_t)dimension * es, &nbytes)) return fail(MVF_ERR_INVALID_ARGUMENT, "n_vectors * dimension overflows");
     s->vectors.insert(s->vectors.end(), p, p + nbytes);
+    return MVF_OK;
+}
+
+// EXTENSION: room for n_vectors rows up front.  Vec<u8>-style doubling (the reference, builder.rs:176-191) re-copies and
+// re-faults a multi-GB block several times on its way up; one reservation, with transparent huge pages asked for, does not.
+int mvf_builder_reserve_vectors(mvf_builder* b, const char* space_name, uint64_t n_vectors) {
+    if (!b || !space_name) return fail(MVF_ERR_INVALID_ARGUMENT, "NULL argument");
+    SpaceB* s = find_space(b, space_name);
+    if (!s) return fail(MVF_ERR_SPACE_NOT_FOUND, std::string("Vector space '") + space_name + "' not found");
+    uint32_t es = elem_size(s->data_type);
+    if (!es) return fail(MVF_ERR_BUILD, "Unsupported data type for vectors");
+    uint64_t nbytes = 0;
+    if (__builtin_mul_overflow(n_vectors, (uint64_t)s->dimension * es, &nbytes)) return fail(MVF_ERR_INVALID_ARGUMENT, "n_vectors * dimension overflows");
+    try {
+        s->vectors.reserve((size_t)nbytes);
+    } catch (const std::exception&) {
+        return fail(MVF_ERR_IO, "I/O error: out of memory");
+    }
+    if (nbytes >= ((uint64_t)64 << 20)) {
+        const uintptr_t lo = (reinterpret_cast<uintptr_t>(s->vectors.data()) + ((1u << 21) - 1)) & ~(uintptr_t)((1u << 21) - 1);
+        const uintptr_t hi = (reinterpret_cast<uintptr_t>(s->vectors.data()) + s->vectors.capacity()) & ~(uintptr_t)((1u << 21) - 1);
+        if (hi > lo) (void)madvise(reinterpret_cast<void*>(lo), hi - lo, MADV_HUGEPAGE);  // advice only
+    }
     return MVF_OK;
 }
 

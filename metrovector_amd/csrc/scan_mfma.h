@@ -111,7 +111,7 @@ struct CompactParams {
 constexpr uint32_t kBatchCap = 4096;  // candidate slots per query between compactions (32 KiB of LDS to sort)
 
 size_t scan_mfma_lds_bytes();
-hipError_t launch_scan_mfma_f32(const BatchParams& p, int metric, int num_cus, hipStream_t s);
+hipError_t launch_scan_mfma_f32(const BatchParams& p, int metric, int num_cus, int force_persistent /* -1: the default grid */, hipStream_t s);
 hipError_t launch_prep_queries(const float* q, uint32_t nq, uint32_t nq_pad, uint32_t dim, uint32_t KP, float* qmat,
                                float* qnorm, hipStream_t s);
 hipError_t launch_row_norms_f32(const unsigned char* rows, uint32_t n, uint32_t pitch, float* xnorm, float* xx2,
@@ -145,11 +145,11 @@ hipError_t launch_refine_tau(const RescoreParams& p, int metric, uint32_t nq, co
                              const float* delta, hipStream_t s);
 
 uint32_t scan_mfma16_queries_per_block(int dtype);
-hipError_t launch_scan_mfma16(const Batch16Params& p, int dtype, int metric, int num_cus, hipStream_t s);
+hipError_t launch_scan_mfma16(const Batch16Params& p, int dtype, int metric, int num_cus, int force_persistent /* -1: per type */, hipStream_t s);
 // small batches (one tile of <= 64 queries): streaming kernel with MFMA dots (scan_mfma16_sb.hip)
 bool scan_mfma16_sb_usable(uint32_t nq_pad, uint32_t KT, uint32_t nq);
 hipError_t launch_scan_mfma16_sb(const Batch16Params& p, int dtype, int metric, int num_cus, hipStream_t s);
-uint32_t scan_mfma16_dma_queries_per_block(uint32_t nq);
+uint32_t scan_mfma16_dma_queries_per_block(uint32_t nq, int forced_tile = 0 /* MVF_K2_TILE */);
 uint32_t scan_mfma16_dma_tile_rows(uint32_t bmq);
 bool scan_mfma16_dma_wave_regions(int dtype, uint32_t bmq, bool direct, bool has_regions, uint32_t dim);
 hipError_t launch_scan_mfma16_dma(const Batch16Params& p, int dtype, int metric, int num_cus, uint32_t bmq, bool persistent,

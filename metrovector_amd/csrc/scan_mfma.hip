@@ -811,7 +811,7 @@ __global__ void __launch_bounds__(1024) rescore_select_kernel(RescoreParams p, i
 
 size_t scan_mfma_lds_bytes() { return kLdsBytes; }
 
-hipError_t launch_scan_mfma_f32(const BatchParams& p, int metric, int num_cus, hipStream_t s) {
+hipError_t launch_scan_mfma_f32(const BatchParams& p, int metric, int num_cus, int force_persistent, hipStream_t s) {
     // Grid: a multiple of 8 (one lane set per XCD).  The kernel is written persistent, but by default it is
     // launched with the FULL grid (every block owns exactly one tile): the dispatcher then starts the query
     // tiles of one corpus tile together, and the corpus tile is served from L2 to 7 of them (FETCH_SIZE 30 GB per
@@ -820,8 +820,7 @@ hipError_t launch_scan_mfma_f32(const BatchParams& p, int metric, int num_cus, h
     const uint32_t total = ((p.ntiles + 7) / 8) * p.mtiles * 8;
     uint32_t nls = std::max(1u, (uint32_t)num_cus * 2u / 8u);
     if (nls > p.mtiles) nls -= nls % p.mtiles;
-    bool persistent = false;
-    if (const char* e = getenv("MVF_K2_PERSISTENT")) persistent = atoi(e) != 0;
+    const bool persistent = force_persistent > 0;  // MVF_K2_PERSISTENT (read once per handle)
     const dim3 grid(persistent ? std::min(total, nls * 8u) : total);
     // > 64 KiB of dynamic LDS needs the attribute; it is per device, and one process may drive several devices
     const void* fn = metric == MVF_METRIC_COSINE ? reinterpret_cast<const void*>(&scan_mfma_f32_kernel<MVF_METRIC_COSINE>)

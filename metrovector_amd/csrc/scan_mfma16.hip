@@ -515,14 +515,14 @@ hipError_t launch_dt(const Batch16Params& p, int metric, dim3 grid, hipStream_t 
 
 uint32_t scan_mfma16_queries_per_block(int) { return 256u; }
 
-hipError_t launch_scan_mfma16(const Batch16Params& p, int dtype, int metric, int num_cus, hipStream_t s) {
+hipError_t launch_scan_mfma16(const Batch16Params& p, int dtype, int metric, int num_cus, int force_persistent, hipStream_t s) {
     // Grid: a multiple of 8 (one lane set per XCD).  Persistent (one block per CU, LDS-limited) or one tile per
     // block — the same kernel: with the full grid every block owns exactly one tile.
     const uint32_t total = ((p.ntiles + 7) / 8) * p.mtiles * 8;
     uint32_t nls = std::max(1u, (uint32_t)num_cus / 8u);
     if (nls > p.mtiles) nls -= nls % p.mtiles;
     bool persistent = dtype != MVF_DTYPE_FLOAT16;  // measured: int8 equal either way, f16 13 % faster with one tile per block
-    if (const char* e = getenv("MVF_K2_PERSISTENT16")) persistent = atoi(e) != 0;
+    if (force_persistent >= 0) persistent = force_persistent != 0;  // MVF_K2_PERSISTENT16 (read once per handle)
     const dim3 grid(persistent ? std::min(total, nls * 8u) : total);
     if (dtype == MVF_DTYPE_FLOAT16) return launch_dt<MVF_DTYPE_FLOAT16>(p, metric, grid, s);
     if (dtype == MVF_DTYPE_UINT8) return launch_dt<MVF_DTYPE_UINT8>(p, metric, grid, s);

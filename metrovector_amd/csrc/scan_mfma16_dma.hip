@@ -530,11 +530,8 @@ extern "C" int mvfgpu_diag_bias_counts(unsigned long long* out8, int reset) {
 
 // queries per block tile for a batch of nq: the 64-query tile (HBM-bound) up to 64 queries, the 128-query tile up to 128,
 // else the 256-query tile
-uint32_t scan_mfma16_dma_queries_per_block(uint32_t nq) {
-    if (const char* e = getenv("MVF_K2_TILE")) {
-        const int t = atoi(e);
-        return t == 64 ? 64u : t == 128 ? 128u : 256u;
-    }
+uint32_t scan_mfma16_dma_queries_per_block(uint32_t nq, int forced_tile) {
+    if (forced_tile) return forced_tile == 64 ? 64u : forced_tile == 128 ? 128u : 256u;  // MVF_K2_TILE
     return nq <= 64 ? 64u : nq <= 128 ? 128u : 256u;
 }
 

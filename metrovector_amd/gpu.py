@@ -194,6 +194,10 @@ class GpuCorpus:
     def set_scan_path(self, path: int) -> None:
         _lib.gpu_check(_lib.gpu().mvfgpu_set_scan_path(self._h, path))
 
+    def reload_tuning(self) -> None:
+        """Re-read the MVF_* tuning switches of the environment (they are read once, when the handle is created)."""
+        _lib.gpu_check(_lib.gpu().mvfgpu_corpus_reload_tuning(self._h))
+
 
 class ShardSet:
     """Several GPUs in ONE process (`mvfgpu_shardset_*`): per-shard searches on every device, one packed RCCL

@@ -2,7 +2,7 @@
 
 For each BASELINE batched config the same resident corpus is searched with the variants interleaved, several
 rounds each; prints wall ms per search (device-resident queries and results) and the last phase's scan ms.
-Variants are environment switches libmvf_gpu reads per call (MVF_K2_PP, MVF_K2_GROWTH, MVF_I8_SHADOW): see ALL_VARIANTS.
+Variants are environment switches libmvf_gpu reads per handle (re-read here with mvfgpu_corpus_reload_tuning) (MVF_K2_PP, MVF_K2_GROWTH, MVF_I8_SHADOW): see ALL_VARIANTS.
 usage: python scripts/probe_k2_ab.py [cfg4,cfg5,cfg3] [rounds] [variant,variant,...]
 """
 import os
@@ -94,6 +94,7 @@ def main():
                         os.environ.pop(ek, None)
                     else:
                         os.environ[ek] = ev
+                c.reload_tuning()  # the switches are read once per handle
                 c.set_profiling(True)
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()

@@ -14,6 +14,7 @@ for (n, dim, dt) in ((10_000_000, 768, 0), (10_000_000, 1024, 0), (12_500_000, 1
         out = []
         for sb in ("0", "1"):
             os.environ["MVF_K2_SB"] = sb
+            c.reload_tuning()
             for it in range(2):
                 torch.cuda.synchronize(); t0 = time.perf_counter()
                 for _ in range(5):

@@ -16,6 +16,7 @@ for dim in (512, 768, 1008, 1024, 1040, 1280, 2048):
     c.set_scan_path(2)
     for sb in ("0", "1"):
         os.environ["MVF_K2_SB"] = sb
+        c.reload_tuning()
         for it in range(2):
             torch.cuda.synchronize(); t0 = time.perf_counter()
             for _ in range(5):

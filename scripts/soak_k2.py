@@ -57,6 +57,7 @@ for (n, dim, dt, metric, nq) in CONFIGS:
     for i in range(REPS):
         ds.add(digest(c.search(q, 100, metric)))
     os.environ["MVF_K2_DMA"] = "0"
+    c.reload_tuning()
     ref = digest(c.search(q, 100, metric))
     del os.environ["MVF_K2_DMA"]
     ok = len(ds) == 1 and ref in ds

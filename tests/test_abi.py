@@ -118,3 +118,42 @@ def test_merge_topk_host_padding(oracle):
     assert (got.indices == wi).all()
     got = G.merge_topk_host(a[0][None], a[1][None], None, 0, 0)
     assert got.indices[0, 2] == np.uint64(0xFFFFFFFFFFFFFFFF) and got.scores[0, 2] == np.inf
+
+
+def test_abi_version_is_exported_and_checked_at_load():
+    lib = _lib.gpu()  # raises ImportError on a mismatch
+    assert lib.mvfgpu_abi_version() == _lib.ABI_VERSION
+    text = open(os.path.join(ROOT, "include", "mvf_gpu.h")).read()
+    assert int(re.search(r"#define MVFGPU_ABI_VERSION (\d+)u", text).group(1)) == _lib.ABI_VERSION
+
+
+def _feedback(samples):
+    a = np.asarray(samples, np.uint32).reshape(-1, 4)
+    out = np.zeros(4, np.uint32)
+    _lib.gpu_check(_lib.gpu().mvfgpu_selftest_feedback(a.ctypes.data_as(C.c_void_p), a.shape[0], out.ctypes.data_as(C.c_void_p)))
+    return dict(seen=int(out[0]), redone=int(out[1]), bias_off=bool(out[2]), qs_off=bool(out[3]))
+
+
+def test_repair_feedback_blames_the_prefilter_first_and_drops_its_stale_sample():
+    """The automatic path choice as a pure function of the sample sequence (no GPU): {queries, repaired, ran with the folded
+    pre-filter, selected on the int8 shadow}.  ADVICE r3: two searches are in flight, so when the first bad one switches
+    the pre-filter off, the NEXT sample consumed still comes from a search that ran with it -- it must not be counted
+    against the fresh totals (it used to switch the int8 selection off for good one search later)."""
+    bad_with_bias, good_without = [1024, 600, 1, 1], [1024, 0, 0, 1]
+    st = _feedback([bad_with_bias])
+    assert st == dict(seen=0, redone=0, bias_off=True, qs_off=False)
+    st = _feedback([bad_with_bias, bad_with_bias])            # the stale second sample is dropped
+    assert st == dict(seen=0, redone=0, bias_off=True, qs_off=False)
+    st = _feedback([bad_with_bias, bad_with_bias] + [good_without] * 5)
+    assert st["bias_off"] and not st["qs_off"] and st["redone"] == 0 and st["seen"] == 5 * 1024
+    # repairs that persist WITHOUT the pre-filter are the int8 bound's: the selection goes, as before
+    st = _feedback([bad_with_bias, bad_with_bias, [1024, 600, 0, 1]])
+    assert st["bias_off"] and st["qs_off"]
+    # a corpus that never used the pre-filter (Float16 rows on the f16 flavour, MVF_K2_BIAS=0): straight to the selection
+    assert _feedback([[1024, 600, 0, 1]]) == dict(seen=1024, redone=600, bias_off=False, qs_off=True)
+    # sane data: a handful of repairs in thousands of queries changes nothing, and old history fades (halving at 8192)
+    st = _feedback([[1024, 1, 1, 1]] * 20)
+    assert not st["bias_off"] and not st["qs_off"] and st["seen"] < 8192 + 1024
+    # fewer than four repairs never trigger, whatever the ratio (single streamed queries)
+    assert _feedback([[1, 1, 0, 1]] * 3) == dict(seen=3, redone=3, bias_off=False, qs_off=False)
+    assert _feedback([[1, 1, 0, 1]] * 4)["qs_off"]

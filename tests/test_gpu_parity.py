@@ -449,8 +449,10 @@ def test_batched_register_staged_reference_kernel_agrees(oracle, dtype, metric, 
     with G.GpuCorpus.from_array(rows) as c:
         c.set_scan_path(3)
         monkeypatch.setenv("MVF_K2_DMA", "0")
+        c.reload_tuning()   # the switches are read once per handle, at creation
         ref = c.search(q, k, metric)
         monkeypatch.delenv("MVF_K2_DMA")
+        c.reload_tuning()
         res = c.search(q, k, metric)
     assert (res.indices == ref.indices).all()
     assert (res.scores.view(np.uint32) == ref.scores.view(np.uint32)).all()

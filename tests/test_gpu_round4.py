@@ -105,8 +105,10 @@ def test_multi_gb_mvf_file_open_upload_search(oracle, tmp_path):
         b = MvfBuilder()
         b.add_vector_space("big", dim, VectorType.Dense, DistanceMetric.Cosine, DataType.Float32)
         b.add_vector_space("small_i8", dim8, VectorType.Dense, DistanceMetric.InnerProduct, DataType.Int8)
+        b.reserve_vectors("big", n)
+        buf = np.empty((250_000, dim), np.float32)
         for r0 in range(0, n, 250_000):
-            b.add_vectors_raw("big", oracle.synth_rows(SEED, r0, min(250_000, n - r0), dim, 0))
+            b.add_vectors_raw("big", oracle.synth_rows(SEED, r0, min(250_000, n - r0), dim, 0, out=buf))
         rows8 = oracle.synth_rows(SEED + 7, 0, n8, dim8, 2)
         b.add_vectors_raw("small_i8", rows8)
         b.build().save(path)

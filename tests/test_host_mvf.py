@@ -236,6 +236,58 @@ def test_crc_and_half_helpers():
         assert h.mvf_f32_to_f16(x) == int(np.float32(x).astype(np.float16).view(np.uint16))
 
 
+def test_crc_of_large_blocks_is_threaded_and_still_the_ieee_crc():
+    """Blocks of 8 MiB and more are hashed in one segment per host thread and joined with the GF(2) append operator: the
+    result must stay crc32fast::hash (src/builder.rs:251) at every size / alignment / thread count."""
+    import binascii
+    import ctypes
+    h = _lib.host()
+    rng = np.random.default_rng(5)
+    base = rng.integers(0, 256, (24 << 20) + 77, dtype=np.uint8)
+    for n in (0, 1, 7, 8, 9, 4097, (8 << 20) - 1, 8 << 20, (8 << 20) + 3, (24 << 20) + 70):
+        for off in (0, 1, 5):
+            a = base[off:off + n]
+            assert h.mvf_crc32(ctypes.c_void_p(a.ctypes.data), a.size) == binascii.crc32(a.tobytes()), (n, off)
+    for threads in ("1", "3", "7", "16"):
+        os.environ["MVF_CRC_THREADS"] = threads
+        try:
+            assert h.mvf_crc32(ctypes.c_void_p(base.ctypes.data), base.size) == binascii.crc32(base.tobytes())
+        finally:
+            del os.environ["MVF_CRC_THREADS"]
+
+
+def test_streamed_save_equals_to_bytes_and_reserve_does_not_change_the_image(tmp_path):
+    """BuiltMvf::save (builder.rs:408-411) writes the blocks as they lie in the builder instead of assembling a second
+    copy of the image: the file must be to_bytes() byte for byte; reserve_vectors (extension) must not show in it."""
+    rng = np.random.default_rng(9)
+    rows = rng.standard_normal((1000, 48)).astype(np.float32)
+    rows8 = rng.integers(-128, 128, (333, 17)).astype(np.int8)
+    imgs = []
+    for reserve in (False, True):
+        b = MvfBuilder()
+        b.add_vector_space("a", 48, VectorType.Dense, DistanceMetric.Cosine, DataType.Float32)
+        b.add_vector_space("b", 17, VectorType.Dense, DistanceMetric.InnerProduct, DataType.Int8)
+        if reserve:
+            b.reserve_vectors("a", 5000)
+            b.reserve_vectors("b", 10)
+        for r0 in range(0, 1000, 300):
+            b.add_vectors_raw("a", rows[r0:r0 + 300])
+        b.add_vectors_raw("b", rows8)
+        b.set_vector_ids("b", np.arange(333, dtype=np.uint64) * 3)
+        b.add_metadata_column("col", DataType.UInt32, b"\x01\x02\x03\x04")
+        built = b.build()
+        path = tmp_path / f"s{int(reserve)}.mvf"
+        built.save(path)
+        assert path.read_bytes() == built.to_bytes()
+        imgs.append(path.read_bytes())
+    assert imgs[0] == imgs[1]
+    with pytest.raises(E.VectorSpaceNotFound):
+        MvfBuilder().reserve_vectors("nope", 1)
+    with MvfReader.open(tmp_path / "s1.mvf") as r:
+        r.validate_with_checksum()
+        assert (r.vector_space("a").map_vector_range(0, 1000).to_numpy(48) == rows).all()
+
+
 def test_reader_survives_corrupted_footers():
     """Untrusted input: random byte flips / truncations / splices in the footer region must give an MvfError
     (or a still-valid file), never a crash or an out-of-bounds read (the same loop runs under ASan in CI notes)."""

@@ -47,10 +47,8 @@ def _worker(rank, world, port, dtype, metric, n, dim, nq, k, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("dtype,metric,n,k", [(0, 2, 5000, 100), (2, 1, 3001, 64), (1, 0, 40, 100), (3, 0, 999, 10)])
-def test_two_rank_gloo_merge_equals_global(oracle, dtype, metric, n, k):
+def _run_world(oracle, world, dtype, metric, n, k, dim=32, nq=3):
     import torch.multiprocessing as mp
-    dim, nq, world = 32, 3, 2
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
@@ -59,13 +57,35 @@ def test_two_rank_gloo_merge_equals_global(oracle, dtype, metric, n, k):
     q = ctx.Queue()
     procs = [ctx.Process(target=_worker, args=(r, world, port, dtype, metric, n, dim, nq, k, q)) for r in range(world)]
     [p.start() for p in procs]
-    outs = [q.get(timeout=120) for _ in range(world)]
+    outs = [q.get(timeout=180) for _ in range(world)]
     [p.join(timeout=60) for p in procs]
     assert all(p.exitcode == 0 for p in procs)
     rows = oracle.synth_rows(123, 0, n, dim, dtype)
     queries = oracle.synth_queries(124, nq, dim, dtype)
     ws, wi, wr = oracle.search(rows, dtype, metric, queries, k)
+    assert sorted(o[0] for o in outs) == list(range(world))
     for _, sc, idx, raw in outs:   # every rank holds the same, global answer
         assert (idx == wi).all()
         assert (sc.view(np.uint32) == ws.view(np.uint32)).all()
         assert (raw == wr).all()
+
+
+@pytest.mark.parametrize("dtype,metric,n,k", [(0, 2, 5000, 100), (2, 1, 3001, 64), (1, 0, 40, 100), (3, 0, 999, 10)])
+def test_two_rank_gloo_merge_equals_global(oracle, dtype, metric, n, k):
+    _run_world(oracle, 2, dtype, metric, n, k)
+
+
+@pytest.mark.parametrize("world,dtype,metric,n,k", [
+    (3, 0, 2, 5000, 100),   # N not divisible by the world (1667 + 1667 + 1666)
+    (3, 2, 1, 2, 5),        # N < world: shard_range gives the last rank lo == hi (an EMPTY shard), k > N pads
+    (8, 1, 0, 1003, 50),    # eight ranks (the node's shape), ragged last shard
+    (8, 3, 0, 5, 8),        # eight ranks, five rows: three empty tail shards, k > rows
+])
+def test_wider_worlds_ragged_and_empty_shards(oracle, world, dtype, metric, n, k):
+    """The N>1 protocol at the world sizes the node has: shard_range when N is no multiple of the
+    world and when it is smaller (empty tail shards contribute padding-only lists), merged == global on every rank."""
+    from metrovector_amd.sharded import shard_range
+    ranges = [shard_range(n, world, r) for r in range(world)]
+    if n < world:
+        assert any(lo == hi for lo, hi in ranges)
+    _run_world(oracle, world, dtype, metric, n, k)
