@@ -24,7 +24,14 @@ Third leg at EVERY N, `shardset` (what a Rust host binds, include/mvf_gpu.h mvfg
 handles on N devices, the same cfg5 shard shape per device, per-shard searches + one grouped RCCL all-gather + merge
 inside the library; run by rank 0 in a child process after the ranks have released their GPUs.
 
-N = 1 also: `cfg4_int8` (BASELINE.json configs[3]: 50M x 768 Int8 dot, 256 batched queries, top-100; both the HBM and the
+Fourth leg at EVERY N, `cfg5_strong`: STRONG scaling of the same config -- ONE fixed 100M x 1024 Float16 corpus (204.8 GB:
+it fits one MI355X without a selection shadow) split by row range over the N ranks, value = 1024 * 100M / t at every N, so
+value(N) / value(1) is north_star's ">= 6x at 8 GPUs vs 1".  A 204.8 GB shard has no room for the int8 shadow the smaller
+shards select on, so the leg also runs with the f16 selection forced on every rank (`f16_selection_at_every_n`): that
+pair of numbers compares like with like.
+
+N = 1 also: `mvf_file_e2e` (a real 4.6 GB two-space .mvf: write, open, upload off the mmap cold and warm, checksum,
+search), `cfg4_int8` (BASELINE.json configs[3]: 50M x 768 Int8 dot, 256 batched queries, top-100; both the HBM and the
 int8-MFMA fraction of the whole search) and `cfg1` (configs[0]: 10k x 128 f32 L2 top-10, the faithful CPU restatement
 timed in full beside the GPU's time for the same search).
 
@@ -107,6 +114,9 @@ def parse_args():
     ap.add_argument("--no-batched", action="store_true", help="skip the extra q=1024 legs of the default N=1 run")
     ap.add_argument("--no-cfg5", action="store_true", help="skip the cfg5_sharded leg")
     ap.add_argument("--no-shardset", action="store_true", help="skip the single-process shard-set leg")
+    ap.add_argument("--no-strong", action="store_true", help="skip the strong-scaling leg (cfg5_strong)")
+    ap.add_argument("--strong-rows", type=int, default=100_000_000,
+                    help="rows of the FIXED 1024-dim f16 corpus the strong-scaling leg splits over the ranks (BASELINE configs[4]: 100M)")
     ap.add_argument("--no-cfg4", action="store_true", help="skip the cfg4_int8 leg (N = 1)")
     ap.add_argument("--no-cfg1", action="store_true", help="skip the cfg1 block (N = 1)")
     ap.add_argument("--no-file", action="store_true", help="skip the mvf_file_e2e leg (N = 1)")
@@ -371,7 +381,11 @@ def self_launch(args):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
            "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ)
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL across processes needs it on this host driver
+    # dmabuf IPC.  The pool's environment notes say its host driver supports only dmabuf IPC and that RCCL / device-tensor
+    # sharing across processes fails with "hipIpcGetMemHandle: invalid argument" without this setting, and export it on
+    # every box already; kept here (setdefault: a no-op there) for a launch from a bare shell.  NOT verified by this repo:
+    # a one-GPU box cannot run two RCCL processes.
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.setdefault("OMP_NUM_THREADS", "4")
     proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
     for line in proc.stdout:  # the contract is ONE JSON line on stdout: anything else the ranks print goes to stderr
@@ -810,6 +824,9 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
+            "value_timed_region": "query already on the device -> kernels + on-device top-k (+ all-gather and merge at N > 1) -> "
+                                  "results left on the device; the query's H2D copy and the results' D2H copy of SURVEY.md "
+                                  "§8(d)'s region are NOT in `value` -- `host_api` is the same search including both (+0.5 %)",
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -827,6 +844,8 @@ def main():
         }
         if rehearsal:
             result["rehearsal"] = rehearsal
+        if world > 1:
+            result["cpu_baseline_note"] = "cpu_baseline, recall of the headline and the N = 1 legs are reported by the --gpus 1 run only"
         # ---- roofline of the dominant kernel (rank 0's shard) ---------------------------
         alg_bytes = float(args.rows) * args.dim * es  # N*d*es per launch
         if tm.samples and tm.scan_ms_avg > 0 and tm.scan_kernel >= 2:
@@ -1011,6 +1030,21 @@ def main():
             if rehearsal:
                 leg["rehearsal"] = rehearsal
             result["cfg5_sharded"] = leg
+
+    # ---- the same config as STRONG scaling, every N: ONE fixed 100M x 1024 f16 corpus split by row range over the ranks --
+    if not args.no_strong:
+        torch.cuda.empty_cache()
+        try:
+            leg = cfg5_sharded_leg(args, rank, local_rank, world, backend, dist, torch, G, ShardedSearcher, _lib,
+                                   total_rows=args.strong_rows)
+        except Exception as e:  # e.g. a device too small for its share: the line keeps its other legs
+            if world > 1:
+                raise
+            leg = {"error": f"{type(e).__name__}: {e}"[:400]}
+        if rank == 0:
+            if rehearsal:
+                leg["rehearsal"] = rehearsal
+            result["cfg5_strong"] = leg
 
     # ---- context for the MFMA fractions above: what the vendor GEMM library holds on THIS box (best case, 8192^3) --------
     if rank == 0 and world == 1 and not args.no_batched:

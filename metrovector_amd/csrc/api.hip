@@ -18,7 +18,6 @@
 #include <cstring>
 #include <mutex>
 #include <string>
-#include <sys/mman.h>
 #include <thread>
 #include <vector>
 
@@ -106,7 +105,6 @@ Tuning read_tuning() {
     t.stream_i8 = flag("MVF_STREAM_I8", false);
     t.stream_shadow = flag("MVF_STREAM_SHADOW", false);
     t.upload_threads = (unsigned)std::max(0l, num("MVF_UPLOAD_THREADS", 0));
-    t.upload_advise = flag("MVF_UPLOAD_ADVISE", true);
     return t;
 }
 }  // namespace mvf
@@ -1393,25 +1391,12 @@ int upload_rows(mvfgpu_corpus* c, const void* rows, uint64_t stride, const mvfgp
     unsigned threads = std::min(8u, std::max(1u, std::thread::hardware_concurrency()));
     if (c->tune.upload_threads) threads = c->tune.upload_threads;
 
-    // Rows handed over straight off an mmap'd .mvf (VectorSpace::map_vector_range, src/vectors/vector_space.rs:155-188): with
-    // a cold page cache the copy threads' page faults read the file in readahead-sized pieces, one synchronous read per
-    // fault.  MADV_WILLNEED on the chunks AHEAD of the copy queues those reads as large asynchronous ones (advice only:
-    // harmless on anonymous memory, and errors are ignored).  MVF_UPLOAD_ADVISE=0 switches it off (A/B runs).
-    const uint64_t advise_ahead = (pinned && c->tune.upload_advise) ? 3 : 0;
-    auto advise = [&](uint64_t chunk) {
-        const uint64_t r0 = chunk * chunk_rows;
-        if (r0 >= n) return;
-        const uint64_t h = std::min(chunk_rows, n - r0);
-        const uintptr_t lo = reinterpret_cast<uintptr_t>(src + r0 * stride) & ~(uintptr_t)4095;
-        const uintptr_t hi = (reinterpret_cast<uintptr_t>(src + r0 * stride) + (h - 1) * stride + row_bytes + 4095) & ~(uintptr_t)4095;
-        (void)madvise(reinterpret_cast<void*>(lo), hi - lo, MADV_WILLNEED);
-    };
-    for (uint64_t a = 0; a < advise_ahead; a++) advise(a);
-
+    // (Rows handed over straight off an mmap'd .mvf: with the page cache warm the copy threads' minor faults cost nothing
+    // measurable -- 52 GB/s, the same as anonymous memory; cold, the file's device sets the rate, and MADV_WILLNEED on the
+    // chunks ahead of the copy changed nothing (profiles/r04_upload_from_mmap.txt), so there is no readahead code here.)
     uint64_t i = 0;
     for (uint64_t r0 = 0; r0 < n; r0 += chunk_rows, i++) {
         const int b = (int)(i & 1);
-        if (advise_ahead) advise(i + advise_ahead);
         const uint64_t h = std::min(chunk_rows, n - r0);
         const uint64_t span = (h - 1) * stride + row_bytes;
         unsigned char* place = c->d_rows + r0 * c->pitch;

@@ -46,7 +46,6 @@ struct Tuning {
     bool stream_i8 = false;     // MVF_STREAM_I8=1
     bool stream_shadow = false; // MVF_STREAM_SHADOW=1
     unsigned upload_threads = 0;  // MVF_UPLOAD_THREADS
-    bool upload_advise = true;    // MVF_UPLOAD_ADVISE=0: no MADV_WILLNEED ahead of the upload's copy threads
 };
 Tuning read_tuning();
 

@@ -1,0 +1,367 @@
+// probe_k2_w1.hip -- the k-loop of the int8 K2 kernel (scan_mfma16_dma.hip: LDS-DMA ring, v_mfma_i32_16x16x64_i8, 256 queries
+// x 256 corpus rows per block tile, 64-byte k-tiles, persistent XCD-aware blocks) in TWO wave structures, nothing else:
+//
+//   W8: 8 waves per block (2 x 4), wave tile 128 queries x 64 rows  = the shipped structure, two waves per SIMD:
+//       per k-tile a wave reads 8 A + 4 B fragments (12 KB) for 32 MFMAs -> 96 KB of LDS reads per CU and k-tile;
+//   W4: 4 waves per block (2 x 2), wave tile 128 x 128, ONE wave per SIMD on 512 registers (256 accumulators):
+//       per k-tile a wave reads 8 A + 8 B fragments (16 KB) for 64 MFMAs -> 64 KB per CU and k-tile (a third fewer);
+//   W4P: W4 with the barrier moved to the middle of the k-tile and the next k-tile's B fragments read under the second
+//       half of this one's MFMAs (one wave per SIMD has no partner to hide the fragment latency behind).
+//
+// DESIGN.md §10.1 named W4 for two rounds as "the one structure not built"; VERDICT r3 item 4 asks for it or for the
+// counters that close it.  The epilogue is replaced by a checksum (every accumulator is summed into one word per lane at
+// the end of a tile), so the three variants do the same arithmetic and their totals must agree with each other and with
+// the host's (sum_q q) . (sum_r r).
+//
+// build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -o scripts/bin/probe_k2_w1 scripts/probe_k2_w1.hip
+// run:   scripts/bin/probe_k2_w1 [rows=50000000] [dim=768] [nq=256] [reps=5] [variants=8,4,4p]
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+typedef int32_t i32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* glb_ptr_t;
+
+#define HIP_OK(x)                                                                      \
+    do {                                                                               \
+        hipError_t e_ = (x);                                                           \
+        if (e_ != hipSuccess) {                                                        \
+            fprintf(stderr, "%s:%d %s: %s\n", __FILE__, __LINE__, #x, hipGetErrorString(e_)); \
+            exit(1);                                                                   \
+        }                                                                              \
+    } while (0)
+
+struct P {
+    const unsigned char* rows;   // [n][pitch] int8
+    const unsigned char* qprep;  // [nq][KPB] int8 (KPB = KT * 64)
+    const unsigned char* zeros;  // >= 16 zero bytes
+    uint32_t* out;               // [grid][threads] checksums
+    uint32_t n, pitch, V, KT, KPB, ntiles, mtiles;
+};
+
+constexpr int DKB = 64, BMQ = 256, BR = 256, NSTAGE = 4, SH = 16;
+constexpr int A_B = BMQ * DKB, STAGE_B = A_B + BR * DKB;  // 32 KB
+constexpr size_t LDS_BYTES = (size_t)NSTAGE * STAGE_B;
+
+__device__ __forceinline__ uint32_t slot_swz(uint32_t x) { return (0x78u >> (2u * x)) & 3u; }
+
+// s_waitcnt with vmcnt = v (6 bits: [3:0] and [15:14]), expcnt / lgkmcnt as given
+constexpr int waitcnt_imm(int vm, int lgkm) { return (vm & 0xF) | ((vm >> 4) << 14) | 0x0070 | ((lgkm & 0xF) << 8); }
+
+template <int NW, bool PIPE>
+__global__ void __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) kloop_kernel(P p) {
+    constexpr int WN = NW == 8 ? 4 : 2;              // waves along the rows; 2 along the queries
+    constexpr int WQ = 128, WR = BR / WN;            // wave tile
+    constexpr int NI = WQ / SH, NJ = WR / SH;        // 8 x 4 or 8 x 8 MFMA sub-tiles
+    constexpr int APW = BMQ / 16 / NW, BPW = BR / 16 / NW, PIECES = APW + BPW;  // 1-KB DMA pieces per wave and k-tile (4 or 8)
+    constexpr int INFLIGHT = PIECES * (NSTAGE - 2);
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+
+    const uint32_t xcd = blockIdx.x & 7u, ls = blockIdx.x >> 3, nls = gridDim.x >> 3;
+    auto slot_tile = [&](uint32_t n, uint32_t& nt, uint32_t& mt) {
+        const uint32_t slot = ls + n * nls;
+        nt = (slot / p.mtiles) * 8u + xcd;
+        mt = slot % p.mtiles;
+    };
+    uint32_t my_tiles = 0;
+    {
+        const uint32_t max_slot_excl = ((p.ntiles + 7u - xcd) / 8u) * p.mtiles;
+        if (ls < max_slot_excl) my_tiles = (max_slot_excl - ls + nls - 1) / nls;
+    }
+    if (my_tiles == 0) return;
+    const uint32_t G = my_tiles * p.KT;
+
+    const uint32_t rl = (uint32_t)lane >> 2;
+    const uint32_t cl = ((uint32_t)lane & 3u) ^ slot_swz(((uint32_t)lane >> 4) & 3u);
+    uint32_t d_n = 0, d_kt = 0;
+    const unsigned char* a_src[APW];
+    const unsigned char* b_src[BPW];
+    auto set_dma_tile = [&](uint32_t n) {
+        uint32_t nt, mt;
+        slot_tile(n, nt, mt);
+        const uint32_t r0 = nt * BR;
+#pragma unroll
+        for (int j = 0; j < APW; j++) a_src[j] = p.qprep + ((size_t)mt * BMQ + ((uint32_t)wave * APW + j) * 16u + rl) * p.KPB + cl * 16u;
+#pragma unroll
+        for (int j = 0; j < BPW; j++) {
+            const uint32_t r = r0 + ((uint32_t)wave * BPW + j) * 16u + rl;
+            b_src[j] = p.rows + (size_t)(r < p.n ? r : r0) * p.pitch;
+        }
+    };
+    auto dma_piece = [&](uint32_t stage, int piece) __attribute__((always_inline)) {
+        unsigned char* st = smem + stage * STAGE_B;
+        if (piece < APW) {
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)(a_src[piece] + (size_t)d_kt * DKB), (lds_ptr_t)(st + (wave * APW + piece) * (16 * DKB)), 16, 0, 0);
+        } else {
+            const int j = piece - APW;
+            const uint32_t v = d_kt * 4u + cl;
+            const unsigned char* src = v < p.V ? b_src[j] + (size_t)v * 16u : p.zeros;
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)(st + A_B + (wave * BPW + j) * (16 * DKB)), 16, 0, 0);
+        }
+    };
+    auto dma_advance = [&]() __attribute__((always_inline)) {
+        if (++d_kt == p.KT) {
+            d_kt = 0;
+            if (++d_n < my_tiles) set_dma_tile(d_n);
+        }
+    };
+
+    i32x4 acc[NI][NJ];
+#pragma unroll
+    for (int i = 0; i < NI; i++)
+#pragma unroll
+        for (int j = 0; j < NJ; j++) acc[i][j] = i32x4{0, 0, 0, 0};
+    uint32_t check = 0;
+
+    set_dma_tile(0);
+#pragma unroll
+    for (int st = 0; st < NSTAGE - 1; st++) {
+#pragma unroll
+        for (int piece = 0; piece < PIECES; piece++) dma_piece(st, piece);
+        dma_advance();
+    }
+    __builtin_amdgcn_s_waitcnt(waitcnt_imm(INFLIGHT, 15));
+    __syncthreads();
+
+    const uint32_t frow = (uint32_t)lane & (SH - 1), fchunk = (uint32_t)lane >> 4;
+    const uint32_t fslot = (fchunk ^ slot_swz((frow >> 2) & 3u)) & 3u;
+    const uint32_t a_off = ((uint32_t)wm * WQ + frow) * DKB + fslot * 16u;
+    const uint32_t b_off = A_B + ((uint32_t)wn * WR + frow) * DKB + fslot * 16u;
+    auto read_a = [&](const unsigned char* st, int i) __attribute__((always_inline)) -> u32x4 {
+        return *reinterpret_cast<const u32x4*>(st + a_off + i * SH * DKB);
+    };
+    auto read_b = [&](const unsigned char* st, int j) __attribute__((always_inline)) -> u32x4 {
+        return *reinterpret_cast<const u32x4*>(st + b_off + j * SH * DKB);
+    };
+    auto mfma1 = [&](i32x4& c, const u32x4& fa, const u32x4& fb) __attribute__((always_inline)) {
+        c = __builtin_amdgcn_mfma_i32_16x16x64_i8(__builtin_bit_cast(i32x4, fa), __builtin_bit_cast(i32x4, fb), c, 0, 0, 0);
+    };
+    auto tile_end = [&]() __attribute__((always_inline)) {  // stands in for the epilogue: fold and clear the accumulators
+#pragma unroll
+        for (int i = 0; i < NI; i++)
+#pragma unroll
+            for (int j = 0; j < NJ; j++) {
+                check += (uint32_t)(acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3]);
+                acc[i][j] = i32x4{0, 0, 0, 0};
+            }
+    };
+
+    uint32_t cs = 0, ds = NSTAGE - 1;
+    // (a conditional reset of the accumulators inside the loop made the compiler shuffle all 256 through copies, and a
+    // per-tile fold spilled: the accumulators run on over the block's tiles and are folded once, behind the loop)
+    if constexpr (!PIPE) {
+        {
+            for (uint32_t g = 0; g < G; g++) {
+                const unsigned char* st = smem + cs * STAGE_B;
+                u32x4 fb[NJ], fa[2];
+#pragma unroll
+                for (int j = 0; j < NJ; j++) fb[j] = read_b(st, j);
+                fa[0] = read_a(st, 0);
+#pragma unroll
+                for (int i = 0; i < NI; i++) {
+                    if (i + 1 < NI) fa[(i + 1) & 1] = read_a(st, i + 1);
+#pragma unroll
+                    for (int j = 0; j < NJ; j++) mfma1(acc[i][j], fa[i & 1], fb[j]);
+                    if (PIECES == 8) dma_piece(ds, i);
+                    else if ((i & 1) == 0) dma_piece(ds, i / 2);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                dma_advance();
+                cs = cs + 1 == NSTAGE ? 0 : cs + 1;
+                ds = ds + 1 == NSTAGE ? 0 : ds + 1;
+                __builtin_amdgcn_s_waitcnt(waitcnt_imm(INFLIGHT, 0));
+                asm volatile("" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+            }
+        }
+    } else {
+        // one barrier per k-tile, in the MIDDLE: [groups 0..3 of k-tile g on the fragments read during k-tile g-1]
+        // wait(k-tile g+1 landed) barrier [groups 4..7, reading k-tile g+1's B fragments and first A fragment underneath;
+        // DMA of k-tile g+3 into the stage k-tile g-1 used: every wave is past its reads of that stage at this barrier]
+        u32x4 fbc[NJ], fa[2];
+#pragma unroll
+        for (int j = 0; j < NJ; j++) fbc[j] = read_b(smem, j);
+        fa[0] = read_a(smem, 0);
+        {
+            for (uint32_t g = 0; g < G; g++) {
+                const unsigned char* st = smem + cs * STAGE_B;
+                const uint32_t ns = cs + 1 == NSTAGE ? 0 : cs + 1;
+                const unsigned char* stn = smem + ns * STAGE_B;
+                u32x4 fbn[NJ];
+#pragma unroll
+                for (int i = 0; i < NI; i++) {
+                    if (i == NI / 2) {
+                        __builtin_amdgcn_s_waitcnt(waitcnt_imm(PIECES, 15));  // k-tile g+1's pieces have landed; only k-tile g+2's may still be in flight
+                        asm volatile("" ::: "memory");
+                        __builtin_amdgcn_s_barrier();
+                        asm volatile("" ::: "memory");
+                    }
+                    if (i + 1 < NI) fa[(i + 1) & 1] = read_a(st, i + 1);
+                    else fa[(i + 1) & 1] = read_a(stn, 0);  // the next k-tile's first A fragment
+                    if (i >= NI / 2) {  // the next k-tile's B fragments, two per group
+#pragma unroll
+                        for (int j = 0; j < NJ / (NI / 2); j++) fbn[(i - NI / 2) * (NJ / (NI / 2)) + j] = read_b(stn, (i - NI / 2) * (NJ / (NI / 2)) + j);
+                    }
+#pragma unroll
+                    for (int j = 0; j < NJ; j++) mfma1(acc[i][j], fa[i & 1], fbc[j]);
+                    if (i >= NI / 2) {  // all of the k-tile's DMA pieces behind the barrier, two per group
+                        dma_piece(ds, 2 * (i - NI / 2));
+                        dma_piece(ds, 2 * (i - NI / 2) + 1);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+                for (int j = 0; j < NJ; j++) fbc[j] = fbn[j];
+                dma_advance();
+                cs = ns;
+                ds = ds + 1 == NSTAGE ? 0 : ds + 1;
+            }
+        }
+    }
+    tile_end();  // the sums simply run on over the block's tiles (mod 2^32): the k-loop alone is what is timed here
+    __builtin_amdgcn_s_waitcnt(waitcnt_imm(0, 0));
+    p.out[(size_t)blockIdx.x * (NW * 64) + tid] = check;
+}
+
+static uint64_t mix64(uint64_t z) {
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+__global__ void fill_kernel(unsigned char* p, size_t n, uint64_t seed) {
+    size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 8;
+    const size_t stride = (size_t)gridDim.x * blockDim.x * 8;
+    for (; i + 8 <= n; i += stride) {
+        uint64_t z = seed + i;
+        z += 0x9E3779B97F4A7C15ull;
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        z ^= z >> 31;
+        *reinterpret_cast<uint64_t*>(p + i) = z;
+    }
+}
+
+__global__ void colsum_kernel(const unsigned char* rows, uint32_t n, uint32_t pitch, uint32_t dim, long long* out) {
+    // out[d] += sum over this block's rows of (int8) rows[r][d]
+    const uint32_t d = threadIdx.x + blockIdx.y * blockDim.x;
+    if (d >= dim) return;
+    long long s = 0;
+    for (uint32_t r = blockIdx.x; r < n; r += gridDim.x) s += (signed char)rows[(size_t)r * pitch + d];
+    atomicAdd(reinterpret_cast<unsigned long long*>(out + d), (unsigned long long)s);
+}
+
+int main(int argc, char** argv) {
+    const uint32_t n = (argc > 1 ? (uint32_t)atoll(argv[1]) : 50000000u) / BR * BR;  // whole block tiles (the checksum counts every output)
+    const uint32_t dim = argc > 2 ? (uint32_t)atoi(argv[2]) : 768u;
+    const uint32_t nq = argc > 3 ? (uint32_t)atoi(argv[3]) : 256u;
+    const int reps = argc > 4 ? atoi(argv[4]) : 5;
+    const std::string variants = argc > 5 ? argv[5] : "8,4,4p";
+    if (nq % BMQ || dim % 16) {
+        fprintf(stderr, "nq must be a multiple of 256, dim of 16\n");
+        return 2;
+    }
+    P p{};
+    p.n = n;
+    p.pitch = dim;
+    p.V = dim / 16;
+    p.KT = (dim + DKB - 1) / DKB;
+    p.KPB = p.KT * DKB;
+    p.ntiles = (n + BR - 1) / BR;
+    p.mtiles = nq / BMQ;
+    unsigned char *rows, *q, *zeros;
+    HIP_OK(hipMalloc(&rows, (size_t)n * dim));
+    HIP_OK(hipMalloc(&q, (size_t)nq * p.KPB));
+    HIP_OK(hipMalloc(&zeros, 256));
+    HIP_OK(hipMemset(zeros, 0, 256));
+    HIP_OK(hipMemset(q, 0, (size_t)nq * p.KPB));
+    fill_kernel<<<4096, 256>>>(rows, (size_t)n * dim, 1234567);
+    std::vector<signed char> hq((size_t)nq * p.KPB, 0);
+    for (uint32_t i = 0; i < nq; i++)
+        for (uint32_t d = 0; d < dim; d++) hq[(size_t)i * p.KPB + d] = (signed char)(mix64(77 + (uint64_t)i * dim + d) >> 56);
+    HIP_OK(hipMemcpy(q, hq.data(), hq.size(), hipMemcpyHostToDevice));
+    p.rows = rows;
+    p.qprep = q;
+    p.zeros = zeros;
+    int num_cus = 256;
+    {
+        hipDeviceProp_t prop;
+        HIP_OK(hipGetDeviceProperties(&prop, 0));
+        num_cus = prop.multiProcessorCount;
+    }
+    // expected total: sum_d (sum_q q[d]) * (sum_r x[d])  (mod 2^32)
+    long long* colsum;
+    HIP_OK(hipMalloc(&colsum, (size_t)dim * 8));
+    HIP_OK(hipMemset(colsum, 0, (size_t)dim * 8));
+    colsum_kernel<<<dim3(2048, (dim + 255) / 256), 256>>>(rows, n, dim, dim, colsum);
+    std::vector<long long> hx(dim);
+    HIP_OK(hipMemcpy(hx.data(), colsum, (size_t)dim * 8, hipMemcpyDeviceToHost));
+    uint32_t want = 0;
+    for (uint32_t d = 0; d < dim; d++) {
+        long long sq = 0;
+        for (uint32_t i = 0; i < nq; i++) sq += hq[(size_t)i * p.KPB + d];
+        want += (uint32_t)((unsigned long long)sq * (unsigned long long)hx[d]);
+    }
+    const uint32_t total = ((p.ntiles + 7) / 8) * p.mtiles * 8;
+    uint32_t nls = std::max(1u, (uint32_t)num_cus / 8u);
+    if (nls > p.mtiles) nls -= nls % p.mtiles;
+    const uint32_t grid = std::min(total, nls * 8u);
+    HIP_OK(hipMalloc(&p.out, (size_t)grid * 512 * 4));
+    printf("rows %u x %u int8, %u queries: %u x %u block tiles of 256 x 256, %u k-tiles, grid %u; %.2f GB of rows, %.3e ops\n", n, dim, nq,
+           p.ntiles, p.mtiles, p.KT, grid, (double)n * dim / 1e9, 2.0 * nq * (double)n * dim);
+    hipEvent_t e0, e1;
+    HIP_OK(hipEventCreate(&e0));
+    HIP_OK(hipEventCreate(&e1));
+    struct V {
+        const char* name;
+        void (*fn)(P);
+        int threads;
+    };
+    std::vector<V> vs;
+    for (size_t a = 0; a <= variants.size();) {
+        size_t b = variants.find(',', a);
+        if (b == std::string::npos) b = variants.size();
+        const std::string t = variants.substr(a, b - a);
+        if (t == "8") vs.push_back({"W8  (8 waves, 128x64, two per SIMD; shipped)", &kloop_kernel<8, false>, 512});
+        if (t == "4") vs.push_back({"W4  (4 waves, 128x128, one per SIMD)", &kloop_kernel<4, false>, 256});
+        if (t == "4p") vs.push_back({"W4P (W4 + mid-tile barrier, fragments prefetched)", &kloop_kernel<4, true>, 256});
+        a = b + 1;
+    }
+    for (auto& v : vs) HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(v.fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
+    for (int round = 0; round < 2; round++) {  // interleaved: the boxes' clocks drift
+        for (auto& v : vs) {
+            HIP_OK(hipMemset(p.out, 0, (size_t)grid * 512 * 4));
+            hipLaunchKernelGGL(v.fn, dim3(grid), dim3(v.threads), LDS_BYTES, 0, p);  // warm-up
+            HIP_OK(hipDeviceSynchronize());
+            HIP_OK(hipEventRecord(e0));
+            for (int r = 0; r < reps; r++) hipLaunchKernelGGL(v.fn, dim3(grid), dim3(v.threads), LDS_BYTES, 0, p);
+            HIP_OK(hipEventRecord(e1));
+            HIP_OK(hipEventSynchronize(e1));
+            float ms = 0;
+            HIP_OK(hipEventElapsedTime(&ms, e0, e1));
+            ms /= reps;
+            std::vector<uint32_t> ho((size_t)grid * v.threads);
+            HIP_OK(hipMemcpy(ho.data(), p.out, ho.size() * 4, hipMemcpyDeviceToHost));
+            uint32_t got = 0;
+            for (uint32_t x : ho) got += x;
+            printf("%-52s %8.3f ms  %6.3f POP/s  %5.2f TB/s  checksum %s\n", v.name, ms, 2.0 * nq * (double)n * dim / (ms * 1e-3) / 1e15,
+                   (double)n * dim / (ms * 1e-3) / 1e12, got == want ? "ok" : "WRONG");
+            fflush(stdout);
+        }
+    }
+    return 0;
+}

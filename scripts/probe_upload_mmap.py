@@ -69,7 +69,7 @@ try:
         print(f"{label:58s} {dt:7.3f} s  {nbytes / dt / 1e9:6.1f} GB/s  results {'ok' if ok else 'WRONG'}", flush=True)
 
     for threads in ("8", "16", "32"):
-        for adv in ("1", "0"):
+        for adv in ("0",):  # MADV_WILLNEED ahead of the copy was measured here in round 4: no effect, removed
             evict()
             upload(f"COLD  threads={threads} advise={adv}", MVF_UPLOAD_THREADS=threads, MVF_UPLOAD_ADVISE=adv)
     for threads in ("4", "8", "16", "32", "64"):
