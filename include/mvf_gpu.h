@@ -52,7 +52,11 @@ extern "C" {
 
 typedef struct mvfgpu_corpus mvfgpu_corpus;
 
-#define MVFGPU_MAX_K 1024u        /* largest k a search accepts */
+#define MVFGPU_MAX_K 16384u       /* largest k a search accepts (the reference takes any usize, similarity_search.rs:143) */
+#define MVFGPU_K_PER_PASS 1024u   /* results one pass over the rows selects: k beyond it costs ceil(k / 1024) passes of the
+                                     streaming kernel per 1..4 queries, each returning the rows ranked strictly behind the
+                                     last one of the pass before (exact, whatever the batch size; the cross-shard merges keep
+                                     their own limit n_shards * k <= 8192) */
 #define MVFGPU_MAX_INT_DIM 33025u /* d*255^2 < 2^31 */
 
 /*

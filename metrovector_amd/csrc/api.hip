@@ -125,6 +125,7 @@ struct mvfgpu_corpus {
     mutable DevBuf bq, bstate, bcand, xnorm;  // K2: padded queries + norms; tau/cnt/overflow; candidates; row norms
     mutable DevBuf blk;                   // K2 narrow types: per-block candidate regions + their counts (scan_mfma.h)
     mutable DevBuf repair;                // K2 overflow repair: gathered queries + their results
+    mutable DevBuf floor1;                // k > MVFGPU_K_PER_PASS: per query, the last composite the pass before returned, + 1
     mutable DevBuf shadow, xscale;        // Float32 corpora: scaled-f16 shadow rows (selection only) + 2^-s_r per row
     DevBuf tomb, ids;                     // deletion bitmap (u32 words over local rows) / vector ids (u64 per local row)
     uint64_t deleted = 0;                 // bits set in the bitmap
@@ -274,8 +275,11 @@ struct ShadowStream {
 
 int search_stream_path(const mvfgpu_corpus* c, uint8_t metric, const void* d_queries, uint32_t nq, uint32_t k,
                        float* d_scores, uint64_t* d_indices, int32_t* d_raw, hipStream_t s, bool profile = true,
-                       const ShadowStream* alt = nullptr) {
+                       const ShadowStream* alt = nullptr, const uint64_t* floor1 = nullptr, uint64_t* out_floor1 = nullptr,
+                       uint32_t out_stride = 0, uint32_t out_offset = 0) {
+    // floor1 / out_floor1 / out_stride / out_offset: one pass of a k > MVFGPU_K_PER_PASS search (search_large_k)
     const uint32_t kcap = next_pow2(k);
+    const uint32_t ostride = out_stride ? out_stride : k;
     const bool alt8 = alt && alt->i8;
     const uint8_t kdtype = alt8 ? (uint8_t)MVF_DTYPE_INT8 : alt ? (uint8_t)MVF_DTYPE_FLOAT16 : c->dtype;
     const uint32_t kV = alt ? alt->V : c->V;
@@ -373,6 +377,7 @@ int search_stream_path(const mvfgpu_corpus* c, uint8_t metric, const void* d_que
             sp.chunk_rows = chunk_rows;
             sp.chunk_safe = std::min(scan_chunk_safe(G), chunk_rows);
             sp.nchunks = nchunks;
+            sp.floor1 = floor1;
             if (ps && first) HIP_TRY(hipEventRecord(ps->e[0], s));
             if (alt8) HIP_TRY(scan_stream_launch_dt2x(sp, metric, G, nqv, dim3(nblocks), lds, s));
             else if (alt) HIP_TRY(scan_stream_launch_dt1x(sp, metric, G, nqv, dim3(nblocks), lds, s));
@@ -409,9 +414,12 @@ int search_stream_path(const mvfgpu_corpus* c, uint8_t metric, const void* d_que
                     fp.margin_rank = alt->rank_k;
                 }
             } else {
-                fp.out_scores = d_scores + (size_t)q0 * k;
-                fp.out_indices = d_indices + (size_t)q0 * k;
-                fp.out_raw = d_raw ? d_raw + (size_t)q0 * k : nullptr;
+                fp.out_scores = d_scores + (size_t)q0 * ostride;
+                fp.out_indices = d_indices + (size_t)q0 * ostride;
+                fp.out_raw = d_raw ? d_raw + (size_t)q0 * ostride : nullptr;
+                fp.out_stride = out_stride;
+                fp.out_offset = out_offset;
+                fp.out_floor1 = out_floor1 ? out_floor1 + q0 : nullptr;
             }
             HIP_TRY(launch_select_final(fp, nq_here, s));
         }
@@ -1083,7 +1091,7 @@ int search_stream_shadow_path(const mvfgpu_corpus* c, uint8_t metric, const void
     float* qaux1 = qaux0 + nq_pad;
     HIP_TRY(launch_prep_queries16(d_queries, MVF_DTYPE_FLOAT16, nq, nq_pad, c->dim, KPB, qprep, qaux0, qaux1, s));
 
-    const uint32_t ksel = std::min<uint32_t>(MVFGPU_MAX_K, std::max(2u * k, k + 64u));  // k' candidates per query
+    const uint32_t ksel = std::min<uint32_t>(MVFGPU_K_PER_PASS, std::max(2u * k, k + 64u));  // k' candidates per query
     ShadowStream alt{};
     alt.rows = static_cast<const unsigned char*>(c->shadow.p);
     alt.xscale = static_cast<const float*>(c->xscale.p);
@@ -1443,13 +1451,31 @@ int upload_rows(mvfgpu_corpus* c, const void* rows, uint64_t stride, const mvfgp
     return MVF_OK;
 }
 
+// k beyond one pass (MVFGPU_K_PER_PASS): ceil(k / 1024) passes of the streaming kernel, pass p returning the 1024 best rows
+// ranked STRICTLY BEHIND the last row of pass p - 1 -- composites (order key << 32 | row) are distinct and totally ordered,
+// so "behind the floor" is exactly the set of rows not yet returned.  The floor travels on the device (select_final writes
+// it, the next pass's scan reads it): no host wait.  The reference takes any k: usize (examples/similarity_search.rs:143,
+// :166-168); its heap holds k + 1 entries whatever k is.
+int search_large_k(const mvfgpu_corpus* c, uint8_t metric, const void* d_queries, uint32_t nq, uint32_t k, float* d_scores,
+                   uint64_t* d_indices, int32_t* d_raw, hipStream_t s) {
+    HIP_TRY(c->floor1.reserve((size_t)nq * 8));
+    uint64_t* fl = static_cast<uint64_t*>(c->floor1.p);
+    for (uint32_t off = 0; off < k; off += MVFGPU_K_PER_PASS) {
+        const uint32_t kk = std::min<uint32_t>(MVFGPU_K_PER_PASS, k - off);
+        int rc = search_stream_path(c, metric, d_queries, nq, kk, d_scores, d_indices, d_raw, s, /*profile=*/off == 0, nullptr,
+                                    off ? fl : nullptr, fl, k, off);
+        if (rc != MVF_OK) return rc;
+    }
+    return MVF_OK;
+}
+
 int check_query_args(const mvfgpu_corpus* c, uint8_t metric, const void* queries, uint8_t query_dtype,
                      uint32_t query_dim, uint32_t nq, uint32_t k, const void* out_scores, const void* out_indices) {
     if (!c) return fail(MVF_ERR_INVALID_ARGUMENT, "corpus is NULL");
     if (metric != MVF_METRIC_L2 && metric != MVF_METRIC_INNER_PRODUCT && metric != MVF_METRIC_COSINE)
         return fail(MVF_ERR_INVALID_ARGUMENT, "unsupported distance metric code " + std::to_string(metric));
     if (nq == 0) return fail(MVF_ERR_INVALID_ARGUMENT, "nq must be > 0");
-    if (k == 0 || k > MVFGPU_MAX_K) return fail(MVF_ERR_INVALID_ARGUMENT, "k must be in 1..1024");
+    if (k == 0 || k > MVFGPU_MAX_K) return fail(MVF_ERR_INVALID_ARGUMENT, "k must be in 1..16384");
     if (!queries || !out_scores || !out_indices) return fail(MVF_ERR_INVALID_ARGUMENT, "NULL buffer");
     const uint8_t want = is_int_dtype(c->dtype) ? c->dtype : (uint8_t)MVF_DTYPE_FLOAT32;
     if (query_dtype != want)
@@ -1592,6 +1618,7 @@ void mvfgpu_corpus_destroy(mvfgpu_corpus* c) {
         c->blk.release();
         c->xnorm.release();
         c->repair.release();
+        c->floor1.release();
         c->shadow.release();
         c->xscale.release();
         c->tomb.release();
@@ -1632,7 +1659,7 @@ int mvfgpu_corpus_get_info(const mvfgpu_corpus* c, mvfgpu_corpus_info* out) {
         inf.shadows = (uint8_t)((c->shadow8_state == 1 ? 1 : 0) | (c->shadow_state == 1 ? 2 : 0));
         inf.selection_state = (uint8_t)((c->qs_disabled ? 1 : 0) | (c->bias_disabled ? 2 : 0));
         inf.device_bytes = c->tomb.bytes + c->ids.bytes + c->rows_bytes + c->cand.bytes + c->bq.bytes + c->bstate.bytes + c->bcand.bytes +
-                           c->xnorm.bytes + c->repair.bytes + c->blk.bytes + c->shadow8.bytes + c->xscale8.bytes + c->qs_stats.bytes +
+                           c->xnorm.bytes + c->repair.bytes + c->floor1.bytes + c->blk.bytes + c->shadow8.bytes + c->xscale8.bytes + c->qs_stats.bytes +
                            c->shadow.bytes + c->xscale.bytes + c->h_q.bytes + c->h_s.bytes + c->h_i.bytes + c->h_r.bytes;
     }
     return copy_out_struct(out, inf);
@@ -1793,6 +1820,16 @@ int mvfgpu_search_device(const mvfgpu_corpus* c, uint8_t metric, const void* d_q
             }
         }
     } done_guard{c, s};
+    if (k > MVFGPU_K_PER_PASS) {  // more results than one pass selects: passes of the exact streaming kernel
+        rc = search_large_k(c, metric, d_queries, nq, k, d_scores, d_indices, d_raw, s);
+        if (rc != MVF_OK) return rc;
+        if (wps && c->prof_next == prof_before + 1) {
+            HIP_TRY(hipEventRecord(wps->e[4], s));
+            wps->whole = true;
+            c->timing.search_flops = 2ull * nq * c->n * c->dim * ((k + MVFGPU_K_PER_PASS - 1) / MVFGPU_K_PER_PASS);
+        }
+        return MVF_OK;
+    }
     bool shadow_stream = false, qs_stream = false;
     if (stream_qs_wanted(c, nq, k)) qs_feedback_poll(c);  // may switch the int8 selection off
     if (stream_qs_wanted(c, nq, k)) {

@@ -38,6 +38,11 @@ struct SelectParams {
     const uint32_t* redo_list;  // nullable
     const uint32_t* redo_cnt;
     uint32_t redo_base;
+    // one pass of a k > MVFGPU_K_PER_PASS search (api.hip: search_large_k): the result row of a query is out_stride entries
+    // long (0: k) and this pass fills [out_offset, out_offset + k); out_floor1[query] receives the last composite written
+    // + 1 -- the next pass's floor (ScanParams::floor1) -- or ~0 when fewer than k rows were left
+    uint32_t out_stride, out_offset;
+    uint64_t* out_floor1;  // nullable
 };
 
 // queries flagged by the K2 compactions -> a dense list + its length, flags cleared (one block)

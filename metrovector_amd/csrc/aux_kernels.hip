@@ -207,7 +207,9 @@ __global__ void __launch_bounds__(1024) select_final_kernel(SelectParams p) {
         if (tid == 0) p.out_cnt[q] = keep;
         return;
     }
-    for (uint32_t i = tid; i < p.k; i += 1024) write_result(i < m ? buf[i] : kPadComposite, qout * p.k + i, p);
+    const uint32_t stride = p.out_stride ? p.out_stride : p.k;
+    for (uint32_t i = tid; i < p.k; i += 1024) write_result(i < m ? buf[i] : kPadComposite, qout * stride + p.out_offset + i, p);
+    if (p.out_floor1 && tid == 0) p.out_floor1[qout] = m >= p.k ? buf[p.k - 1] + 1ull : ~0ull;
 }
 
 // The K2 compactions flag queries whose candidate budget overflowed (overflow[q] != 0).  One block turns the flags into

@@ -37,6 +37,10 @@ struct ScanParams {
     const uint32_t* redo_list;
     const uint32_t* redo_cnt;
     uint32_t redo_base, redo_max;
+    // k beyond MVFGPU_K_PER_PASS (api.hip: search_large_k): a search for more results than one pass holds runs as several
+    // passes, each returning the best k composites STRICTLY BEHIND the last one the pass before returned.
+    // floor1[query] = that composite + 1 (0: no floor; ~0: the rows are exhausted, nothing may pass); NULL = none.
+    const uint64_t* floor1;
 };
 
 // nqv: queries per pass, 1 or 4; p.redo_list != NULL selects the repair variant of the kernel

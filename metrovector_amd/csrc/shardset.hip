@@ -326,7 +326,7 @@ int mvfgpu_shardset_search(mvfgpu_shardset* ss, uint8_t metric, const void* quer
     // against their own handle)
     if (!ss) return set_fail(MVF_ERR_INVALID_ARGUMENT, "shard set is NULL");
     if (!queries || !out_scores || !out_indices) return set_fail(MVF_ERR_INVALID_ARGUMENT, "NULL buffer");
-    if (nq == 0 || k == 0 || k > MVFGPU_MAX_K) return set_fail(MVF_ERR_INVALID_ARGUMENT, "nq must be > 0 and k in 1..1024");
+    if (nq == 0 || k == 0 || k > MVFGPU_K_PER_PASS) return set_fail(MVF_ERR_INVALID_ARGUMENT, "nq must be > 0 and k in 1..1024 (a shard set merges n_shards * k <= 8192 entries)");
     if (metric != MVF_METRIC_L2 && metric != MVF_METRIC_INNER_PRODUCT && metric != MVF_METRIC_COSINE)
         return set_fail(MVF_ERR_INVALID_ARGUMENT, "unsupported distance metric code");
     const bool int_space = ss->dtype == MVF_DTYPE_INT8 || ss->dtype == MVF_DTYPE_UINT8;

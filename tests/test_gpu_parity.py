@@ -193,7 +193,7 @@ def test_error_codes_mirror_reference():
         with pytest.raises(E.InvalidArgument):
             c.search(np.zeros(16, np.float32), 0)
         with pytest.raises(E.InvalidArgument):
-            c.search(np.zeros(16, np.float32), 2000)
+            c.search(np.zeros(16, np.float32), 16385)   # MVFGPU_MAX_K = 16384
         with pytest.raises(E.InvalidArgument):
             c.search(np.zeros(16, np.float32), 2, metric=255)
         with pytest.raises(E.IndexOutOfBounds):

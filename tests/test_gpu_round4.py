@@ -147,3 +147,79 @@ def test_multi_gb_mvf_file_open_upload_search(oracle, tmp_path):
     finally:
         if os.path.exists(path):
             os.remove(path)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Part 3 -- k beyond one pass.  The reference takes any k: usize (examples/similarity_search.rs:143,
+# :166-168); a search for more than MVFGPU_K_PER_PASS = 1024 results runs ceil(k / 1024) passes of the streaming kernel, each
+# returning the rows ranked strictly behind the last row of the pass before (the floor travels on the device).
+# ---------------------------------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("dtype", [0, 1, 2, 3])
+@pytest.mark.parametrize("metric", [G.L2, G.INNER_PRODUCT, G.COSINE])
+def test_k_5000_on_200k_rows_vs_the_oracle(oracle, dtype, metric):
+    n, dim, k = 200_000, 96, 5000
+    rows = oracle.synth_rows(SEED, 0, n, dim, dtype)
+    q = oracle.synth_queries(SEED + 1, 3, dim, dtype)
+    with G.GpuCorpus.from_array(rows, index_base=7_000_000) as c:
+        one = c.search(q[0], k, metric)          # one query per pass
+        three = c.search(q, k, metric)           # the four-query pass
+    osc, oidx, oraw = oracle.search(rows, dtype, metric, q, k, index_base=7_000_000)
+    if dtype in (2, 3):                          # integer spaces: bit-exact, ties by row position across the pass boundaries
+        assert_exact(three, osc, oidx, oraw)
+        assert_exact(one, osc[:1], oidx[:1], oraw[:1])
+    else:
+        rows32 = rows.astype(np.float32)
+        for qi in range(3):
+            sc = oracle.scores(rows, dtype, metric, q[qi])[0]
+            assert_float_topk(metric, three.scores[qi], three.indices[qi], sc, rows32, q[qi], k, index_base=7_000_000)
+        assert (one.indices[0] == three.indices[0]).all() and (one.scores[0].view(np.uint32) == three.scores[0].view(np.uint32)).all()
+
+
+def test_large_k_ties_deletions_ids_and_exhaustion(oracle):
+    """What the pass boundaries must not break: a tie group that straddles rank 1024 (equal keys: the floor is the full
+    composite, so the split is by row position), deleted rows, vector ids, k beyond the live rows (the later passes find
+    nothing and pad), k = 16384 = MVFGPU_MAX_K, and batches above the four-query pass."""
+    rng = np.random.default_rng(11)
+    n, dim = 30_000, 32
+    rows = rng.integers(-3, 4, (n, dim)).astype(np.int8)          # few distinct scores: ties everywhere
+    q = rng.integers(-3, 4, (6, dim)).astype(np.int8)
+    dead = np.zeros(n, bool)
+    dead[rng.choice(n, 12_000, replace=False)] = True
+    ids = rng.permutation(n).astype(np.uint64) + np.uint64(10**12)
+    live = np.nonzero(~dead)[0]
+    with G.GpuCorpus.from_array(rows) as c:
+        for k in (1025, 2048, 5000, 16384):
+            got = c.search(q, k, G.INNER_PRODUCT)
+            assert_exact(got, *oracle.search(rows, 2, 1, q, k))
+        c.set_tombstones(np.packbits(dead, bitorder="little"))
+        c.set_vector_ids(ids)
+        k = 16384                                                  # 18 000 live rows: the last passes still find rows
+        got = c.search(q, k, G.L2)
+        osc, oidx, oraw = oracle.search(rows[live], 2, 0, q, k)
+        assert (got.indices == ids[live[oidx.astype(np.int64)]]).all() and (got.raw == oraw).all()
+    with G.GpuCorpus.from_array(rows[:3000]) as c:                 # k beyond the rows: 3000 results, then padding
+        got = c.search(q[:2], 5000, G.INNER_PRODUCT)
+        assert_exact(got, *oracle.search(rows[:3000], 2, 1, q[:2], 5000))
+        assert (got.indices[:, 3000:] == np.uint64(0xFFFFFFFFFFFFFFFF)).all() and (got.scores[:, 3000:] == -np.inf).all()
+    with pytest.raises(Exception):
+        with G.GpuCorpus.from_array(rows[:100]) as c:
+            c.search(q[:1], 16385, G.L2)
+
+
+def test_large_k_on_a_batch_the_mfma_path_would_take(oracle):
+    """300 queries, k = 1500, Float32 cosine: above one pass the batch is served by passes of the exact streaming kernel
+    (four queries each) instead of the MFMA path -- same answers as 300 single searches at k = 1024 on their first 1024."""
+    n, dim, nq, k = 50_000, 64, 300, 1500
+    rows = oracle.synth_rows(SEED, 0, n, dim, 0)
+    q = oracle.synth_queries(SEED + 1, nq, dim, 0)
+    with G.GpuCorpus.from_array(rows) as c:
+        got = c.search(q, k, G.COSINE)
+        c.set_scan_path(1)
+        ref = c.search(q, 1024, G.COSINE)
+    assert (got.indices[:, :1024] == ref.indices).all()
+    assert (got.scores[:, :1024].view(np.uint32) == ref.scores.view(np.uint32)).all()
+    rows32 = rows.astype(np.float32)
+    for qi in (0, 150, 299):
+        sc = oracle.scores(rows, 0, 2, q[qi])[0]
+        assert_float_topk(2, got.scores[qi], got.indices[qi], sc, rows32, q[qi], k)
