@@ -243,12 +243,12 @@ hipError_t scan_launch(uint8_t dtype, const ScanParams& p, int metric, int G, in
     }
 }
 
-const void* scan_kernel(uint8_t dtype, int metric, int G, int nqv, bool redo = false) {
+const void* scan_kernel(uint8_t dtype, int metric, int G, int nqv, bool redo = false, bool floor = false) {
     switch (dtype) {
-    case MVF_DTYPE_FLOAT32: return scan_stream_kernel_ptr_dt0(metric, G, nqv, redo);
-    case MVF_DTYPE_FLOAT16: return scan_stream_kernel_ptr_dt1(metric, G, nqv, redo);
-    case MVF_DTYPE_INT8: return scan_stream_kernel_ptr_dt2(metric, G, nqv, redo);
-    default: return scan_stream_kernel_ptr_dt3(metric, G, nqv, redo);
+    case MVF_DTYPE_FLOAT32: return scan_stream_kernel_ptr_dt0(metric, G, nqv, redo, floor);
+    case MVF_DTYPE_FLOAT16: return scan_stream_kernel_ptr_dt1(metric, G, nqv, redo, floor);
+    case MVF_DTYPE_INT8: return scan_stream_kernel_ptr_dt2(metric, G, nqv, redo, floor);
+    default: return scan_stream_kernel_ptr_dt3(metric, G, nqv, redo, floor);
     }
 }
 
@@ -317,7 +317,7 @@ int search_stream_path(const mvfgpu_corpus* c, uint8_t metric, const void* d_que
         if (nchunks > 0) {
             const void* kfn = alt8  ? scan_stream_kernel_ptr_dt2x(metric, G, nqv)
                               : alt ? scan_stream_kernel_ptr_dt1x(metric, G, nqv)
-                                    : scan_kernel(c->dtype, metric, G, nqv);
+                                    : scan_kernel(c->dtype, metric, G, nqv, /*redo=*/false, floor1 != nullptr);
             if (lds > 48 * 1024)
                 HIP_TRY(hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             int occ = 0;

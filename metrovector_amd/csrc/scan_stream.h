@@ -43,11 +43,12 @@ struct ScanParams {
     const uint64_t* floor1;
 };
 
-// nqv: queries per pass, 1 or 4; p.redo_list != NULL selects the repair variant of the kernel
+// nqv: queries per pass, 1 or 4; p.redo_list != NULL selects the repair variant of the kernel, p.floor1 != NULL the
+// floor variant (stored rows only: units 0..3)
 #define MVF_DECL_SCAN(dt)                                                                          \
     hipError_t scan_stream_launch_dt##dt(const ScanParams& p, int metric, int G, int nqv, dim3 grid, \
                                          size_t lds, hipStream_t s);                               \
-    const void* scan_stream_kernel_ptr_dt##dt(int metric, int G, int nqv, bool redo = false);
+    const void* scan_stream_kernel_ptr_dt##dt(int metric, int G, int nqv, bool redo = false, bool floor = false);
 MVF_DECL_SCAN(0)
 MVF_DECL_SCAN(1)
 MVF_DECL_SCAN(2)
