@@ -27,6 +27,8 @@ extern "C" {
                      query_dim: u32, nq: u32, k: u32, out_scores: *mut f32, out_indices: *mut u64,
                      out_raw: *mut i32) -> c_int;
     fn mvfgpu_last_error_message() -> *const c_char;
+    /// `MVFGPU_ABI_VERSION` of the loaded library (include/mvf_gpu.h): struct layouts and signatures this file mirrors.
+    fn mvfgpu_abi_version() -> u32;
     /// Rows by GLOBAL index from HBM: the `ScoredVector.vector` payload (similarity_search.rs:18).
     fn mvfgpu_corpus_gather_rows(corpus: *const MvfGpuCorpus, indices: *const u64, count: u64,
                                  out_rows: *mut c_void) -> c_int;
@@ -47,6 +49,20 @@ extern "C" {
 #[repr(C)]
 pub struct MvfGpuShardset {
     _private: [u8; 0],
+}
+
+/// The `MVFGPU_ABI_VERSION` this binding was written against (include/mvf_gpu.h; 3 = round 4).
+pub const MVFGPU_ABI_VERSION: u32 = 3;
+
+/// Refuse a library that speaks another ABI version (its out-structs or signatures may differ); call once at start-up.
+pub fn check_abi() -> Result<()> {
+    let got = unsafe { mvfgpu_abi_version() };
+    if got != MVFGPU_ABI_VERSION {
+        return Err(MvfError::Extension(format!(
+            "libmvf_gpu speaks ABI version {got}, this binding was written against {MVFGPU_ABI_VERSION}"
+        )));
+    }
+    Ok(())
 }
 
 /// First two unsigned integers found in `msg` ("Index out of bounds: 7 >= 3", "Dimension mismatch: expected 768,

@@ -278,6 +278,9 @@ class GpuVectorSpace {
 public:
     explicit GpuVectorSpace(const VectorSpace& space, int device = 0)
         : dim_(space.dimension()), metric_(space.distance_metric()), dt_(space.data_type()) {
+        if (mvfgpu_abi_version() != MVFGPU_ABI_VERSION)  // a library built from another header: its structs may differ
+            throw MvfError(MVF_ERR_INVALID_ARGUMENT, "libmvf_gpu speaks ABI version " + std::to_string(mvfgpu_abi_version()) +
+                                                         ", this program was built against " + std::to_string(MVFGPU_ABI_VERSION));
         const VectorSlice s = space.map_vector_range(0, space.total_vectors());
         detail::check_gpu(mvfgpu_corpus_create(s.data, s.count, dim_, (uint8_t)s.data_type, s.stride, 0, device, &c_));
     }
