@@ -669,19 +669,19 @@ __global__ void __launch_bounds__(1024) compact_margin_kernel(CompactParams p) {
 // takes the 16-candidate slices b, b + B, ... (round 2 had one block per query walk all of them, four at a time:
 // 0.46 ms for the ~700 candidates of an int8-selected query whatever the batch size -- a fifth of a 64-query search).
 // rescore_select_kernel: one block per query sorts the re-scored candidates and formats the k best.
-template <int METRIC, bool REFINE = false, int NW = 4>
-__global__ void __launch_bounds__(NW * 64) rescore_score_kernel(RescoreParams p, const uint32_t* ntop = nullptr, uint32_t* lkey = nullptr) {
+template <int METRIC, bool REFINE = false>
+__global__ void __launch_bounds__(256) rescore_score_kernel(RescoreParams p, const uint32_t* ntop = nullptr, uint32_t* lkey = nullptr) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t dim4 = (p.dim + 7u) & ~7u;  // zero-padded to a multiple of 8 (one f16 vector)
     float* qs = reinterpret_cast<float*>(smem);
-    __shared__ float qq_part[NW];
+    __shared__ float qq_part[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t q = blockIdx.y;
     const uint32_t keep_cap = p.cap / 2;
     const uint32_t m = REFINE ? (ntop[q] >= p.k ? min(ntop[q], keep_cap) : 0u) : min(p.cnt[q], keep_cap);  // REFINE: the best k (+ ties) only
-    if (blockIdx.x * (NW * 4u) >= m) return;  // block-uniform
+    if (blockIdx.x * 16u >= m) return;  // block-uniform
     float qq = 0.f;
-    for (uint32_t e = tid; e < dim4; e += NW * 64) {
+    for (uint32_t e = tid; e < dim4; e += 256) {
         const float v = e < p.dim ? p.queries[(size_t)q * p.dim + e] : 0.f;
         qs[e] = v;
         qq = fmaf(v, v, qq);
@@ -691,15 +691,11 @@ __global__ void __launch_bounds__(NW * 64) rescore_score_kernel(RescoreParams p,
         if (lane == 0) qq_part[wave] = qq;
     }
     __syncthreads();
-    if (METRIC == MVF_METRIC_COSINE) {
-        qq = 0.f;
-#pragma unroll
-        for (int w = 0; w < NW; w += 4) qq += (qq_part[w] + qq_part[w + 1]) + (qq_part[w + 2] + qq_part[w + 3]);  // NW = 4: the sum as it always was
-    }
+    if (METRIC == MVF_METRIC_COSINE) qq = (qq_part[0] + qq_part[1]) + (qq_part[2] + qq_part[3]);
     uint64_t* c = p.cand + (size_t)q * p.cap;
     const uint32_t V = p.pitch / 16;
     const uint32_t tau_q = p.tau[q];
-    for (uint32_t c0 = blockIdx.x * (NW * 4u); c0 < m; c0 += gridDim.x * (NW * 4u)) {
+    for (uint32_t c0 = blockIdx.x * 16u; c0 < m; c0 += gridDim.x * 16u) {
         // this wave's four candidates: c0 + wave * 4 + u (a row past the end repeats the slice's first; not written)
         uint32_t r[4];
         const unsigned char* rp[4];
@@ -887,32 +883,9 @@ hipError_t launch_compact_margin(const CompactParams& p, uint32_t nq, hipStream_
     return hipGetLastError();
 }
 
-namespace {
-int g_rescore_wide = -1;  // experiment switch (MVF_RESCORE_WIDE): 16 waves per block instead of 4
-bool rescore_wide() {
-    if (g_rescore_wide < 0) {
-        const char* e = getenv("MVF_RESCORE_WIDE");
-        g_rescore_wide = e ? atoi(e) : 0;
-    }
-    return g_rescore_wide != 0;
-}
-}  // namespace
-
 hipError_t launch_rescore(const RescoreParams& p, int metric, uint32_t nq, hipStream_t s) {
     if (nq == 0) return hipSuccess;
     const size_t lds = (size_t)((p.dim + 7u) & ~7u) * 4;
-    if (rescore_wide()) {
-        const uint32_t slices = (p.cap / 2 + 63u) / 64u;
-        const uint32_t B = std::min(slices, std::max(2u, std::min(16u, 512u / nq)));
-        const dim3 grid(B, nq);
-        if (metric == MVF_METRIC_L2) hipLaunchKernelGGL((rescore_score_kernel<MVF_METRIC_L2, false, 16>), grid, dim3(1024), lds, s, p, nullptr, nullptr);
-        else if (metric == MVF_METRIC_COSINE) hipLaunchKernelGGL((rescore_score_kernel<MVF_METRIC_COSINE, false, 16>), grid, dim3(1024), lds, s, p, nullptr, nullptr);
-        else hipLaunchKernelGGL((rescore_score_kernel<MVF_METRIC_INNER_PRODUCT, false, 16>), grid, dim3(1024), lds, s, p, nullptr, nullptr);
-        hipError_t e = hipGetLastError();
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(rescore_select_kernel, dim3(nq), dim3(1024), (size_t)(p.cap / 2) * 8, s, p, metric);
-        return hipGetLastError();
-    }
     // blocks per query: enough to fill the chip with a small batch, few enough that a block's staged query serves
     // several 16-candidate slices with a large one
     const uint32_t slices = (p.cap / 2 + 15u) / 16u;
@@ -931,16 +904,6 @@ hipError_t launch_refine_tau(const RescoreParams& p, int metric, uint32_t nq, co
                              const float* delta, hipStream_t s) {
     if (nq == 0) return hipSuccess;
     const size_t lds = (size_t)((p.dim + 7u) & ~7u) * 4;
-    if (rescore_wide()) {  // one block of 16 waves per query: the k best (+ ties) in two rounds of 64 rows, the query staged once
-        const dim3 grid(2, nq);
-        if (metric == MVF_METRIC_L2) hipLaunchKernelGGL((rescore_score_kernel<MVF_METRIC_L2, true, 16>), grid, dim3(1024), lds, s, p, ntop, lkey);
-        else if (metric == MVF_METRIC_COSINE) hipLaunchKernelGGL((rescore_score_kernel<MVF_METRIC_COSINE, true, 16>), grid, dim3(1024), lds, s, p, ntop, lkey);
-        else hipLaunchKernelGGL((rescore_score_kernel<MVF_METRIC_INNER_PRODUCT, true, 16>), grid, dim3(1024), lds, s, p, ntop, lkey);
-        hipError_t e = hipGetLastError();
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(refine_tau_kernel, dim3((nq + 255u) / 256u), dim3(256), 0, s, p.tau, ntop, lkey, delta, metric, p.k, nq);
-        return hipGetLastError();
-    }
     const uint32_t slices = (p.k + 15u) / 16u + 1u;  // k best + a few ties
     const dim3 grid(std::min(slices, 64u), nq);
     if (metric == MVF_METRIC_L2) hipLaunchKernelGGL((rescore_score_kernel<MVF_METRIC_L2, true>), grid, dim3(256), lds, s, p, ntop, lkey);
