@@ -246,7 +246,13 @@ int mvfgpu_search(const mvfgpu_corpus* corpus, uint8_t metric,
  * asynchronous on `hip_stream` (a hipStream_t; NULL = the default stream).
  * This is the timed region of bench.py and the producer of the per-shard
  * lists that RCCL all-gathers.  d_raw may be NULL.
- * The call never waits for the device.  Small batches run the streaming kernel (below 32 queries on corpora under
+ * The call does not wait for the device -- with ONE bound: a handle keeps at most TWO int8-selected batched searches
+ * in flight.  Such a search posts how many of its queries the repair pass redid (a 4-byte copy behind an event) and the
+ * search two calls later consumes that sample before it picks its path, waiting for it if it has not arrived: which path
+ * a search takes then depends on the sequence of searches alone, never on how far the host runs ahead.  A caller that
+ * pipelines three or more batched searches on one handle has its third enqueue wait for the first search to finish.
+ * k > MVFGPU_K_PER_PASS: ceil(k / 1024) passes of the streaming kernel, no host wait (the floor travels on the device).
+ * Small batches run the streaming kernel (below 32 queries on corpora under
  * 1 GiB; on larger ones a single query, below 5 for Int8/UInt8 and below 9 for Float32 without the f16 shadow -- the
  * measured crossovers: the streaming kernel takes up to 4 queries per pass over the rows, the MFMA path uses a
  * 64-query tile up to 128 queries).  Larger batches run the MFMA path in phases; an adversarially ordered corpus can

@@ -967,7 +967,10 @@ int search_batched_path(const mvfgpu_corpus* c, uint8_t metric, const void* d_qu
             const bool use_sb = !wide && !use_pp && dma && qpb == 64u && k2_sb_enabled(c) && scan_mfma16_sb_usable(nq_pad, KT, nq);
             const bool persistent = k2_dma_persistent(c);
             // per-wave regions of raw records (scan_mfma16_bias.inc): the persistent LDS-DMA kernel on i32 accumulators
+            // (per-wave regions: num_cus blocks x kBlkWaves counters in blk_cnt, which holds kBlkMaxBlocks * kBlkWaves -- a part
+            // with more CUs than kBlkMaxBlocks keeps round 2's per-block regions instead of reading counters past the array)
             const bool wave_regions = !wide && dma && !use_pp && !use_sb && persistent && !c->bias_disabled && k2_bias_enabled(c) &&
+                                      (uint32_t)c->num_cus <= kBlkMaxBlocks &&
                                       scan_mfma16_dma_wave_regions(kdtype, qpb, hp.direct != 0, regions, c->dim);
             hp.wave_regions = wave_regions ? 1u : 0u;
             used_bias |= wave_regions;

@@ -78,7 +78,10 @@ def test_random_case_against_the_oracle(oracle, case):
                 if dim >= 16:  # tiny dimensions: crowds of scores within the tolerance of each other (checked above)
                     # one boundary tie ranked the other way (legitimate within the tolerance; the check above is the
                     # criterion) is 2 % of a 5 x 10 answer: allow one such row on small answers
-                    assert recall_at_k(res.indices, want) >= min(0.99, 1.0 - 1.5 / (nq * min(k, len(pos)))), tag
+                    # (answers of one or two entries: a single boundary tie is the whole answer -- the criterion above decides)
+                    nres = nq * min(k, len(pos))
+                    if nres >= 3:
+                        assert recall_at_k(res.indices, want) >= min(0.99, max(1.0 - 1.5 / nres, 1.0 - 1.0 / 3.0)), tag
 
 
 @pytest.mark.parametrize("case", range(24))

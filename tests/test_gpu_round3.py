@@ -230,8 +230,9 @@ def test_batched_search_device_returns_behind_unfinished_work(oracle):
         for _ in range(24):  # fp32 8192^3 GEMMs: ~10 ms each on this part
             a @ a
         _lib.gpu_check(_lib.gpu().mvfgpu_search_device(*args))
-        ev = torch.cuda.Event()
-        ev.record()
+        _lib.gpu_check(_lib.gpu().mvfgpu_search_device(*args))  # TWO searches in flight behind the GEMMs: still no host wait
+        ev = torch.cuda.Event()                                  # (include/mvf_gpu.h: a third would wait for the first --
+        ev.record()                                              #  the repair feedback consumes the sample two searches back)
         assert not ev.query(), "mvfgpu_search_device returned only after the stream had drained"
         torch.cuda.synchronize()
         assert (di.cpu().numpy() == first).all()
