@@ -209,3 +209,53 @@ def test_random_short_rows_in_long_pieces(oracle, case):
             else:
                 assert recall_at_k(res.indices, want) >= 0.99, tag
                 assert np.abs(res.scores - osc).max() <= 1e-5 * max(1.0, float(np.abs(osc).max())), tag
+
+
+@pytest.mark.parametrize("case", range(48))
+def test_random_large_k_against_the_oracle(oracle, case):
+    """The same sweep for k beyond one pass (MVFGPU_K_PER_PASS = 1024; round 4): random k up to 16384 next to, at and beyond
+    the live row count, batch sizes on both sides of the four-query pass, deletions, ids, index bases, and a forced scan
+    path -- which must not matter: above one pass every request is served by passes of the exact streaming kernel."""
+    rng = np.random.default_rng(9000 + case + OFFSET)
+    dtype = int(rng.integers(0, 4))
+    metric = int(rng.integers(0, 3))
+    dim = int(rng.choice([1, 3, 8, 16, 33, 64, 100, 256]))
+    n = int(rng.choice([17, 1023, 1024, 1025, 2047, 3000, 9000, 40000]))
+    rows = oracle.synth_rows(SEED + 500 + case, 0, n, dim, dtype)
+    if dtype >= 2 and rng.random() < 0.5:
+        rows[rng.choice(n, n // 3, replace=False)] = rows[0]   # big tie groups across the pass boundaries
+    dead = rng.random(n) < rng.choice([0.05, 0.5]) if rng.random() < 0.4 else None
+    ids = rng.permutation(np.arange(10_000, 10_000 + n)).astype(np.uint64) if rng.random() < 0.3 else None
+    index_base = int(rng.choice([0, 5, 1 << 33]))
+    with G.GpuCorpus.from_array(rows, index_base=index_base) as c:
+        if dead is not None:
+            c.set_tombstones(np.packbits(dead, bitorder="little"))
+        if ids is not None:
+            c.set_vector_ids(ids)
+        for step in range(2):
+            nq = int(rng.choice([1, 2, 4, 5, 9, 70]))
+            k = int(rng.choice([1025, 1500, 2048, 2049, 4000, 16384]))
+            c.set_scan_path(int(rng.choice([0, 1, 2, 3, 5, 6] if dtype < 2 else [0, 1, 2])))
+            q = oracle.synth_queries(SEED + 11 * case + step, nq, dim, dtype)
+            res = c.search(q, k, metric)
+            live = np.ones(n, bool) if dead is None else ~dead
+            sub, pos = rows[live], np.nonzero(live)[0]
+            osc, oidx, oraw = oracle.search(sub, dtype, metric, q, k)
+            ok = oidx != PAD
+            want = np.full(oidx.shape, PAD, np.uint64)
+            p = pos[oidx[ok].astype(np.int64)]
+            want[ok] = ids[p] if ids is not None else p.astype(np.uint64) + np.uint64(index_base)
+            tag = f"case {case} step {step}: dtype {dtype} metric {metric} n {n} dim {dim} nq {nq} k {k}"
+            assert ((res.indices == PAD) == (want == PAD)).all(), tag
+            if dtype >= 2:
+                assert (res.indices == want).all(), tag
+                assert (res.raw == oraw).all(), tag
+                assert (res.scores.view(np.uint32) == osc.view(np.uint32)).all(), tag
+            else:
+                inv = {int(v): i for i, v in enumerate(ids[pos] if ids is not None else pos.astype(np.uint64) + np.uint64(index_base))}
+                rf = sub.astype(np.float32)
+                for qi in sorted(set([0, nq // 2, nq - 1])):
+                    kk = min(k, len(pos))
+                    local = np.array([inv[int(g)] for g in res.indices[qi][:kk]], np.uint64)
+                    sc = oracle.scores(sub, dtype, metric, q[qi])[0]
+                    assert_float_topk(metric, res.scores[qi], np.concatenate([local, res.indices[qi][kk:]]), sc, rf, q[qi], k)
