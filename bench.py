@@ -58,6 +58,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+T_START = time.perf_counter()
 
 SEED = 0x4D564631  # "MVF1"
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
@@ -1096,6 +1097,7 @@ def main():
     if not args.no_shardset:
         result["shardset"] = shardset_leg(args, world)
 
+    result["bench_wall_s"] = time.perf_counter() - T_START  # rank 0, from interpreter start to the line (all legs, oracle checks included)
     print(json.dumps(result), flush=True)
 
 
