@@ -390,7 +390,9 @@ __global__ void __launch_bounds__(256) row_norms_f32_kernel(const unsigned char*
 // The block's regions are walked as ONE flat record range (their counts are prefix-summed first): the record loads of
 // a pass are independent of each other, where a region-by-region walk paid two dependent round trips per region and pass
 // (8 regions x 2 passes: 50-100 us per call, 0.4 ms of a 10.8-ms search).
-constexpr uint32_t kScatterBlocks = 128, kScatterMaxQueries = 8192, kScatterMaxPer = 64;
+// (round 4: 256 blocks -- one per CU -- instead of 128: every launch of a 1024-query search 25-30 % shorter, 220 -> 153 us per
+// search; 512 blocks measured the same on 1024 queries and worse on 64.)
+constexpr uint32_t kScatterBlocks = 256, kScatterMaxQueries = 8192, kScatterMaxPer = 64;
 
 // RAW records {integer sum, row, query, 1} (scan_mfma16_dma.hip's i32-accumulator flavours, scan_mfma16_key.h) are turned
 // into keyed ones in pass 1, in place: key computed, the threshold / padding-query / deletion tests applied; a record that
@@ -762,6 +764,147 @@ __global__ void __launch_bounds__(256) rescore_score_kernel(RescoreParams p, con
     }
 }
 
+// ---- the same scoring, WAVE-AUTONOMOUS (round 4) -----------------------------------------------------------------------
+// rescore_score_kernel above stages the query in LDS per block (a global read, a barrier, THEN the rows) and its blocks live
+// for one or two 16-row rounds: the refinement passes ran at 2.5 TB/s and the final pass at 3.8 where the same access shape --
+// one wave per row, four rows in flight, random 3-KB rows out of 30 GB -- holds 6.0 TB/s in a bare kernel
+// (scripts/probe_gather.hip, profiles/r04_gather_random_rows.txt).  Here nothing is shared between waves: a persistent wave
+// takes (query, 64-candidate slice) items; every lane holds ONE candidate of the slice and its own share of the query in
+// registers (the vectors v = lane + 64 j it will meet in every row: L2-resident reads, no LDS, no barrier); the LIVE candidates
+// (inside the -- possibly refined -- threshold) are compacted with a ballot and scored four at a time, all twelve row loads of
+// a round in flight together.  Per-lane element assignment and the xor reduction are rescore_score_kernel's.
+// VPL = 16-byte row vectors per lane (rows of up to 64 VPL vectors: 768 x f32 = 3, 1024 x f16 = 2); longer rows keep the
+// block kernel.
+template <int METRIC, bool REFINE, bool F16ROWS, int VPL>
+__global__ void __launch_bounds__(256) rescore_wave_kernel(RescoreParams p, uint32_t nq, uint32_t slices, const uint32_t* ntop, uint32_t* lkey) {
+    constexpr int EPV = F16ROWS ? 8 : 4;  // query floats per row vector
+    const int lane = threadIdx.x & 63;
+    const uint32_t wave = (blockIdx.x * 256u + threadIdx.x) >> 6, nwaves = (gridDim.x * 256u) >> 6;
+    const uint32_t keep_cap = p.cap / 2;
+    const uint32_t V = p.pitch / 16;
+    // items in SLICE-major order (item = slice * nq + query): every wave meets low slices -- the ones that exist -- first, the
+    // empty tail of the longest possible list costs each wave a few reads of cnt[q].  (Query-major order with a power-of-two
+    // slice count gave wave w the slice w % slices of every query it met: two thirds of the waves never found work.)
+    for (uint32_t item = wave; item < nq * slices; item += nwaves) {
+        const uint32_t q = item % nq, sl0 = item / nq;
+        const uint32_t m = REFINE ? (ntop[q] >= p.k ? min(ntop[q], keep_cap) : 0u) : min(p.cnt[q], keep_cap);
+        if (sl0 * 64u >= m) continue;  // wave-uniform
+        // this lane's share of the query (zero beyond the dimension: the rows' padding is zero too, but 0 x NaN is not)
+        float qf[VPL][EPV];
+        float qq = 0.f;
+        const float* qp = p.queries + (size_t)q * p.dim;
+#pragma unroll
+        for (int j = 0; j < VPL; j++)
+#pragma unroll
+            for (int w = 0; w < EPV; w++) {
+                const uint32_t e = ((uint32_t)lane + 64u * j) * EPV + w;
+                qf[j][w] = e < p.dim ? qp[e] : 0.f;
+                if (METRIC == MVF_METRIC_COSINE) qq = fmaf(qf[j][w], qf[j][w], qq);
+            }
+        if (METRIC == MVF_METRIC_COSINE)
+            for (int off = 32; off > 0; off >>= 1) qq += __shfl_xor(qq, off, 64);
+        const uint32_t tau_q = p.tau[q];
+        uint64_t* c = p.cand + (size_t)q * p.cap;
+        uint32_t worst = 0;  // REFINE: the worst exact key of this wave's rows
+        for (uint32_t sl = sl0; sl * 64u < m; sl += slices) {
+            const uint32_t ci = sl * 64u + (uint32_t)lane;
+            const uint64_t ce = ci < m ? c[ci] : kPadComposite;
+            // outside the (possibly refined) threshold: cannot be in the top-k; not fetched, not scored
+            const bool live = ci < m && (REFINE || tau_q == kNanKey || (uint32_t)(ce >> 32) <= tau_q);
+            if (!REFINE && ci < m && !live) c[ci] = kPadComposite;
+            const uint32_t myrow = (uint32_t)ce;
+            unsigned long long mask = __builtin_amdgcn_ballot_w64(live);
+            while (mask) {  // wave-uniform
+                int l[4];
+                uint32_t r[4];
+                bool ok[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    ok[u] = mask != 0;
+                    l[u] = ok[u] ? __builtin_ctzll(mask) : l[0];
+                    if (ok[u]) mask &= mask - 1;
+                    r[u] = (uint32_t)__builtin_amdgcn_readlane((int)myrow, l[u]);
+                }
+                u32x4 x[4][VPL];
+#pragma unroll
+                for (int j = 0; j < VPL; j++) {
+                    const uint32_t v = (uint32_t)lane + 64u * j;
+#pragma unroll
+                    for (int u = 0; u < 4; u++)
+                        x[u][j] = (ok[u] && v < V) ? *reinterpret_cast<const u32x4*>(p.rows + (size_t)r[u] * p.pitch + (size_t)v * 16) : u32x4{0, 0, 0, 0};
+                }
+                float s[4] = {0.f, 0.f, 0.f, 0.f}, xx[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int j = 0; j < VPL; j++)
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        auto term = [&](float qv, float xv) __attribute__((always_inline)) {
+                            if (METRIC == MVF_METRIC_L2) {
+                                const float t = qv - xv;
+                                s[u] = fmaf(t, t, s[u]);
+                            } else {
+                                s[u] = fmaf(qv, xv, s[u]);
+                                if (METRIC == MVF_METRIC_COSINE) xx[u] = fmaf(xv, xv, xx[u]);
+                            }
+                        };
+                        if constexpr (!F16ROWS) {
+#pragma unroll
+                            for (int w = 0; w < 4; w++) term(qf[j][w], __uint_as_float(x[u][j][w]));
+                        } else {
+#pragma unroll
+                            for (int w = 0; w < 4; w++) {
+                                term(qf[j][2 * w], __half2float(__ushort_as_half((unsigned short)(x[u][j][w] & 0xFFFFu))));
+                                term(qf[j][2 * w + 1], __half2float(__ushort_as_half((unsigned short)(x[u][j][w] >> 16))));
+                            }
+                        }
+                    }
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    for (int off = 32; off > 0; off >>= 1) {
+                        s[u] += __shfl_xor(s[u], off, 64);
+                        if (METRIC == MVF_METRIC_COSINE) xx[u] += __shfl_xor(xx[u], off, 64);
+                    }
+                    float sc = s[u];
+                    if (METRIC == MVF_METRIC_L2 && !REFINE) sc = sqrtf(s[u]);  // REFINE: the squared distance the selection works on
+                    if (METRIC == MVF_METRIC_COSINE) {
+                        const float den = sqrtf(qq) * sqrtf(xx[u]);
+                        sc = den > 0.0f ? s[u] / den : 0.0f;
+                    }
+                    const uint32_t key = key_from_score(sc, METRIC);
+                    if (REFINE) {
+                        if (ok[u]) worst = max(worst, key);
+                    } else if (ok[u] && lane == l[u]) {
+                        c[ci] = ((uint64_t)key << 32) | myrow;
+                    }
+                }
+            }
+        }
+        if (REFINE && lane == 0 && worst) atomicMax(&lkey[q], worst);  // one atomic per wave and query
+    }
+}
+
+template <int METRIC, bool REFINE>
+bool launch_rescore_wave(const RescoreParams& p, uint32_t nq, uint32_t slices, const uint32_t* ntop, uint32_t* lkey, hipStream_t s) {
+    const uint32_t V = p.pitch / 16, vpl = (V + 63u) / 64u;
+    if (vpl == 0 || vpl > 4u || (p.dtype != MVF_DTYPE_FLOAT32 && p.dtype != MVF_DTYPE_FLOAT16)) return false;  // longer rows: the block kernel
+    const uint32_t items = nq * slices;
+    const dim3 grid(std::max(1u, std::min((items + 3u) / 4u, 2048u)));
+    const bool h = p.dtype == MVF_DTYPE_FLOAT16;
+#define MVF_RW(VPL_)                                                                                                          \
+    do {                                                                                                                      \
+        if (h) hipLaunchKernelGGL((rescore_wave_kernel<METRIC, REFINE, true, VPL_>), grid, dim3(256), 0, s, p, nq, slices, ntop, lkey);  \
+        else hipLaunchKernelGGL((rescore_wave_kernel<METRIC, REFINE, false, VPL_>), grid, dim3(256), 0, s, p, nq, slices, ntop, lkey);   \
+    } while (0)
+    switch (vpl) {
+    case 1: MVF_RW(1); break;
+    case 2: MVF_RW(2); break;
+    case 3: MVF_RW(3); break;
+    default: MVF_RW(4); break;
+    }
+#undef MVF_RW
+    return true;
+}
+
 // One thread per query: tau[q] = the tighter of itself and ord(L -/+ delta), L = the worst exact score of its k best
 // approximate candidates (rescore_score_kernel<., true>); re-arms lkey.  The 2 % on delta covers the f32 rounding of the
 // exact scores themselves (the final ranking is by those f32 values).
@@ -783,10 +926,21 @@ __global__ void __launch_bounds__(1024) rescore_select_kernel(RescoreParams p, i
     const int tid = threadIdx.x;
     const uint32_t q = blockIdx.x;
     const uint32_t keep_cap = p.cap / 2;
-    const uint32_t m = min(p.cnt[q], keep_cap);
+    const uint32_t m0 = min(p.cnt[q], keep_cap);
     const uint64_t* c = p.cand + (size_t)q * p.cap;
+    // only the candidates the scoring pass kept (it pads the ones outside the refined threshold: four fifths of an
+    // int8-selected list) are sorted: ~300 of ~1500 on cfg3, a 512-entry network instead of a 2048-entry one
+    __shared__ uint32_t live_s;
+    if (tid == 0) live_s = 0;
+    __syncthreads();
+    for (uint32_t i = tid; i < m0; i += 1024) {
+        const uint64_t e = c[i];
+        if (e != kPadComposite) buf[atomicAdd(&live_s, 1u)] = e;
+    }
+    __syncthreads();
+    const uint32_t m = live_s;
     const uint32_t P2 = next_pow2(m < 2 ? 2 : m);
-    for (uint32_t i = tid; i < P2; i += 1024) buf[i] = i < m ? c[i] : kPadComposite;
+    for (uint32_t i = m + tid; i < P2; i += 1024) buf[i] = kPadComposite;
     __syncthreads();
     bitonic_sort_u64<1024>(buf, P2, tid);
     for (uint32_t i = tid; i < p.k; i += 1024) {
@@ -885,6 +1039,18 @@ hipError_t launch_compact_margin(const CompactParams& p, uint32_t nq, hipStream_
 
 hipError_t launch_rescore(const RescoreParams& p, int metric, uint32_t nq, hipStream_t s) {
     if (nq == 0) return hipSuccess;
+    {
+        const uint32_t sl = (p.cap / 2 + 63u) / 64u;  // a query keeps at most cap / 2 candidates; empty slices cost a read of cnt[q]
+        const bool done = metric == MVF_METRIC_L2       ? launch_rescore_wave<MVF_METRIC_L2, false>(p, nq, sl, nullptr, nullptr, s)
+                          : metric == MVF_METRIC_COSINE ? launch_rescore_wave<MVF_METRIC_COSINE, false>(p, nq, sl, nullptr, nullptr, s)
+                                                        : launch_rescore_wave<MVF_METRIC_INNER_PRODUCT, false>(p, nq, sl, nullptr, nullptr, s);
+        if (done) {
+            hipError_t e = hipGetLastError();
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL(rescore_select_kernel, dim3(nq), dim3(1024), (size_t)(p.cap / 2) * 8, s, p, metric);
+            return hipGetLastError();
+        }
+    }
     const size_t lds = (size_t)((p.dim + 7u) & ~7u) * 4;
     // blocks per query: enough to fill the chip with a small batch, few enough that a block's staged query serves
     // several 16-candidate slices with a large one
@@ -903,6 +1069,18 @@ hipError_t launch_rescore(const RescoreParams& p, int metric, uint32_t nq, hipSt
 hipError_t launch_refine_tau(const RescoreParams& p, int metric, uint32_t nq, const uint32_t* ntop, uint32_t* lkey,
                              const float* delta, hipStream_t s) {
     if (nq == 0) return hipSuccess;
+    {
+        const uint32_t sl = (p.k + 63u) / 64u + 1u;  // k best + ties (a longer head is walked in further rounds of the same waves)
+        const bool done = metric == MVF_METRIC_L2       ? launch_rescore_wave<MVF_METRIC_L2, true>(p, nq, sl, ntop, lkey, s)
+                          : metric == MVF_METRIC_COSINE ? launch_rescore_wave<MVF_METRIC_COSINE, true>(p, nq, sl, ntop, lkey, s)
+                                                        : launch_rescore_wave<MVF_METRIC_INNER_PRODUCT, true>(p, nq, sl, ntop, lkey, s);
+        if (done) {
+            hipError_t e = hipGetLastError();
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL(refine_tau_kernel, dim3((nq + 255u) / 256u), dim3(256), 0, s, p.tau, ntop, lkey, delta, metric, p.k, nq);
+            return hipGetLastError();
+        }
+    }
     const size_t lds = (size_t)((p.dim + 7u) & ~7u) * 4;
     const uint32_t slices = (p.k + 15u) / 16u + 1u;  // k best + a few ties
     const dim3 grid(std::min(slices, 64u), nq);

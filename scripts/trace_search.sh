@@ -27,5 +27,7 @@ print(f"sum of kernel durations {busy:.1f} us (gaps {(t1 - t0) / 1e3 - busy:.1f}
 for k, v in sorted(tot.items(), key=lambda x: -x[1][0]):
     print(f"{v[0]:9.1f} us  x{v[1]:<3d} {k}")
 print("scan launches (us):", [round((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3, 1) for r in rows[s:] if "scan_mfma" in r["Kernel_Name"]])
+for pat in ("scatter_cand", "compact_margin", "rescore_", "refine_tau"):
+    print(pat, "launches (us):", [round((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3, 1) for r in rows[s:] if pat in r["Kernel_Name"]])
 PY
 rm -rf $O; cat gpurun_out/${TAG}_kernels.txt
