@@ -529,11 +529,13 @@ def cfg4_leg(args, torch, G, _lib, oracle, local_rank):
                              "hbm_frac": tm.scan_bytes / (tm.scan_ms_avg * 1e-3) / 1e9 / HBM_PEAK_GBS,
                              "mfma_frac": tm.scan_flops / (tm.scan_ms_avg * 1e-3) / 1e12 / MFMA_I8_PEAK_TOPS,
                              "scan_launches_per_search": tm.scan_launches}
-    tp = os.path.join(ROOT, "profiles", "r03_cfg4_hbm_traffic.json")
+    tp = os.path.join(ROOT, "profiles", "r04_cfg4_hbm_traffic.json")
+    if not os.path.exists(tp):
+        tp = os.path.join(ROOT, "profiles", "r03_cfg4_hbm_traffic.json")
     if os.path.exists(tp):
         prof = json.load(open(tp))
         leg["roofline"]["traffic"] = prof.get("search_traffic_bytes")
-        leg["roofline"]["traffic_source"] = "profiles/r03_cfg4_hbm_traffic.json (separate --pmc passes, FETCH_SIZE x2 + WRITE_SIZE, summed over the search's kernels)"
+        leg["roofline"]["traffic_source"] = "profiles/" + os.path.basename(tp) + " (separate --pmc passes, FETCH_SIZE x2 + WRITE_SIZE, summed over the search's kernels)"
     # bit-exactness of what came back: every returned row of three queries regenerated on the CPU, exact i64 dot
     if oracle is not None:
         q = dq.cpu().numpy()
@@ -874,7 +876,7 @@ def main():
         # wide streaming reads on gfx950 + WRITE_SIZE, MI355X_MICROARCH.md §HBM), so the figure is the committed
         # summary of those passes for this exact workload, not a live measurement.
         if "roofline" in result:
-            for name in ("r03_bench_n1_hbm_traffic.json", "r02_bench_n1_hbm_traffic.json", "r01_bench_n1_hbm_traffic.json"):
+            for name in ("r04_bench_n1_hbm_traffic.json", "r03_bench_n1_hbm_traffic.json", "r02_bench_n1_hbm_traffic.json"):
                 tp = os.path.join(ROOT, "profiles", name)
                 if not os.path.exists(tp) or result["roofline"].get("traffic"):
                     continue
@@ -1005,11 +1007,11 @@ def main():
                 if tmb.samples and tmb.scan_ms_avg > 0 and tmb.scan_kernel >= 2:
                     leg["roofline"] = mfma_roofline(tmb, args.dtype)
                     # HBM bytes per launch from the committed PMC passes of this exact workload and kernel
-                    tp = os.path.join(ROOT, "profiles", {2: "r03_bench_n1_q1024_hbm_traffic.json",
-                                                         4: "r03_bench_n1_q1024_shadow_hbm_traffic.json",
-                                                         6: "r03_bench_n1_q1024_i8_shadow_hbm_traffic.json"}.get(tmb.scan_kernel, "-"))
+                    tp = os.path.join(ROOT, "profiles", {2: "r04_bench_n1_q1024_hbm_traffic.json",
+                                                         4: "r04_bench_n1_q1024_shadow_hbm_traffic.json",
+                                                         6: "r04_bench_n1_q1024_i8_shadow_hbm_traffic.json"}.get(tmb.scan_kernel, "-"))
                     if not os.path.exists(tp):
-                        tp = tp.replace("r03_", "r02_")
+                        tp = tp.replace("r04_", "r03_")
                     if os.path.exists(tp):
                         leg["roofline"]["traffic"] = json.load(open(tp))["roofline_traffic_bytes_per_launch"]
                         leg["roofline"]["traffic_source"] = "profiles/" + os.path.basename(tp)
