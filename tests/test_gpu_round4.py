@@ -223,3 +223,54 @@ def test_large_k_on_a_batch_the_mfma_path_would_take(oracle):
     for qi in (0, 150, 299):
         sc = oracle.scores(rows, 0, 2, q[qi])[0]
         assert_float_topk(2, got.scores[qi], got.indices[qi], sc, rows32, q[qi], k)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Part 4 -- the automatic path choice on the device: what the handle reports after a run of searches
+# ---------------------------------------------------------------------------------------------------------------------
+
+def test_sane_and_wild_norm_corpora_keep_the_int8_selection(oracle):
+    """mvfgpu_corpus_get_info().selection_state: bit 0 = the repair feedback switched the int8-shadow selection off, bit 1 =
+    it switched the folded pre-filter off.  Neither may happen on the benchmark's rows nor on rows whose norms span two
+    orders of magnitude (cosine / inner product: the multiplicative row term of the bounds carries them) -- after eight
+    searches (the feedback consumes samples two searches back) the handle still selects on the int8 shadow."""
+    rng = np.random.default_rng(4)
+    n, dim, nq, k = 200_000, 64, 300, 25
+    wild = (rng.standard_normal((n, dim)) * np.exp(rng.uniform(-2.3, 2.3, n))[:, None]).astype(np.float32)
+    sane = oracle.synth_rows(SEED, 0, n, dim, 0)
+    q = rng.standard_normal((nq, dim)).astype(np.float32)
+    for rows, metrics in ((sane, (G.COSINE, G.L2, G.INNER_PRODUCT)), (wild, (G.COSINE, G.INNER_PRODUCT))):
+        with G.GpuCorpus.from_array(rows) as c:
+            c.set_profiling(True)
+            for i in range(8):
+                c.search(q, k, metrics[i % len(metrics)])
+                assert c.last_timing().repaired_queries == 0
+            inf = c.info()
+            assert inf.selection_state == 0, f"selection_state {inf.selection_state}"
+            assert inf.shadows & 1 and c.last_timing().scan_kernel == 6
+
+
+def test_prefilter_switched_off_by_the_feedback_leaves_the_int8_selection_on(oracle, monkeypatch):
+    """ADVICE r3 (medium), on the device.  Tiny candidate regions make nearly every query of a search overflow while the
+    folded pre-filter is on (one record per wave region); round 2's epilogue spills a full region into the per-query list
+    and needs no repair.  So: the first searches are repaired, the feedback switches the pre-filter off (selection_state
+    2) -- and the NEXT sample consumed still comes from a search that ran with it.  Counted against the fresh totals it
+    used to switch the int8 selection off as well, one search later and for good (selection_state 3, the f16 selection,
+    ~1.6 x slower); it is dropped now: the handle stays at 2, keeps selecting on the int8 shadow and needs no repairs."""
+    n, dim, nq, k = 200_000, 64, 300, 20
+    rows = oracle.synth_rows(SEED, 0, n, dim, 0)
+    q = oracle.synth_queries(SEED + 1, nq, dim, 0)
+    monkeypatch.setenv("MVF_K2_REGION_RECORDS", "4096")
+    want = oracle.search(rows, 0, 2, q, k)
+    with G.GpuCorpus.from_array(rows) as c:
+        c.set_profiling(True)
+        states, repaired = [], []
+        for _ in range(8):
+            got = c.search(q, k, G.COSINE)
+            states.append(c.info().selection_state)
+            repaired.append(c.last_timing().repaired_queries)
+            assert (np.sort(got.indices, axis=1) == np.sort(want[1], axis=1)).mean() >= 0.999   # exact on the way, too
+        assert repaired[0] > nq // 2, repaired                      # the regions WERE too small for the folded pre-filter
+        assert states[0] == 0 and sorted(states) == states and states[-1] == 2, states   # 0 -> 2, never 3
+        assert repaired[-1] == 0 and repaired[-2] == 0, repaired
+        assert c.last_timing().scan_kernel == 6                     # still the int8 kernel on the int8 shadow
