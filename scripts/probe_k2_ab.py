@@ -45,7 +45,12 @@ ALL_VARIANTS = {"lockstep": {"MVF_K2_PP": "0", "MVF_K2_GROWTH": None, "MVF_I8_SH
                 "i8s_ls": {"MVF_K2_PP": "0", "MVF_K2_GROWTH": None, "MVF_I8_SHADOW": "1"},
                 "i8s_pp": {"MVF_K2_PP": "1", "MVF_K2_GROWTH": None, "MVF_I8_SHADOW": "1"},
                 "ls_g4": {"MVF_K2_PP": "0", "MVF_K2_GROWTH": "4", "MVF_I8_SHADOW": "0"},
-                "ls_g3": {"MVF_K2_PP": "0", "MVF_K2_GROWTH": "3", "MVF_I8_SHADOW": "0"}}
+                "ls_g3": {"MVF_K2_PP": "0", "MVF_K2_GROWTH": "3", "MVF_I8_SHADOW": "0"},
+                # round 4: the f16 selection (no int8 shadow) on the lockstep kernel with / without the folded pre-filter, and on
+                # the ping-pong kernel (round 2's epilogue)
+                "f16_ls_bias": {"MVF_K2_PP": "0", "MVF_K2_GROWTH": None, "MVF_I8_SHADOW": "0", "MVF_K2_BIAS": None},
+                "f16_ls_old": {"MVF_K2_PP": "0", "MVF_K2_GROWTH": None, "MVF_I8_SHADOW": "0", "MVF_K2_BIAS": "0"},
+                "f16_pp": {"MVF_K2_PP": "1", "MVF_K2_GROWTH": None, "MVF_I8_SHADOW": "0", "MVF_K2_BIAS": None}}
 VARIANTS = [(v, ALL_VARIANTS[v]) for v in (sys.argv[3].split(",") if len(sys.argv) > 3 else ["lockstep", "pingpong"])]
 
 
