@@ -776,7 +776,8 @@ __global__ void __launch_bounds__(256) rescore_score_kernel(RescoreParams p, con
 // VPL = 16-byte row vectors per lane (rows of up to 64 VPL vectors: 768 x f32 = 3, 1024 x f16 = 2); longer rows keep the
 // block kernel.
 template <int METRIC, bool REFINE, bool F16ROWS, int VPL>
-__global__ void __launch_bounds__(256) rescore_wave_kernel(RescoreParams p, uint32_t nq, uint32_t slices, const uint32_t* ntop, uint32_t* lkey) {
+__global__ void __launch_bounds__(256) rescore_wave_kernel(RescoreParams p, uint32_t nq, uint32_t slices, uint32_t split, const uint32_t* ntop,
+                                                            uint32_t* lkey) {
     constexpr int EPV = F16ROWS ? 8 : 4;  // query floats per row vector
     const int lane = threadIdx.x & 63;
     const uint32_t wave = (blockIdx.x * 256u + threadIdx.x) >> 6, nwaves = (gridDim.x * 256u) >> 6;
@@ -785,8 +786,10 @@ __global__ void __launch_bounds__(256) rescore_wave_kernel(RescoreParams p, uint
     // items in SLICE-major order (item = slice * nq + query): every wave meets low slices -- the ones that exist -- first, the
     // empty tail of the longest possible list costs each wave a few reads of cnt[q].  (Query-major order with a power-of-two
     // slice count gave wave w the slice w % slices of every query it met: two thirds of the waves never found work.)
-    for (uint32_t item = wave; item < nq * slices; item += nwaves) {
-        const uint32_t q = item % nq, sl0 = item / nq;
+    // small batches: `split` waves share a slice -- every one of them reads its 64 candidates and forms the same ballot, wave
+    // `part` scores the rounds part, part + split, ... (64 queries: 192 refinement items became 3072)
+    for (uint32_t item = wave; item < nq * slices * split; item += nwaves) {
+        const uint32_t q = item % nq, sl0 = (item / nq) % slices, part = item / (nq * slices);
         const uint32_t m = REFINE ? (ntop[q] >= p.k ? min(ntop[q], keep_cap) : 0u) : min(p.cnt[q], keep_cap);
         if (sl0 * 64u >= m) continue;  // wave-uniform
         // this lane's share of the query (zero beyond the dimension: the rows' padding is zero too, but 0 x NaN is not)
@@ -811,10 +814,15 @@ __global__ void __launch_bounds__(256) rescore_wave_kernel(RescoreParams p, uint
             const uint64_t ce = ci < m ? c[ci] : kPadComposite;
             // outside the (possibly refined) threshold: cannot be in the top-k; not fetched, not scored
             const bool live = ci < m && (REFINE || tau_q == kNanKey || (uint32_t)(ce >> 32) <= tau_q);
-            if (!REFINE && ci < m && !live) c[ci] = kPadComposite;
+            if (!REFINE && part == 0 && ci < m && !live) c[ci] = kPadComposite;
             const uint32_t myrow = (uint32_t)ce;
             unsigned long long mask = __builtin_amdgcn_ballot_w64(live);
-            while (mask) {  // wave-uniform
+            for (uint32_t rnd = 0; mask; rnd++) {  // wave-uniform
+                if (split > 1 && rnd % split != part) {  // another wave's round: drop its four candidates
+#pragma unroll
+                    for (int u = 0; u < 4; u++) mask &= mask - 1;
+                    continue;
+                }
                 int l[4];
                 uint32_t r[4];
                 bool ok[4];
@@ -887,13 +895,17 @@ template <int METRIC, bool REFINE>
 bool launch_rescore_wave(const RescoreParams& p, uint32_t nq, uint32_t slices, const uint32_t* ntop, uint32_t* lkey, hipStream_t s) {
     const uint32_t V = p.pitch / 16, vpl = (V + 63u) / 64u;
     if (vpl == 0 || vpl > 4u || (p.dtype != MVF_DTYPE_FLOAT32 && p.dtype != MVF_DTYPE_FLOAT16)) return false;  // longer rows: the block kernel
-    const uint32_t items = nq * slices;
+    // waves that share a slice: enough items to fill the chip with a small batch (a slice holds at most 16 rounds)
+    // REFINE only: the final pass writes the exact keys back into the list in place, and a wave that started late would
+    // read them as if they were the approximate ones (its ballot, and with it the partition of the rounds, would differ)
+    const uint32_t split = REFINE ? std::max(1u, std::min(16u, 4096u / std::max(1u, nq * slices))) : 1u;
+    const uint32_t items = nq * slices * split;
     const dim3 grid(std::max(1u, std::min((items + 3u) / 4u, 2048u)));
     const bool h = p.dtype == MVF_DTYPE_FLOAT16;
 #define MVF_RW(VPL_)                                                                                                          \
     do {                                                                                                                      \
-        if (h) hipLaunchKernelGGL((rescore_wave_kernel<METRIC, REFINE, true, VPL_>), grid, dim3(256), 0, s, p, nq, slices, ntop, lkey);  \
-        else hipLaunchKernelGGL((rescore_wave_kernel<METRIC, REFINE, false, VPL_>), grid, dim3(256), 0, s, p, nq, slices, ntop, lkey);   \
+        if (h) hipLaunchKernelGGL((rescore_wave_kernel<METRIC, REFINE, true, VPL_>), grid, dim3(256), 0, s, p, nq, slices, split, ntop, lkey);  \
+        else hipLaunchKernelGGL((rescore_wave_kernel<METRIC, REFINE, false, VPL_>), grid, dim3(256), 0, s, p, nq, slices, split, ntop, lkey);   \
     } while (0)
     switch (vpl) {
     case 1: MVF_RW(1); break;
