@@ -70,6 +70,28 @@ struct DevBuf {
     }
 };
 
+// Pinned host memory the device reads and writes in place (hipHostMalloc: mapped, coherent): the host-buffer API's
+// mirrors for small queries / results.
+struct PinBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    hipError_t reserve(size_t need) {
+        if (need <= bytes) return hipSuccess;
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        bytes = 0;
+        need = (need + 4095) & ~(size_t)4095;
+        hipError_t e = hipHostMalloc(&p, need, hipHostMallocDefault);
+        if (e == hipSuccess) bytes = need;
+        return e;
+    }
+    void release() {
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+};
+
 }  // namespace
 
 namespace mvf {
@@ -105,6 +127,8 @@ Tuning read_tuning() {
     t.stream_i8 = flag("MVF_STREAM_I8", false);
     t.stream_shadow = flag("MVF_STREAM_SHADOW", false);
     t.upload_threads = (unsigned)std::max(0l, num("MVF_UPLOAD_THREADS", 0));
+    t.host_zc_query = (size_t)std::max(0l, num("MVF_HOST_ZC_QUERY", 64l << 10));
+    t.host_zc_results = (size_t)std::max(0l, num("MVF_HOST_ZC_RESULTS", 256l << 10));
     return t;
 }
 }  // namespace mvf
@@ -157,6 +181,7 @@ struct mvfgpu_corpus {
     mutable bool xnorm_ready = false;
     mutable uint32_t bstate_slots = 0;    // queries the K2 state arrays are armed for
     mutable DevBuf h_q, h_s, h_i, h_r;    // device mirrors for the host-buffer API
+    mutable PinBuf pin_q, pin_out;        // ... and its pinned host mirrors (small queries / results: no copy engine at all)
     mutable hipStream_t own_stream = nullptr;
     hipStream_t up_stream = nullptr;      // upload pipeline: re-pitch / norms / shadow of chunk i beside the copy of chunk i+1
     mutable hipEvent_t ev_done = nullptr;
@@ -311,7 +336,8 @@ int search_stream_path(const mvfgpu_corpus* c, uint8_t metric, const void* d_que
         }
         uint32_t nchunks = (uint32_t)((c->n + chunk_rows - 1) / chunk_rows);
         if (lds > 160 * 1024) return fail(MVF_ERR_BUILD, "dimension too large for the streaming kernel's LDS query tile");
-        const uint32_t nq_here = std::min<uint32_t>(nqv, nq - q0);
+        uint32_t nq_here = std::min<uint32_t>(nqv, nq - q0);
+        uint32_t npass = 1;  // passes of nqv queries in this launch (grid.y)
 
         uint32_t nblocks = 0;
         if (nchunks > 0) {
@@ -350,7 +376,15 @@ int search_stream_path(const mvfgpu_corpus* c, uint8_t metric, const void* d_que
                 }
             }
             nblocks = std::min<uint32_t>(nchunks, (uint32_t)occ * (uint32_t)c->num_cus);
-            HIP_TRY(c->cand.reserve((size_t)nq_here * nblocks * kcap * 8));
+            // A corpus that leaves most of the GPU idle (one small chunk per block and blocks to spare) takes ALL its four-query
+            // passes in one launch, pass = blockIdx.y: the passes of a small batch were launch pairs in a row, ~40 us each
+            // (10k x 128 f32, 16 queries: 165 -> 50 us; profiles/r04_host_api_latency.txt).  Up to 8 passes = every batch the
+            // small-corpus rule of use_batched_path leaves to this kernel.
+            if (nqv == 4 && !alt && !floor1 && nblocks == nchunks && 2u * nblocks <= (uint32_t)occ * (uint32_t)c->num_cus) {
+                npass = std::min<uint32_t>(8u, (nq - q0 + 3u) / 4u);
+                nq_here = std::min<uint32_t>(npass * 4u, nq - q0);
+            }
+            HIP_TRY(c->cand.reserve((size_t)npass * nqv * nblocks * kcap * 8));
 
             ScanParams sp{};
             sp.rows = alt ? alt->rows : c->d_rows;
@@ -381,12 +415,13 @@ int search_stream_path(const mvfgpu_corpus* c, uint8_t metric, const void* d_que
             if (ps && first) HIP_TRY(hipEventRecord(ps->e[0], s));
             if (alt8) HIP_TRY(scan_stream_launch_dt2x(sp, metric, G, nqv, dim3(nblocks), lds, s));
             else if (alt) HIP_TRY(scan_stream_launch_dt1x(sp, metric, G, nqv, dim3(nblocks), lds, s));
-            else HIP_TRY(scan_launch(c->dtype, sp, metric, G, nqv, dim3(nblocks), lds, s));
+            else HIP_TRY(scan_launch(c->dtype, sp, metric, G, nqv, dim3(nblocks, npass), lds, s));
             if (ps && first) {
                 HIP_TRY(hipEventRecord(ps->e[1], s));
                 ps->scanned = true;
                 tm.scan_bytes = (uint64_t)c->n * c->dim * elem_size(kdtype);
                 tm.scan_flops = 2ull * nq_here * c->n * c->dim;
+                if (npass > 1) tm.scan_bytes *= npass;
             }
             tm.scan_launches++;
         }
@@ -1633,6 +1668,8 @@ void mvfgpu_corpus_destroy(mvfgpu_corpus* c) {
         c->h_s.release();
         c->h_i.release();
         c->h_r.release();
+        c->pin_q.release();
+        c->pin_out.release();
         if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
         if (c->up_stream) (void)hipStreamDestroy(c->up_stream);
         for (auto e : c->qs_redo_ev)
@@ -1720,18 +1757,36 @@ int mvfgpu_corpus_gather_rows(const mvfgpu_corpus* c, const uint64_t* indices, u
     DeviceGuard guard(c->device);
     if (!guard.ok) return fail(MVF_ERR_DEVICE, "hipSetDevice failed");
     const uint32_t row_bytes = c->dim * elem_size(c->dtype);
+    // small fetches (the payload rows of one result list) go through pinned host memory in place, like mvfgpu_search's
+    const size_t ibytes = (size_t)count * 8, obytes = (size_t)count * row_bytes;
+    const bool zc_i = ibytes <= c->tune.host_zc_query, zc_o = obytes <= c->tune.host_zc_results;
+    void *di, *dout;
     std::lock_guard<std::mutex> host_lk(c->host_mu);
     {
         std::lock_guard<std::mutex> lk(c->mu);
         if (c->has_done) HIP_TRY(hipEventSynchronize(c->ev_done));
-        HIP_TRY(c->h_i.reserve((size_t)count * 8));
-        HIP_TRY(c->h_q.reserve((size_t)count * row_bytes));
+        if (zc_i) {
+            HIP_TRY(c->pin_q.reserve(ibytes));
+            memcpy(c->pin_q.p, indices, ibytes);
+            di = c->pin_q.p;
+        } else {
+            HIP_TRY(c->h_i.reserve(ibytes));
+            di = c->h_i.p;
+        }
+        if (zc_o) {
+            HIP_TRY(c->pin_out.reserve(obytes));
+            dout = c->pin_out.p;
+        } else {
+            HIP_TRY(c->h_q.reserve(obytes));
+            dout = c->h_q.p;
+        }
     }
-    HIP_TRY(hipMemcpyAsync(c->h_i.p, indices, (size_t)count * 8, hipMemcpyHostToDevice, c->own_stream));
-    HIP_TRY(launch_gather_rows(c->d_rows, c->n, c->pitch, row_bytes, c->index_base, static_cast<const uint64_t*>(c->h_i.p),
-                               (uint32_t)count, static_cast<unsigned char*>(c->h_q.p), c->own_stream));
-    HIP_TRY(hipMemcpyAsync(out_rows, c->h_q.p, (size_t)count * row_bytes, hipMemcpyDeviceToHost, c->own_stream));
+    if (!zc_i) HIP_TRY(hipMemcpyAsync(di, indices, ibytes, hipMemcpyHostToDevice, c->own_stream));
+    HIP_TRY(launch_gather_rows(c->d_rows, c->n, c->pitch, row_bytes, c->index_base, static_cast<const uint64_t*>(di),
+                               (uint32_t)count, static_cast<unsigned char*>(dout), c->own_stream));
+    if (!zc_o) HIP_TRY(hipMemcpyAsync(out_rows, dout, obytes, hipMemcpyDeviceToHost, c->own_stream));
     HIP_TRY(hipStreamSynchronize(c->own_stream));
+    if (zc_o) memcpy(out_rows, dout, obytes);
     return MVF_OK;
 }
 
@@ -1869,25 +1924,51 @@ int mvfgpu_search(const mvfgpu_corpus* c, uint8_t metric, const void* queries, u
     if (!guard.ok) return fail(MVF_ERR_DEVICE, "hipSetDevice failed");
     const size_t qbytes = (size_t)nq * c->dim * (is_int_dtype(c->dtype) ? 1 : 4);
     const size_t nres = (size_t)nq * k;
+    // Small queries / results skip the copy engine: the query is copied (by the CPU) into pinned host memory the kernels
+    // read in place, and the selection kernels write the results into pinned host memory -- 10k x 128 f32, top-10:
+    // 65 -> 30 us per call (profiles/r04_host_api_latency.txt); three staged hipMemcpyAsync of pageable memory cost more
+    // than the search.  Larger transfers keep the device mirrors (a kernel reading megabytes over PCIe stalls its blocks).
+    const size_t out_bytes = nres * 16;
+    const bool zc_q = qbytes <= c->tune.host_zc_query, zc_out = out_bytes <= c->tune.host_zc_results;
     void *dq, *ds, *di, *dr;
     std::lock_guard<std::mutex> host_lk(c->host_mu);
     {
         std::lock_guard<std::mutex> lk(c->mu);
         // wait for any in-flight user of the mirrors before (re)allocating them
         if (c->has_done) HIP_TRY(hipEventSynchronize(c->ev_done));
-        HIP_TRY(c->h_q.reserve(qbytes));
-        HIP_TRY(c->h_s.reserve(nres * 4));
-        HIP_TRY(c->h_i.reserve(nres * 8));
-        HIP_TRY(c->h_r.reserve(nres * 4));
-        dq = c->h_q.p;
-        ds = c->h_s.p;
-        di = c->h_i.p;
-        dr = c->h_r.p;
-        HIP_TRY(hipMemcpyAsync(dq, queries, qbytes, hipMemcpyHostToDevice, c->own_stream));
+        if (zc_q) {
+            HIP_TRY(c->pin_q.reserve(qbytes));
+            memcpy(c->pin_q.p, queries, qbytes);
+            dq = c->pin_q.p;
+        } else {
+            HIP_TRY(c->h_q.reserve(qbytes));
+            dq = c->h_q.p;
+            HIP_TRY(hipMemcpyAsync(dq, queries, qbytes, hipMemcpyHostToDevice, c->own_stream));
+        }
+        if (zc_out) {
+            HIP_TRY(c->pin_out.reserve(nres * 16));
+            di = c->pin_out.p;  // u64[nres] | f32[nres] | i32[nres]
+            ds = static_cast<unsigned char*>(c->pin_out.p) + nres * 8;
+            dr = static_cast<unsigned char*>(c->pin_out.p) + nres * 12;
+        } else {
+            HIP_TRY(c->h_s.reserve(nres * 4));
+            HIP_TRY(c->h_i.reserve(nres * 8));
+            HIP_TRY(c->h_r.reserve(nres * 4));
+            ds = c->h_s.p;
+            di = c->h_i.p;
+            dr = c->h_r.p;
+        }
     }
     rc = mvfgpu_search_device(c, metric, dq, query_dtype, query_dim, nq, k, static_cast<float*>(ds),
                               static_cast<uint64_t*>(di), static_cast<int32_t*>(dr), c->own_stream);
     if (rc != MVF_OK) return rc;
+    if (zc_out) {
+        HIP_TRY(hipStreamSynchronize(c->own_stream));
+        memcpy(out_scores, ds, nres * 4);
+        memcpy(out_indices, di, nres * 8);
+        if (out_raw) memcpy(out_raw, dr, nres * 4);
+        return MVF_OK;
+    }
     HIP_TRY(hipMemcpyAsync(out_scores, ds, nres * 4, hipMemcpyDeviceToHost, c->own_stream));
     HIP_TRY(hipMemcpyAsync(out_indices, di, nres * 8, hipMemcpyDeviceToHost, c->own_stream));
     if (out_raw) HIP_TRY(hipMemcpyAsync(out_raw, dr, nres * 4, hipMemcpyDeviceToHost, c->own_stream));

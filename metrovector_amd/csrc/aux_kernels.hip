@@ -324,17 +324,19 @@ __global__ void repack_rows_kernel(const unsigned char* src, unsigned char* dst,
 
 // Payload gather: rows[idx[i] - index_base] -> out[i] (tightly packed, row_bytes each); out-of-range / padding
 // indices give zero rows.  One wave per row, byte granular (result sets are tiny).
+template <typename T>  // the copy unit: 16 bytes when the row size allows it (stored rows start on 16-byte pitches), else 4 or 1
 __global__ void __launch_bounds__(256) gather_rows_kernel(const unsigned char* rows, uint64_t n, uint32_t pitch,
                                                            uint32_t row_bytes, uint64_t index_base, const uint64_t* idx,
                                                            uint32_t count, unsigned char* out) {
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = (blockIdx.x * 256u + threadIdx.x) >> 6, nwaves = (gridDim.x * 256u) >> 6;
+    const uint32_t units = row_bytes / (uint32_t)sizeof(T);
     for (uint32_t i = wave; i < count; i += nwaves) {
         const uint64_t g = idx[i];
         const bool ok = g >= index_base && g - index_base < n;
-        const unsigned char* src = rows + (ok ? (g - index_base) : 0) * pitch;
-        unsigned char* dst = out + (size_t)i * row_bytes;
-        for (uint32_t b = lane; b < row_bytes; b += 64) dst[b] = ok ? src[b] : (unsigned char)0;
+        const T* src = reinterpret_cast<const T*>(rows + (ok ? (g - index_base) : 0) * pitch);
+        T* dst = reinterpret_cast<T*>(out + (size_t)i * row_bytes);
+        for (uint32_t b = lane; b < units; b += 64) dst[b] = ok ? src[b] : T{};
     }
 }
 
@@ -400,7 +402,10 @@ hipError_t launch_gather_rows(const unsigned char* rows, uint64_t n, uint32_t pi
                               const uint64_t* d_idx, uint32_t count, unsigned char* d_out, hipStream_t s) {
     if (count == 0) return hipSuccess;
     const uint32_t blocks = std::min<uint32_t>((count + 3) / 4, 2048u);
-    hipLaunchKernelGGL(gather_rows_kernel, dim3(blocks), dim3(256), 0, s, rows, n, pitch, row_bytes, index_base, d_idx, count, d_out);
+    const uint64_t al = row_bytes | reinterpret_cast<uintptr_t>(d_out);
+    if (al % 16 == 0) hipLaunchKernelGGL(gather_rows_kernel<uint4>, dim3(blocks), dim3(256), 0, s, rows, n, pitch, row_bytes, index_base, d_idx, count, d_out);
+    else if (al % 4 == 0) hipLaunchKernelGGL(gather_rows_kernel<uint32_t>, dim3(blocks), dim3(256), 0, s, rows, n, pitch, row_bytes, index_base, d_idx, count, d_out);
+    else hipLaunchKernelGGL(gather_rows_kernel<unsigned char>, dim3(blocks), dim3(256), 0, s, rows, n, pitch, row_bytes, index_base, d_idx, count, d_out);
     return hipGetLastError();
 }
 

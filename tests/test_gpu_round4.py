@@ -274,3 +274,83 @@ def test_prefilter_switched_off_by_the_feedback_leaves_the_int8_selection_on(ora
         assert states[0] == 0 and sorted(states) == states and states[-1] == 2, states   # 0 -> 2, never 3
         assert repaired[-1] == 0 and repaired[-2] == 0, repaired
         assert c.last_timing().scan_kernel == 6                     # still the int8 kernel on the int8 shadow
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Part 5 -- small searches (BASELINE configs[0] and the reference example's own sizes): the host API reads the query and
+# writes the results in pinned host memory (no copy engine), and a small corpus takes the four-query passes of a batch
+# in ONE launch (pass = blockIdx.y)
+# ---------------------------------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("dtype", [0, 1, 2, 3])
+@pytest.mark.parametrize("metric", [G.L2, G.INNER_PRODUCT, G.COSINE])
+def test_small_corpus_batches_take_their_passes_in_one_launch(oracle, dtype, metric):
+    """Batches of 2 .. 31 queries on corpora that leave the GPU mostly idle (60 .. 40 000 rows): up to 8 four-query
+    passes per launch, the last one padded; against the oracle, with deleted rows and an index base."""
+    rng = np.random.default_rng(100 * dtype + metric)
+    for (n, dim, k) in ((60, 4, 5), (10_000, 128, 10), (40_000, 40, 100), (3_000, 300, 33)):
+        rows = oracle.synth_rows(SEED + n, 0, n, dim, dtype)
+        dead = rng.random(n) < 0.1
+        live = np.nonzero(~dead)[0]
+        with G.GpuCorpus.from_array(rows, index_base=1_000) as c:
+            c.set_tombstones(np.packbits(dead, bitorder="little"))
+            for nq in (2, 5, 8, 9, 16, 29, 31):
+                q = oracle.synth_queries(SEED + 1 + nq, nq, dim, dtype)
+                got = c.search(q, k, metric)
+                osc, oidx, oraw = oracle.search(rows[live], dtype, metric, q, min(k, len(live)))
+                oidx = live[oidx.astype(np.int64)].astype(np.uint64) + np.uint64(1_000)
+                kk = osc.shape[1]
+                if dtype in (2, 3):
+                    assert (got.indices[:, :kk] == oidx).all() and (got.raw[:, :kk] == oraw).all(), (n, nq)
+                    assert (got.scores[:, :kk].view(np.uint32) == osc.view(np.uint32)).all(), (n, nq)
+                else:
+                    rows32 = rows.astype(np.float32)
+                    for qi in (0, nq // 2, nq - 1):
+                        sc = oracle.scores(rows, dtype, metric, q[qi])[0]
+                        sc = np.where(dead, np.inf if metric == G.L2 else -np.inf, sc).astype(np.float32)
+                        assert_float_topk(metric, got.scores[qi, :kk], got.indices[qi, :kk], sc, rows32, q[qi], kk, index_base=1_000)
+                    one = c.search(q[nq - 1], k, metric)      # the same query through the single-query kernel
+                    assert (one.indices[0] == got.indices[nq - 1]).all(), (n, nq)
+
+
+def test_host_api_in_place_buffers_agree_with_the_copy_path(oracle, monkeypatch):
+    """mvfgpu_search with the query read / the results written in pinned host memory (the default for small transfers)
+    returns what the staged-copy path returns, bit for bit, on both sides of the size limits; the limits come from the
+    handle's tuning (MVF_HOST_ZC_QUERY / MVF_HOST_ZC_RESULTS, bytes)."""
+    n, dim = 50_000, 96
+    for dtype, metric in ((0, G.COSINE), (1, G.L2), (2, G.INNER_PRODUCT)):
+        rows = oracle.synth_rows(SEED, 0, n, dim, dtype)
+        with G.GpuCorpus.from_array(rows) as c:
+            for nq, k in ((1, 10), (1, 1024), (4, 100), (40, 100), (64, 1024), (200, 10), (1, 5000)):
+                q = oracle.synth_queries(SEED + 1, nq, dim, dtype)
+                res = []
+                for zq, zo in ((None, None), ("0", "0"), ("0", None), (None, "0"), ("100", "100000")):
+                    for var, val in (("MVF_HOST_ZC_QUERY", zq), ("MVF_HOST_ZC_RESULTS", zo)):
+                        monkeypatch.delenv(var, raising=False) if val is None else monkeypatch.setenv(var, val)
+                    c.reload_tuning()
+                    res.append(c.search(q, k, metric))
+                for r in res[1:]:
+                    assert (r.indices == res[0].indices).all() and (r.raw == res[0].raw).all(), (dtype, nq, k)
+                    assert (r.scores.view(np.uint32) == res[0].scores.view(np.uint32)).all(), (dtype, nq, k)
+            monkeypatch.delenv("MVF_HOST_ZC_QUERY", raising=False)
+            monkeypatch.delenv("MVF_HOST_ZC_RESULTS", raising=False)
+
+
+def test_payload_fetch_in_place_and_by_copy(oracle, monkeypatch):
+    """mvfgpu_corpus_gather_rows (the payload of ScoredVector.vector, examples/similarity_search.rs:18): small fetches are
+    written straight into pinned host memory, large ones through the device mirror; 16-, 4- and 1-byte copy units."""
+    rng = np.random.default_rng(5)
+    for dtype, dim in ((0, 96), (1, 6), (2, 7), (3, 64), (0, 771)):
+        n = 20_000
+        rows = oracle.synth_rows(SEED, 0, n, dim, dtype)
+        with G.GpuCorpus.from_array(rows, index_base=500) as c:
+            for count in (1, 10, 100, 3000):
+                idx = rng.integers(0, n, count).astype(np.uint64)
+                for zq, zo in ((None, None), ("0", "0"), ("16", "1000")):
+                    for var, val in (("MVF_HOST_ZC_QUERY", zq), ("MVF_HOST_ZC_RESULTS", zo)):
+                        monkeypatch.delenv(var, raising=False) if val is None else monkeypatch.setenv(var, val)
+                    c.reload_tuning()
+                    got = c.gather_rows(idx + np.uint64(500))
+                    assert got.dtype == rows.dtype and (got.view(np.uint8) == rows[idx.astype(np.int64)].view(np.uint8)).all(), (dtype, dim, count, zq)
+        monkeypatch.delenv("MVF_HOST_ZC_QUERY", raising=False)
+        monkeypatch.delenv("MVF_HOST_ZC_RESULTS", raising=False)
