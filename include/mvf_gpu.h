@@ -410,7 +410,7 @@ int mvfgpu_last_timing(const mvfgpu_corpus* corpus, mvfgpu_timing* out);
 int mvfgpu_set_scan_path(mvfgpu_corpus* corpus, int path);
 
 /*
- * The tuning switches of the environment (MVF_K1_G, MVF_K2_*, MVF_I8_SHADOW, MVF_F16_SHADOW, MVF_QS_REFINE,
+ * The tuning switches of the environment (MVF_K1_G, MVF_K1_RANK_MERGE, MVF_K2_*, MVF_I8_SHADOW, MVF_F16_SHADOW, MVF_QS_REFINE,
  * MVF_STREAM_*, MVF_REPAIR_WINDOW, MVF_UPLOAD_THREADS, MVF_HOST_ZC_*, MVF_DEBUG_REPAIR; INTEGRATION.md lists them) are read ONCE per
  * handle, when it is created: a search never calls getenv.  An A/B script that changes the environment of a live handle
  * calls this to have it read again.

@@ -127,6 +127,7 @@ Tuning read_tuning() {
     t.stream_i8 = flag("MVF_STREAM_I8", false);
     t.stream_shadow = flag("MVF_STREAM_SHADOW", false);
     t.upload_threads = (unsigned)std::max(0l, num("MVF_UPLOAD_THREADS", 0));
+    t.k1_rank_merge = (uint32_t)std::min(256l, std::max(0l, num("MVF_K1_RANK_MERGE", 128)));
     t.host_zc_query = (size_t)std::max(0l, num("MVF_HOST_ZC_QUERY", 64l << 10));
     t.host_zc_results = (size_t)std::max(0l, num("MVF_HOST_ZC_RESULTS", 256l << 10));
     return t;
@@ -411,6 +412,7 @@ int search_stream_path(const mvfgpu_corpus* c, uint8_t metric, const void* d_que
             sp.chunk_rows = chunk_rows;
             sp.chunk_safe = std::min(scan_chunk_safe(G), chunk_rows);
             sp.nchunks = nchunks;
+            sp.rank_merge_max = c->tune.k1_rank_merge;
             sp.floor1 = floor1;
             if (ps && first) HIP_TRY(hipEventRecord(ps->e[0], s));
             if (alt8) HIP_TRY(scan_stream_launch_dt2x(sp, metric, G, nqv, dim3(nblocks), lds, s));
@@ -758,6 +760,7 @@ int repair_flagged_queries(const mvfgpu_corpus* c, uint8_t metric, const void* d
         sp.chunk_rows = chunk_rows;
         sp.chunk_safe = std::min(scan_chunk_safe(G), chunk_rows);
         sp.nchunks = nchunks;
+        sp.rank_merge_max = c->tune.k1_rank_merge;
         sp.redo_list = redo_list;
         sp.redo_cnt = redo_cnt;
         sp.redo_base = base;

@@ -42,4 +42,44 @@ __device__ __forceinline__ void bitonic_sort_u64(uint64_t* buf, uint32_t P, int 
     }
 }
 
+// Merge of a few new composites into a short sorted list, by counting instead of sorting: buf[0 .. kp) ascending (kp <= NT),
+// buf[kp .. kp + c) in any order (c <= NT), all composites distinct; afterwards buf[0 .. min(kp + c, k)) holds the smallest
+// of them ascending (whatever ranks at k or behind is dropped).  An element's place = the number of elements in front of it:
+// an old one keeps its index plus the new ones below it, a new one counts the new ones below it plus the old ones (counted
+// one by one while the list is short, by bisection beyond that).  Two barriers and c (+ kp) broadcast reads, where the sort
+// network on next_pow2(kp + c) entries takes log^2 steps with a barrier each -- the usual merge of a scan's piece brings a
+// dozen survivors to a list of k.  One old and one new element per thread: a handful of registers (the callers' row loops
+// set their kernels' register counts; this must not).  The caller has synchronised after the last append; the list is
+// complete on return.
+template <int NT>
+__device__ __forceinline__ void merge_ranked_u64(uint64_t* buf, uint32_t kp, uint32_t c, uint32_t k, int tid) {
+    const bool has_old = (uint32_t)tid < kp, has_new = (uint32_t)tid < c;
+    const uint64_t ov = has_old ? buf[tid] : 0ull;  // 0: nothing ranks below it
+    const uint64_t nv = has_new ? buf[kp + (uint32_t)tid] : 0ull;
+    uint32_t orank = (uint32_t)tid, nrank = 0;
+    const uint64_t* nb = buf + kp;
+    for (uint32_t n = 0; n < c; n++) {
+        const uint64_t e = nb[n];
+        orank += e < ov ? 1u : 0u;
+        nrank += e < nv ? 1u : 0u;
+    }
+    if ((uint32_t)(tid & ~63) < c) {  // the waves that hold new elements
+        if (kp <= 128u) {
+            for (uint32_t j = 0; j < kp; j++) nrank += buf[j] < nv ? 1u : 0u;
+        } else {
+            uint32_t lo = 0, hi = kp;
+            while (lo < hi) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (buf[mid] < nv) lo = mid + 1;
+                else hi = mid;
+            }
+            nrank += lo;
+        }
+    }
+    __syncthreads();
+    if (has_old && orank != (uint32_t)tid && orank < k) buf[orank] = ov;
+    if (has_new && nrank < k) buf[nrank] = nv;
+    __syncthreads();
+}
+
 }  // namespace mvf

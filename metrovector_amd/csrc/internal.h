@@ -46,6 +46,7 @@ struct Tuning {
     bool stream_i8 = false;     // MVF_STREAM_I8=1
     bool stream_shadow = false; // MVF_STREAM_SHADOW=1
     unsigned upload_threads = 0;  // MVF_UPLOAD_THREADS
+    uint32_t k1_rank_merge = 128;  // MVF_K1_RANK_MERGE: a piece's survivors up to this many are merged by counting (0: always sorted; <= 256)
     size_t host_zc_query = 64u << 10;     // MVF_HOST_ZC_QUERY: mvfgpu_search reads queries up to this size in place (pinned host)
     size_t host_zc_results = 256u << 10;  // MVF_HOST_ZC_RESULTS: ... and writes results up to this size in place
 };

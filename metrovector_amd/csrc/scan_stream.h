@@ -31,6 +31,7 @@ struct ScanParams {
     uint32_t chunk_rows;        // rows per chunk (blocks take chunks in turn); a multiple of 16*64/G
     uint32_t chunk_safe;        // rows per piece that cannot overflow the buffer (<= chunk_rows)
     uint32_t nchunks;
+    uint32_t rank_merge_max;    // a piece's survivors up to this many join the list by counting (bitonic.h); 0: always the sort network
     // REPAIR launches (api.hip: queries whose K2 candidate budget overflowed are redone exactly, decided ON THE DEVICE):
     // the queries are redo_list[redo_base + i], i < min(*redo_cnt - redo_base, redo_max); the block walks them in
     // groups of NQ (one pass over the rows per group) and emits list (i, block).  *redo_cnt <= redo_base: exit at once.
