@@ -26,6 +26,9 @@ extern "C" {
     fn mvfgpu_search(corpus: *const MvfGpuCorpus, metric: u8, queries: *const c_void, query_dtype: u8,
                      query_dim: u32, nq: u32, k: u32, out_scores: *mut f32, out_indices: *mut u64,
                      out_raw: *mut i32) -> c_int;
+    fn mvfgpu_search_fetch(corpus: *const MvfGpuCorpus, metric: u8, queries: *const c_void, query_dtype: u8,
+                           query_dim: u32, nq: u32, k: u32, out_scores: *mut f32, out_indices: *mut u64,
+                           out_raw: *mut i32, out_vectors: *mut c_void) -> c_int;
     fn mvfgpu_last_error_message() -> *const c_char;
     /// `MVFGPU_ABI_VERSION` of the loaded library (include/mvf_gpu.h): struct layouts and signatures this file mirrors.
     fn mvfgpu_abi_version() -> u32;
@@ -121,6 +124,7 @@ fn elem_size(dt: DataType) -> Result<usize> {
 pub struct GpuCorpus {
     handle: *mut MvfGpuCorpus,
     dimension: u32,
+    float32: bool,
 }
 
 unsafe impl Send for GpuCorpus {}
@@ -141,7 +145,7 @@ impl GpuCorpus {
         if rc != 0 {
             return Err(status_to_error(rc));
         }
-        Ok(Self { handle, dimension: space.dimension() })
+        Ok(Self { handle, dimension: space.dimension(), float32: space.data_type().0 == DataType::Float32.0 })
     }
 
     /// k best rows for one f32 query, best first: (index, score).
@@ -158,6 +162,31 @@ impl GpuCorpus {
         }
         let _ = self.dimension;
         Ok(indices.into_iter().zip(scores).take_while(|(i, _)| *i != u64::MAX).collect())
+    }
+
+    /// The k best rows WITH their payload -- the reference's `ScoredVector { index, score, vector }`
+    /// (examples/similarity_search.rs:14-19) -- in one call: the rows are gathered on the GPU behind the search.
+    /// Float32 spaces only (the payload comes back in the stored type; a Float16 space would need the widening of
+    /// `Vector::as_f32`, src/vectors/vector.rs:81-89, on the returned halves).
+    pub fn search_with_vectors(&self, metric: DistanceMetric, query: &[f32], k: usize) -> Result<Vec<(u64, f32, Vec<f32>)>> {
+        if !self.float32 {
+            return Err(MvfError::Build("search_with_vectors: Float32 spaces only".to_string()));
+        }
+        let d = self.dimension as usize;
+        let mut scores = vec![0f32; k];
+        let mut indices = vec![0u64; k];
+        let mut rows = vec![0f32; k * d];
+        let rc = unsafe {
+            mvfgpu_search_fetch(self.handle, metric.0, query.as_ptr() as *const c_void, DataType::Float32.0,
+                                query.len() as u32, 1, k as u32, scores.as_mut_ptr(), indices.as_mut_ptr(),
+                                std::ptr::null_mut(), rows.as_mut_ptr() as *mut c_void)
+        };
+        if rc != 0 {
+            return Err(status_to_error(rc));
+        }
+        Ok((0..k).take_while(|&i| indices[i] != u64::MAX)
+            .map(|i| (indices[i], scores[i], rows[i * d..(i + 1) * d].to_vec()))
+            .collect())
     }
 
     /// Batched search: `queries` holds `nq` rows of `dimension` f32 values; returns `nq` lists of up to `k` hits.
@@ -240,7 +269,7 @@ impl ShardedCorpus {
             if rc != 0 {
                 return Err(status_to_error(rc));
             }
-            shards.push(GpuCorpus { handle, dimension: space.dimension() });
+            shards.push(GpuCorpus { handle, dimension: space.dimension(), float32: space.data_type().0 == DataType::Float32.0 });
         }
         let handles: Vec<*mut MvfGpuCorpus> = shards.iter().map(|s| s.handle).collect();
         let mut set = std::ptr::null_mut();

@@ -296,18 +296,18 @@ public:
             throw MvfError(MVF_ERR_BUILD, "find_top_k_similar takes f32 queries: Float32 / Float16 spaces");
         std::vector<float> scores(k);
         std::vector<uint64_t> idx(k);
-        detail::check_gpu(mvfgpu_search(c_, (uint8_t)metric_, query.data(), MVF_DTYPE_FLOAT32, (uint32_t)query.size(), 1, (uint32_t)k,
-                                        scores.data(), idx.data(), nullptr));
+        const size_t es = dt_ == DataType::Float32 ? 4 : 2;
+        std::vector<uint8_t> rows(with_vectors ? k * dim_ * es : 0);
+        if (with_vectors)  // the k best and their rows in one call
+            detail::check_gpu(mvfgpu_search_fetch(c_, (uint8_t)metric_, query.data(), MVF_DTYPE_FLOAT32, (uint32_t)query.size(), 1, (uint32_t)k,
+                                                  scores.data(), idx.data(), nullptr, rows.data()));
+        else
+            detail::check_gpu(mvfgpu_search(c_, (uint8_t)metric_, query.data(), MVF_DTYPE_FLOAT32, (uint32_t)query.size(), 1, (uint32_t)k,
+                                            scores.data(), idx.data(), nullptr));
         std::vector<ScoredVector> out;
-        for (size_t i = 0; i < k && idx[i] != ~0ull; i++) out.push_back({idx[i], scores[i], {}});  // fewer than k rows: the tail is padding
-        if (with_vectors && !out.empty()) {
-            std::vector<uint64_t> ids(out.size());
-            for (size_t i = 0; i < out.size(); i++) ids[i] = out[i].index;
-            const size_t es = dt_ == DataType::Float32 ? 4 : 2;
-            std::vector<uint8_t> rows(out.size() * dim_ * es);
-            detail::check_gpu(mvfgpu_corpus_gather_rows(c_, ids.data(), ids.size(), rows.data()));
-            for (size_t i = 0; i < out.size(); i++)
-                out[i].vector = Vector(rows.data() + i * dim_ * es, dim_ * es, dim_, dt_).as_f32();
+        for (size_t i = 0; i < k && idx[i] != ~0ull; i++) {  // fewer than k rows: the tail is padding
+            out.push_back({idx[i], scores[i], {}});
+            if (with_vectors) out.back().vector = Vector(rows.data() + i * dim_ * es, dim_ * es, dim_, dt_).as_f32();
         }
         return out;
     }

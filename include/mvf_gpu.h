@@ -245,6 +245,19 @@ int mvfgpu_search(const mvfgpu_corpus* corpus, uint8_t metric,
                   uint64_t* out_indices, int32_t* out_raw);
 
 /*
+ * The same search, returning the payload as well: out_vectors = host [nq][k][dimension] in the space's stored type
+ * (zero rows behind a short result list) -- what the reference's ScoredVector.vector holds
+ * (examples/similarity_search.rs:18, :159-163).  The rows are gathered on the device behind the search, from the result
+ * indices where the selection kernel left them: one submission and one wait instead of mvfgpu_search +
+ * mvfgpu_corpus_gather_rows (10k x 128 f32, top-10 with vectors: 55 -> 33 us).  A corpus that reports vector ids maps
+ * them back on the host after the search (the two steps, inside this call).
+ */
+int mvfgpu_search_fetch(const mvfgpu_corpus* corpus, uint8_t metric,
+                        const void* queries, uint8_t query_dtype, uint32_t query_dim,
+                        uint32_t nq, uint32_t k, float* out_scores,
+                        uint64_t* out_indices, int32_t* out_raw, void* out_vectors);
+
+/*
  * Same search with queries and outputs RESIDENT ON THE CORPUS' DEVICE,
  * asynchronous on `hip_stream` (a hipStream_t; NULL = the default stream).
  * This is the timed region of bench.py and the producer of the per-shard

@@ -113,6 +113,7 @@ def gpu() -> C.CDLL:
     lib.mvfgpu_corpus_read_rows.argtypes = [vp, u64, u64, vp]
     lib.mvfgpu_corpus_gather_rows.argtypes = [vp, vp, u64, vp]
     lib.mvfgpu_search.argtypes = [vp, u8, vp, u8, u32, u32, u32, vp, vp, vp]
+    lib.mvfgpu_search_fetch.argtypes = [vp, u8, vp, u8, u32, u32, u32, vp, vp, vp, vp]
     lib.mvfgpu_search_device.argtypes = [vp, u8, vp, u8, u32, u32, u32, vp, vp, vp, vp]
     lib.mvfgpu_merge_topk_host.argtypes = [vp, vp, vp, u32, u32, u32, u8, u8, vp, vp, vp]
     lib.mvfgpu_merge_topk_device.argtypes = [vp, vp, vp, u32, u32, u32, u8, u8, vp, vp, vp, i32, vp]
@@ -131,7 +132,7 @@ def gpu() -> C.CDLL:
     for name in ("mvfgpu_device_count", "mvfgpu_corpus_create", "mvfgpu_corpus_create_ex", "mvfgpu_corpus_create_synthetic",
                  "mvfgpu_corpus_set_tombstones", "mvfgpu_corpus_set_vector_ids", "mvfgpu_shardset_create",
                  "mvfgpu_shardset_get_info", "mvfgpu_shardset_search", "mvfgpu_shardset_last_timing",
-                 "mvfgpu_corpus_get_info", "mvfgpu_corpus_read_rows", "mvfgpu_corpus_gather_rows", "mvfgpu_search", "mvfgpu_search_device",
+                 "mvfgpu_corpus_get_info", "mvfgpu_corpus_read_rows", "mvfgpu_corpus_gather_rows", "mvfgpu_search", "mvfgpu_search_fetch", "mvfgpu_search_device",
                  "mvfgpu_merge_topk_host", "mvfgpu_merge_topk_device", "mvfgpu_merge_topk_packed_device",
                  "mvfgpu_synth_queries_device",
                  "mvfgpu_set_profiling", "mvfgpu_last_timing", "mvfgpu_set_scan_path", "mvfgpu_corpus_reload_tuning",

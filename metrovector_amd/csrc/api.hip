@@ -182,7 +182,8 @@ struct mvfgpu_corpus {
     mutable bool xnorm_ready = false;
     mutable uint32_t bstate_slots = 0;    // queries the K2 state arrays are armed for
     mutable DevBuf h_q, h_s, h_i, h_r;    // device mirrors for the host-buffer API
-    mutable PinBuf pin_q, pin_out;        // ... and its pinned host mirrors (small queries / results: no copy engine at all)
+    mutable PinBuf pin_q, pin_out, pin_vec;  // ... and its pinned host mirrors (small queries / results / payload rows: no copy engine at all)
+    mutable DevBuf h_v;                   // payload rows of mvfgpu_search_fetch too large for that
     mutable hipStream_t own_stream = nullptr;
     hipStream_t up_stream = nullptr;      // upload pipeline: re-pitch / norms / shadow of chunk i beside the copy of chunk i+1
     mutable hipEvent_t ev_done = nullptr;
@@ -1673,6 +1674,8 @@ void mvfgpu_corpus_destroy(mvfgpu_corpus* c) {
         c->h_r.release();
         c->pin_q.release();
         c->pin_out.release();
+        c->pin_vec.release();
+        c->h_v.release();
         if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
         if (c->up_stream) (void)hipStreamDestroy(c->up_stream);
         for (auto e : c->qs_redo_ev)
@@ -1703,7 +1706,7 @@ int mvfgpu_corpus_get_info(const mvfgpu_corpus* c, mvfgpu_corpus_info* out) {
         inf.selection_state = (uint8_t)((c->qs_disabled ? 1 : 0) | (c->bias_disabled ? 2 : 0));
         inf.device_bytes = c->tomb.bytes + c->ids.bytes + c->rows_bytes + c->cand.bytes + c->bq.bytes + c->bstate.bytes + c->bcand.bytes +
                            c->xnorm.bytes + c->repair.bytes + c->floor1.bytes + c->blk.bytes + c->shadow8.bytes + c->xscale8.bytes + c->qs_stats.bytes +
-                           c->shadow.bytes + c->xscale.bytes + c->h_q.bytes + c->h_s.bytes + c->h_i.bytes + c->h_r.bytes;
+                           c->shadow.bytes + c->xscale.bytes + c->h_q.bytes + c->h_s.bytes + c->h_i.bytes + c->h_r.bytes + c->h_v.bytes;
     }
     return copy_out_struct(out, inf);
 }
@@ -1722,10 +1725,9 @@ int mvfgpu_corpus_read_rows(const mvfgpu_corpus* c, uint64_t first, uint64_t cou
     return MVF_OK;
 }
 
-int mvfgpu_corpus_gather_rows(const mvfgpu_corpus* c, const uint64_t* indices, uint64_t count, void* out_rows) {
-    if (!c || (count && (!indices || !out_rows))) return fail(MVF_ERR_INVALID_ARGUMENT, "NULL argument");
-    if (count == 0) return MVF_OK;
-    if (count > 0xFFFFFFFFull) return fail(MVF_ERR_INVALID_ARGUMENT, "too many rows in one gather");
+namespace {
+// mvfgpu_corpus_gather_rows with c->host_mu held by the caller (mvfgpu_search_fetch fetches behind its own search)
+int gather_rows_host_locked(const mvfgpu_corpus* c, const uint64_t* indices, uint64_t count, void* out_rows) {
     std::vector<uint64_t> mapped;  // with vector ids a search reports ids: translate them back to positions
     if (!c->h_ids.empty()) {
         std::lock_guard<std::mutex> lk(c->mu);
@@ -1764,7 +1766,6 @@ int mvfgpu_corpus_gather_rows(const mvfgpu_corpus* c, const uint64_t* indices, u
     const size_t ibytes = (size_t)count * 8, obytes = (size_t)count * row_bytes;
     const bool zc_i = ibytes <= c->tune.host_zc_query, zc_o = obytes <= c->tune.host_zc_results;
     void *di, *dout;
-    std::lock_guard<std::mutex> host_lk(c->host_mu);
     {
         std::lock_guard<std::mutex> lk(c->mu);
         if (c->has_done) HIP_TRY(hipEventSynchronize(c->ev_done));
@@ -1791,6 +1792,15 @@ int mvfgpu_corpus_gather_rows(const mvfgpu_corpus* c, const uint64_t* indices, u
     HIP_TRY(hipStreamSynchronize(c->own_stream));
     if (zc_o) memcpy(out_rows, dout, obytes);
     return MVF_OK;
+}
+}  // namespace
+
+int mvfgpu_corpus_gather_rows(const mvfgpu_corpus* c, const uint64_t* indices, uint64_t count, void* out_rows) {
+    if (!c || (count && (!indices || !out_rows))) return fail(MVF_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (count == 0) return MVF_OK;
+    if (count > 0xFFFFFFFFull) return fail(MVF_ERR_INVALID_ARGUMENT, "too many rows in one gather");
+    std::lock_guard<std::mutex> host_lk(c->host_mu);
+    return gather_rows_host_locked(c, indices, count, out_rows);
 }
 
 int mvfgpu_corpus_set_tombstones(mvfgpu_corpus* c, const uint8_t* bitmap, uint64_t first_bit, uint64_t nbits) {
@@ -1918,27 +1928,38 @@ int mvfgpu_search_device(const mvfgpu_corpus* c, uint8_t metric, const void* d_q
     return MVF_OK;  // ev_done: DoneGuard
 }
 
-int mvfgpu_search(const mvfgpu_corpus* c, uint8_t metric, const void* queries, uint8_t query_dtype,
-                  uint32_t query_dim, uint32_t nq, uint32_t k, float* out_scores, uint64_t* out_indices,
-                  int32_t* out_raw) {
+namespace {
+// mvfgpu_search / mvfgpu_search_fetch.  out_vectors (nullable): [nq][k] rows of the corpus in their stored type.
+int search_host(const mvfgpu_corpus* c, uint8_t metric, const void* queries, uint8_t query_dtype, uint32_t query_dim, uint32_t nq,
+                uint32_t k, float* out_scores, uint64_t* out_indices, int32_t* out_raw, void* out_vectors) {
     int rc = check_query_args(c, metric, queries, query_dtype, query_dim, nq, k, out_scores, out_indices);
     if (rc != MVF_OK) return rc;
     DeviceGuard guard(c->device);
     if (!guard.ok) return fail(MVF_ERR_DEVICE, "hipSetDevice failed");
     const size_t qbytes = (size_t)nq * c->dim * (is_int_dtype(c->dtype) ? 1 : 4);
     const size_t nres = (size_t)nq * k;
+    if (out_vectors && nres > 0xFFFFFFFFull) return fail(MVF_ERR_INVALID_ARGUMENT, "too many rows in one fetch");
     // Small queries / results skip the copy engine: the query is copied (by the CPU) into pinned host memory the kernels
     // read in place, and the selection kernels write the results into pinned host memory -- 10k x 128 f32, top-10:
     // 65 -> 30 us per call (profiles/r04_host_api_latency.txt); three staged hipMemcpyAsync of pageable memory cost more
     // than the search.  Larger transfers keep the device mirrors (a kernel reading megabytes over PCIe stalls its blocks).
     const size_t out_bytes = nres * 16;
     const bool zc_q = qbytes <= c->tune.host_zc_query, zc_out = out_bytes <= c->tune.host_zc_results;
-    void *dq, *ds, *di, *dr;
+    // The payload rows are gathered on the device BEHIND the search, on its stream, from the result indices where the
+    // selection kernel left them: one submission and one wait for "the k best and their vectors" (the reference's
+    // ScoredVector carries the vector, examples/similarity_search.rs:18).  A corpus that reports vector ids translates
+    // them back on the host (mvfgpu_corpus_gather_rows' table), after the search: two steps, as before.
+    const uint32_t row_bytes = c->dim * elem_size(c->dtype);
+    const size_t vec_bytes = nres * row_bytes;
+    const bool zc_vec = vec_bytes <= c->tune.host_zc_results;
+    void *dq, *ds, *di, *dr, *dv = nullptr;
     std::lock_guard<std::mutex> host_lk(c->host_mu);
+    bool fused_fetch = false;
     {
         std::lock_guard<std::mutex> lk(c->mu);
         // wait for any in-flight user of the mirrors before (re)allocating them
         if (c->has_done) HIP_TRY(hipEventSynchronize(c->ev_done));
+        fused_fetch = out_vectors && c->h_ids.empty();
         if (zc_q) {
             HIP_TRY(c->pin_q.reserve(qbytes));
             memcpy(c->pin_q.p, queries, qbytes);
@@ -1961,22 +1982,51 @@ int mvfgpu_search(const mvfgpu_corpus* c, uint8_t metric, const void* queries, u
             di = c->h_i.p;
             dr = c->h_r.p;
         }
+        if (fused_fetch) {
+            if (zc_vec) {
+                HIP_TRY(c->pin_vec.reserve(vec_bytes));
+                dv = c->pin_vec.p;
+            } else {
+                HIP_TRY(c->h_v.reserve(vec_bytes));
+                dv = c->h_v.p;
+            }
+        }
     }
     rc = mvfgpu_search_device(c, metric, dq, query_dtype, query_dim, nq, k, static_cast<float*>(ds),
                               static_cast<uint64_t*>(di), static_cast<int32_t*>(dr), c->own_stream);
     if (rc != MVF_OK) return rc;
+    if (fused_fetch)  // padding entries (index UINT64_MAX) give zero rows
+        HIP_TRY(launch_gather_rows(c->d_rows, c->n, c->pitch, row_bytes, c->index_base, static_cast<const uint64_t*>(di), (uint32_t)nres,
+                                   static_cast<unsigned char*>(dv), c->own_stream));
+    if (!zc_out) {
+        HIP_TRY(hipMemcpyAsync(out_scores, ds, nres * 4, hipMemcpyDeviceToHost, c->own_stream));
+        HIP_TRY(hipMemcpyAsync(out_indices, di, nres * 8, hipMemcpyDeviceToHost, c->own_stream));
+        if (out_raw) HIP_TRY(hipMemcpyAsync(out_raw, dr, nres * 4, hipMemcpyDeviceToHost, c->own_stream));
+    }
+    if (fused_fetch && !zc_vec) HIP_TRY(hipMemcpyAsync(out_vectors, dv, vec_bytes, hipMemcpyDeviceToHost, c->own_stream));
+    HIP_TRY(hipStreamSynchronize(c->own_stream));
     if (zc_out) {
-        HIP_TRY(hipStreamSynchronize(c->own_stream));
         memcpy(out_scores, ds, nres * 4);
         memcpy(out_indices, di, nres * 8);
         if (out_raw) memcpy(out_raw, dr, nres * 4);
-        return MVF_OK;
     }
-    HIP_TRY(hipMemcpyAsync(out_scores, ds, nres * 4, hipMemcpyDeviceToHost, c->own_stream));
-    HIP_TRY(hipMemcpyAsync(out_indices, di, nres * 8, hipMemcpyDeviceToHost, c->own_stream));
-    if (out_raw) HIP_TRY(hipMemcpyAsync(out_raw, dr, nres * 4, hipMemcpyDeviceToHost, c->own_stream));
-    HIP_TRY(hipStreamSynchronize(c->own_stream));
+    if (fused_fetch && zc_vec) memcpy(out_vectors, dv, vec_bytes);
+    if (out_vectors && !fused_fetch) return gather_rows_host_locked(c, out_indices, nres, out_vectors);
     return MVF_OK;
+}
+}  // namespace
+
+int mvfgpu_search(const mvfgpu_corpus* c, uint8_t metric, const void* queries, uint8_t query_dtype,
+                  uint32_t query_dim, uint32_t nq, uint32_t k, float* out_scores, uint64_t* out_indices,
+                  int32_t* out_raw) {
+    return search_host(c, metric, queries, query_dtype, query_dim, nq, k, out_scores, out_indices, out_raw, nullptr);
+}
+
+int mvfgpu_search_fetch(const mvfgpu_corpus* c, uint8_t metric, const void* queries, uint8_t query_dtype,
+                        uint32_t query_dim, uint32_t nq, uint32_t k, float* out_scores, uint64_t* out_indices,
+                        int32_t* out_raw, void* out_vectors) {
+    if (!out_vectors) return fail(MVF_ERR_INVALID_ARGUMENT, "NULL buffer");
+    return search_host(c, metric, queries, query_dtype, query_dim, nq, k, out_scores, out_indices, out_raw, out_vectors);
 }
 
 int mvfgpu_merge_topk_host(const float* scores, const uint64_t* indices, const int32_t* raw, uint32_t nlists,

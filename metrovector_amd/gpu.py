@@ -48,6 +48,7 @@ class GpuCorpus:
 
     def __init__(self, handle: int):
         self._h = C.c_void_p(handle)
+        self._shape = None  # (rows, dimension, data_type): fixed for the life of the handle, asked for once
 
     # ---- construction ------------------------------------------------------
     @classmethod
@@ -126,30 +127,36 @@ class GpuCorpus:
         _lib.gpu_check(_lib.gpu().mvfgpu_corpus_get_info(self._h, C.byref(out)))
         return out
 
+    def _fixed(self) -> tuple[int, int, int]:
+        if self._shape is None:
+            inf = self.info()
+            self._shape = (inf.rows, inf.dimension, inf.data_type)
+        return self._shape
+
     @property
     def rows(self) -> int:
-        return self.info().rows
+        return self._fixed()[0]
 
     @property
     def dimension(self) -> int:
-        return self.info().dimension
+        return self._fixed()[1]
 
     @property
     def data_type(self) -> int:
-        return self.info().data_type
+        return self._fixed()[2]
 
     def read_rows(self, first: int, count: int) -> np.ndarray:
-        inf = self.info()
-        out = np.empty((count, inf.dimension), _NP_OF[inf.data_type])
+        _, dim, dt = self._fixed()
+        out = np.empty((count, dim), _NP_OF[dt])
         _lib.gpu_check(_lib.gpu().mvfgpu_corpus_read_rows(self._h, first, count, out.ctypes.data_as(C.c_void_p)))
         return out
 
     def gather_rows(self, indices) -> np.ndarray:
         """Rows by GLOBAL index, in the order given (`mvfgpu_corpus_gather_rows`): the payload of the
         reference's ScoredVector.vector, served from HBM."""
-        inf = self.info()
+        _, dim, dt = self._fixed()
         idx = np.ascontiguousarray(np.asarray(indices).reshape(-1), np.uint64)
-        out = np.empty((idx.size, inf.dimension), _NP_OF[inf.data_type])
+        out = np.empty((idx.size, dim), _NP_OF[dt])
         _lib.gpu_check(_lib.gpu().mvfgpu_corpus_gather_rows(self._h, idx.ctypes.data_as(C.c_void_p), idx.size,
                                                             out.ctypes.data_as(C.c_void_p)))
         return out
@@ -157,7 +164,6 @@ class GpuCorpus:
     # ---- search ----------------------------------------------------------------
     def search(self, queries: np.ndarray, k: int, metric: int = L2) -> SearchResult:
         """Host-buffer search (`mvfgpu_search`)."""
-        inf = self.info()
         q = np.asarray(queries)
         if q.ndim == 1:
             q = q[None, :]
@@ -173,6 +179,27 @@ class GpuCorpus:
                                                 sc.ctypes.data_as(C.c_void_p), idx.ctypes.data_as(C.c_void_p),
                                                 raw.ctypes.data_as(C.c_void_p)))
         return SearchResult(sc, idx, raw)
+
+    def search_fetch(self, queries: np.ndarray, k: int, metric: int = L2) -> tuple[SearchResult, np.ndarray]:
+        """Search + payload in one call (`mvfgpu_search_fetch`): the results and the rows they name, [nq, k, dimension] in
+        the stored type (zero rows behind a short result list)."""
+        q = np.asarray(queries)
+        if q.ndim == 1:
+            q = q[None, :]
+        qcode = _CODE_OF.get(q.dtype)
+        if qcode is None:
+            raise BuildError(f"unsupported query dtype {q.dtype}")
+        q = np.ascontiguousarray(q)
+        nq, qdim = q.shape
+        _, dim, dt = self._fixed()
+        sc = np.empty((nq, k), np.float32)
+        idx = np.empty((nq, k), np.uint64)
+        raw = np.empty((nq, k), np.int32)
+        vec = np.empty((nq, k, dim), _NP_OF[dt])
+        _lib.gpu_check(_lib.gpu().mvfgpu_search_fetch(self._h, metric, q.ctypes.data_as(C.c_void_p), qcode, qdim, nq, k,
+                                                      sc.ctypes.data_as(C.c_void_p), idx.ctypes.data_as(C.c_void_p),
+                                                      raw.ctypes.data_as(C.c_void_p), vec.ctypes.data_as(C.c_void_p)))
+        return SearchResult(sc, idx, raw), vec
 
     def search_device(self, d_queries: int, query_dtype: int, query_dim: int, nq: int, k: int, metric: int,
                       d_scores: int, d_indices: int, d_raw: int = 0, stream: int = 0) -> None:

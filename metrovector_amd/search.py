@@ -93,9 +93,9 @@ def find_top_k_similar(space: VectorSpace, query, k: int, metric: int | None = N
         corpus = upload_space(space, device)
     try:
         qd = _NP_OF[query_dtype_code(int(space.data_type()))]
-        res = corpus.search(np.asarray(query, dtype=qd), k, metric)
+        res, vec = corpus.search_fetch(np.asarray(query, dtype=qd), k, metric)  # the k best + their payload straight from HBM
         valid = res.indices[0] != np.uint64(0xFFFFFFFFFFFFFFFF)  # fewer than k rows: the reference returns fewer items
-        rows = corpus.gather_rows(res.indices[0][valid])            # payload straight from HBM
+        rows = vec[0][valid]
     finally:
         if own:
             corpus.close()
@@ -125,9 +125,12 @@ def find_top_k_similar_batch(space: VectorSpace, queries, k: int, metric: int | 
     if own:
         corpus = upload_space(space, device)
     try:
-        res = corpus.search(q, k, metric)
+        if with_vectors:
+            res, vec = corpus.search_fetch(q, k, metric)
+        else:
+            res, vec = corpus.search(q, k, metric), None
         valid = res.indices != np.uint64(0xFFFFFFFFFFFFFFFF)
-        rows = corpus.gather_rows(res.indices[valid]) if with_vectors else None
+        rows = vec[valid] if with_vectors else None
     finally:
         if own:
             corpus.close()

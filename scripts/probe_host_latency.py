@@ -3,6 +3,7 @@ median wall time of one blocking mvfgpu_search call with pageable host buffers:
   copies   -- MVF_HOST_ZC_QUERY=0 MVF_HOST_ZC_RESULTS=0: staged hipMemcpyAsync H2D of the query, D2H of the three result arrays
   zc-out   -- results written in place into pinned host memory, the query still copied
   zc       -- the default: the query read in place too
+  with rows -- the k best AND their payload rows: mvfgpu_search_fetch (one call) against mvfgpu_search + mvfgpu_corpus_gather_rows
   device   -- mvfgpu_search_device on device buffers + a stream synchronise (no transfer at all), and `enqueue`, the CPU time
               of that call alone."""
 import ctypes as C, os, sys, time
@@ -67,6 +68,17 @@ for (n, dim, dt, metric, k) in ((60, 4, 0, 0, 5), (10_000, 128, 0, 0, 10), (10_0
             same = np.array_equal(sc, ref[0]) and np.array_equal(ix, ref[1])
             res.append(f"{name} {t:7.1f}{'' if same else ' DIFF'}")
         b = med(B)
+        vec = np.empty((nq, k, dim), hq.dtype)
+
+        def F():  # the k best and their rows: one call ...
+            _lib.gpu_check(lib.mvfgpu_search_fetch(c._h, metric, hq.ctypes.data_as(C.c_void_p), dt, dim, nq, k, sc.ctypes.data_as(C.c_void_p),
+                                                   ix.ctypes.data_as(C.c_void_p), None, vec.ctypes.data_as(C.c_void_p)))
+
+        def S():  # ... or two
+            A()
+            _lib.gpu_check(lib.mvfgpu_corpus_gather_rows(c._h, ix.ctypes.data_as(C.c_void_p), nq * k, vec.ctypes.data_as(C.c_void_p)))
+
+        fetch = (med(F), med(S))
         ts = []
         for _ in range(200):
             t0 = time.perf_counter()
@@ -75,5 +87,5 @@ for (n, dim, dt, metric, k) in ((60, 4, 0, 0, 5), (10_000, 128, 0, 0, 10), (10_0
             ts.append(time.perf_counter() - t0)
             torch.cuda.synchronize()
         ts.sort()
-        print(f"n={n:>9} dim={dim:>4} dt={dt} k={k:>3} nq={nq:>3}:  " + "   ".join(res) + f"   device {b:7.1f}   enqueue {ts[100] * 1e6:5.1f}", flush=True)
+        print(f"n={n:>9} dim={dim:>4} dt={dt} k={k:>3} nq={nq:>3}:  " + "   ".join(res) + f"   device {b:7.1f}   enqueue {ts[100] * 1e6:5.1f}   with rows: fetch {fetch[0]:7.1f}  search+gather {fetch[1]:7.1f}", flush=True)
     c.close()

@@ -354,3 +354,42 @@ def test_payload_fetch_in_place_and_by_copy(oracle, monkeypatch):
                     assert got.dtype == rows.dtype and (got.view(np.uint8) == rows[idx.astype(np.int64)].view(np.uint8)).all(), (dtype, dim, count, zq)
         monkeypatch.delenv("MVF_HOST_ZC_QUERY", raising=False)
         monkeypatch.delenv("MVF_HOST_ZC_RESULTS", raising=False)
+
+
+@pytest.mark.parametrize("dtype", [0, 1, 2, 3])
+def test_search_fetch_returns_the_rows_the_results_name(oracle, dtype, monkeypatch):
+    """mvfgpu_search_fetch = mvfgpu_search + the payload rows (ScoredVector.vector), gathered on the device behind the
+    search: same results as mvfgpu_search bit for bit, rows = the stored rows at the reported indices, zero rows behind a
+    short list; single queries, the four-query pass, a batch on the MFMA path, k beyond one pass; with an index base,
+    deletions and (the host-mapped fallback) vector ids; payloads on both sides of the in-place limit."""
+    rng = np.random.default_rng(40 + dtype)
+    n, dim = 60_000, 72
+    rows = oracle.synth_rows(SEED, 0, n, dim, dtype)
+    dead = rng.random(n) < 0.05
+    ids = rng.permutation(n).astype(np.uint64) + np.uint64(5 * 10**9)
+    pad = np.uint64(0xFFFFFFFFFFFFFFFF)
+    for use_ids in (False, True):
+        with G.GpuCorpus.from_array(rows, index_base=2_000_000) as c:
+            c.set_tombstones(np.packbits(dead, bitorder="little"))
+            if use_ids:
+                c.set_vector_ids(ids)
+            for nq, k in ((1, 10), (3, 100), (40, 50), (1, 3000), (2, 1024)):
+                q = oracle.synth_queries(SEED + 1, nq, dim, dtype)
+                for limit in (None, "0", "4096"):
+                    monkeypatch.delenv("MVF_HOST_ZC_RESULTS", raising=False) if limit is None else monkeypatch.setenv("MVF_HOST_ZC_RESULTS", limit)
+                    c.reload_tuning()
+                    ref = c.search(q, k, G.COSINE)
+                    got, vec = c.search_fetch(q, k, G.COSINE)
+                    assert (got.indices == ref.indices).all() and (got.raw == ref.raw).all()
+                    assert (got.scores.view(np.uint32) == ref.scores.view(np.uint32)).all()
+                    assert vec.shape == (nq, k, dim) and vec.dtype == rows.dtype
+                    pos = (np.argsort(ids)[np.searchsorted(np.sort(ids), got.indices)] if use_ids
+                           else (got.indices - np.uint64(2_000_000)).astype(np.int64))
+                    assert not dead[pos].any()
+                    assert (vec.view(np.uint8) == rows[pos].view(np.uint8)).all(), (dtype, use_ids, nq, k, limit)
+            monkeypatch.delenv("MVF_HOST_ZC_RESULTS", raising=False)
+    with G.GpuCorpus.from_array(rows[:7]) as c:                    # fewer rows than k: zero rows behind the list
+        q = oracle.synth_queries(SEED + 1, 2, dim, dtype)
+        got, vec = c.search_fetch(q, 12, G.L2)
+        assert (got.indices[:, 7:] == pad).all() and not vec[:, 7:].view(np.uint8).any()
+        assert (vec[:, :7].view(np.uint8) == rows[got.indices[:, :7].astype(np.int64)].view(np.uint8)).all()
