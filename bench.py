@@ -585,6 +585,13 @@ def cfg1_block(args, torch, G, oracle, local_rank):
             res = c.search(q, k, G.L2)
             host.append(time.perf_counter() - t0)
         host.sort()
+        fetch = []
+        for _ in range(210):  # the hits WITH their rows, as the reference's ScoredVector carries them
+            t0 = time.perf_counter()
+            res_v, vec = c.search_fetch(q, k, G.L2)
+            fetch.append(time.perf_counter() - t0)
+        fetch = sorted(fetch[10:])
+        rows_ok = bool((vec[0] == rows[res_v.indices[0].astype(np.int64)]).all() and (res_v.indices == res.indices).all())
         dq = torch.from_numpy(q).to(f"cuda:{local_rank}")
         ds = torch.empty((1, k), dtype=torch.float32, device=dq.device)
         di = torch.empty((1, k), dtype=torch.int64, device=dq.device)
@@ -604,7 +611,11 @@ def cfg1_block(args, torch, G, oracle, local_rank):
                                    "what": "oracle faithful restatement of find_top_k_similar, single thread, all 10k rows per run"},
             "gpu_host_api": {"ms_per_search_median": host_ms, "ms_per_search_min": host[0] * 1e3, "runs": len(host),
                              "value": n / (host_ms * 1e-3), "unit": "distance-ops/s",
-                             "what": "mvfgpu_search: query H2D + scan + top-k + results D2H, blocking (latency-bound at this size)"},
+                             "what": "mvfgpu_search: query in, scan + top-k, results out, blocking (latency-bound at this size; small transfers go through pinned host memory in place, profiles/r04_host_api_latency.txt)"},
+            "gpu_host_api_with_vectors": {"ms_per_search_median": fetch[len(fetch) // 2] * 1e3, "ms_per_search_min": fetch[0] * 1e3, "runs": len(fetch),
+                                          "value": n / fetch[len(fetch) // 2], "unit": "distance-ops/s", "rows_match_the_corpus": rows_ok,
+                                          "what": "mvfgpu_search_fetch: the same search returning the k rows as well (ScoredVector.vector, "
+                                                  "examples/similarity_search.rs:18) -- what the CPU figure beside it includes"},
             "gpu_device_ms": {"search_ms_avg": tm.search_ms_avg, "scan_kernel_ms_avg": tm.scan_ms_avg, "select_ms_avg": tm.select_ms_avg},
             "gpu_matches_cpu": {"indices_identical": same, "max_rel_score_diff": rel, "tolerance": 1e-5}}
 
@@ -841,7 +852,8 @@ def main():
             "ms_per_step": elapsed / args.steps * 1e3,
             "value_timed_region": "query already on the device -> kernels + on-device top-k (+ all-gather and merge at N > 1) -> "
                                   "results left on the device; the query's H2D copy and the results' D2H copy of SURVEY.md "
-                                  "§8(d)'s region are NOT in `value` -- `host_api` is the same search including both (+0.5 %)",
+                                  "§8(d)'s region are NOT in `value` -- `host_api` is the same search including both (its ms_per_step is in the "
+                                  "line: within 0.5 % either way since the host call moves small queries / results through pinned memory in place)",
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
