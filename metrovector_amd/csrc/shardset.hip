@@ -124,6 +124,21 @@ struct mvfgpu_shardset {
     std::mutex mu;                       // one search at a time per set (the gather buffers are per set)
     std::vector<DevBuf> d_q, d_gather;   // per shard: queries; [n_shards] packed lists (its own list at slot s)
     DevBuf d_out;                        // shard 0's device: the merged list, packed like the shards' (u64 | f32 | i32)
+    // Small queries / results skip the copy engine, as in mvfgpu_search (api.hip): every shard's kernels read the queries
+    // from ONE pinned host buffer (portable: mapped for every device) and the merge writes into pinned host memory.
+    void* pin_q = nullptr;
+    void* pin_out = nullptr;
+    size_t pin_q_bytes = 0, pin_out_bytes = 0, zc_query = 0, zc_results = 0;
+    hipError_t reserve_pinned(void** p, size_t* have, size_t need) {
+        if (need <= *have) return hipSuccess;
+        if (*p) (void)hipHostFree(*p);
+        *p = nullptr;
+        *have = 0;
+        need = (need + 4095) & ~(size_t)4095;
+        hipError_t e = hipHostMalloc(p, need, hipHostMallocPortable);
+        if (e == hipSuccess) *have = need;
+        return e;
+    }
     mvfgpu_shardset_timing tm{};
 
     // One PERSISTENT host thread per shard beyond the first (the calling thread drives shard 0): a batched search is
@@ -133,6 +148,7 @@ struct mvfgpu_shardset {
         uint8_t metric = 0, query_dtype = 0;
         uint32_t query_dim = 0, nq = 0, k = 0;
         const void* queries = nullptr;
+        const void* queries_in_place = nullptr;  // pinned host copy every shard reads directly (small batches), or NULL
         size_t qbytes = 0, list_bytes = 0, nres = 0;
     } job;
     std::vector<std::thread> workers;
@@ -159,13 +175,17 @@ void mvfgpu_shardset::run_shard(int s) {
     }
     unsigned char* slot = static_cast<unsigned char*>(d_gather[s].p) + job.list_bytes * s;
     hipError_t e = hipEventRecord(ev_t0[s], st[s]);
-    if (e == hipSuccess) e = hipMemcpyAsync(d_q[s].p, job.queries, job.qbytes, hipMemcpyHostToDevice, st[s]);
+    const void* dq = job.queries_in_place;
+    if (!dq) {
+        dq = d_q[s].p;
+        if (e == hipSuccess) e = hipMemcpyAsync(d_q[s].p, job.queries, job.qbytes, hipMemcpyHostToDevice, st[s]);
+    }
     if (e != hipSuccess) {
         rcs[s] = MVF_ERR_DEVICE;
         msgs[s] = std::string("query upload: ") + hipGetErrorString(e);
         return;
     }
-    rcs[s] = mvfgpu_search_device(shards[s], job.metric, d_q[s].p, job.query_dtype, job.query_dim, job.nq, job.k,
+    rcs[s] = mvfgpu_search_device(shards[s], job.metric, dq, job.query_dtype, job.query_dim, job.nq, job.k,
                                   reinterpret_cast<float*>(slot + 8 * job.nres), reinterpret_cast<uint64_t*>(slot),
                                   reinterpret_cast<int32_t*>(slot + 12 * job.nres), st[s]);
     if (rcs[s] != MVF_OK) {
@@ -236,6 +256,11 @@ int mvfgpu_shardset_create(mvfgpu_corpus* const* shards, int n_shards, mvfgpu_sh
     ss->rcs.assign(n_shards, MVF_OK);
     ss->msgs.assign(n_shards, std::string());
     ss->d_q.resize(n_shards);
+    {
+        const mvf::Tuning t = mvf::read_tuning();  // MVF_HOST_ZC_QUERY / MVF_HOST_ZC_RESULTS, as a corpus handle reads them
+        ss->zc_query = t.host_zc_query;
+        ss->zc_results = t.host_zc_results;
+    }
     ss->d_gather.resize(n_shards);
     int rc = MVF_OK;
     for (int s = 0; s < n_shards && rc == MVF_OK; s++) {
@@ -300,6 +325,8 @@ void mvfgpu_shardset_destroy(mvfgpu_shardset* ss) {
         ss->d_gather[s].release();
     }
     ss->d_out.release();
+    if (ss->pin_q) (void)hipHostFree(ss->pin_q);
+    if (ss->pin_out) (void)hipHostFree(ss->pin_out);
     if (prev >= 0) (void)hipSetDevice(prev);
     delete ss;
 }
@@ -349,11 +376,17 @@ int mvfgpu_shardset_search(mvfgpu_shardset* ss, uint8_t metric, const void* quer
 
     const size_t nres = (size_t)nq * k, list_bytes = MVFGPU_PACKED_LIST_BYTES(nq, k);
     const size_t qbytes = (size_t)nq * query_dim * (int_space ? 1u : 4u);
+    const bool zc_q = qbytes <= ss->zc_query, zc_out = nres * 16 <= ss->zc_results;
     for (int s = 0; s < S; s++) {
-        SS_HIP(ss->d_q[s].reserve(ss->dev[s], qbytes));
+        if (!zc_q) SS_HIP(ss->d_q[s].reserve(ss->dev[s], qbytes));
         SS_HIP(ss->d_gather[s].reserve(ss->dev[s], list_bytes * S));
     }
-    SS_HIP(ss->d_out.reserve(ss->dev[0], list_bytes));
+    if (zc_q) {
+        SS_HIP(ss->reserve_pinned(&ss->pin_q, &ss->pin_q_bytes, qbytes));
+        memcpy(ss->pin_q, queries, qbytes);
+    }
+    if (zc_out) SS_HIP(ss->reserve_pinned(&ss->pin_out, &ss->pin_out_bytes, nres * 16));
+    else SS_HIP(ss->d_out.reserve(ss->dev[0], list_bytes));
 
     // ---- per-shard searches, concurrently: the calling thread drives shard 0, a persistent worker each of the others
     const auto t0 = std::chrono::steady_clock::now();
@@ -363,6 +396,7 @@ int mvfgpu_shardset_search(mvfgpu_shardset* ss, uint8_t metric, const void* quer
     ss->job.nq = nq;
     ss->job.k = k;
     ss->job.queries = queries;
+    ss->job.queries_in_place = zc_q ? ss->pin_q : nullptr;
     ss->job.qbytes = qbytes;
     ss->job.list_bytes = list_bytes;
     ss->job.nres = nres;
@@ -414,7 +448,7 @@ int mvfgpu_shardset_search(mvfgpu_shardset* ss, uint8_t metric, const void* quer
     // ---- merge on shard 0's device into one more packed list ({u64 indices | f32 scores | i32 raw}: the u64 array first,
     // so every array is aligned to its element whatever nq * k is), results to the host
     (void)hipSetDevice(ss->dev[0]);
-    unsigned char* ob = static_cast<unsigned char*>(ss->d_out.p);
+    unsigned char* ob = static_cast<unsigned char*>(zc_out ? ss->pin_out : ss->d_out.p);
     uint64_t* mi = reinterpret_cast<uint64_t*>(ob);
     float* ms = reinterpret_cast<float*>(ob + 8 * nres);
     int32_t* mr = reinterpret_cast<int32_t*>(ob + 12 * nres);
@@ -422,12 +456,19 @@ int mvfgpu_shardset_search(mvfgpu_shardset* ss, uint8_t metric, const void* quer
     if (rc != MVF_OK) return rc;
     SS_HIP(hipEventRecord(ss->ev_merged, ss->st[0]));
     const auto t1 = std::chrono::steady_clock::now();  // everything is enqueued (a copy to pageable host memory blocks)
-    SS_HIP(hipMemcpyAsync(out_scores, ms, nres * 4, hipMemcpyDeviceToHost, ss->st[0]));
-    SS_HIP(hipMemcpyAsync(out_indices, mi, nres * 8, hipMemcpyDeviceToHost, ss->st[0]));
-    if (out_raw) SS_HIP(hipMemcpyAsync(out_raw, mr, nres * 4, hipMemcpyDeviceToHost, ss->st[0]));
+    if (!zc_out) {
+        SS_HIP(hipMemcpyAsync(out_scores, ms, nres * 4, hipMemcpyDeviceToHost, ss->st[0]));
+        SS_HIP(hipMemcpyAsync(out_indices, mi, nres * 8, hipMemcpyDeviceToHost, ss->st[0]));
+        if (out_raw) SS_HIP(hipMemcpyAsync(out_raw, mr, nres * 4, hipMemcpyDeviceToHost, ss->st[0]));
+    }
     for (int s = 0; s < S; s++) {  // every rank's part of the collective has to finish before the buffers are reused
         (void)hipSetDevice(ss->dev[s]);
         SS_HIP(hipStreamSynchronize(ss->st[s]));
+    }
+    if (zc_out) {
+        memcpy(out_scores, ms, nres * 4);
+        memcpy(out_indices, mi, nres * 8);
+        if (out_raw) memcpy(out_raw, mr, nres * 4);
     }
     const auto t2 = std::chrono::steady_clock::now();
     mvfgpu_shardset_timing& tm = ss->tm;

@@ -393,3 +393,37 @@ def test_search_fetch_returns_the_rows_the_results_name(oracle, dtype, monkeypat
         got, vec = c.search_fetch(q, 12, G.L2)
         assert (got.indices[:, 7:] == pad).all() and not vec[:, 7:].view(np.uint8).any()
         assert (vec[:, :7].view(np.uint8) == rows[got.indices[:, :7].astype(np.int64)].view(np.uint8)).all()
+
+
+def test_shard_set_in_place_buffers_agree_with_the_copy_path(oracle, monkeypatch):
+    """mvfgpu_shardset_search: every shard reads small batches from ONE pinned host buffer and the merge writes the results
+    into pinned host memory; same answers as with the staged copies (a set reads MVF_HOST_ZC_* when it is created), and as
+    one handle over all the rows."""
+    n, dim = 90_000, 64
+    for dtype, metric in ((0, G.L2), (2, G.INNER_PRODUCT)):
+        rows = oracle.synth_rows(SEED, 0, n, dim, dtype)
+        cuts = [0, 20_000, 20_000, 55_001, n]                    # an empty shard among them
+        shards = [G.GpuCorpus.from_array(rows[a:b], index_base=a) for a, b in zip(cuts[:-1], cuts[1:])]
+        try:
+            with G.GpuCorpus.from_array(rows) as whole:
+                for nq, k in ((1, 10), (5, 100), (300, 20)):
+                    q = oracle.synth_queries(SEED + 1, nq, dim, dtype)
+                    ref = whole.search(q, k, metric)
+                    res = []
+                    for limit in (None, "0"):
+                        for var in ("MVF_HOST_ZC_QUERY", "MVF_HOST_ZC_RESULTS"):
+                            monkeypatch.delenv(var, raising=False) if limit is None else monkeypatch.setenv(var, limit)
+                        with G.ShardSet(shards) as ss:
+                            res.append(ss.search(q, k, metric))
+                            res.append(ss.search(q, k, metric))    # and again on the warm buffers
+                    for r in res:
+                        assert (r.indices == res[0].indices).all() and (r.scores.view(np.uint32) == res[0].scores.view(np.uint32)).all()
+                    if dtype == 2:
+                        assert (res[0].indices == ref.indices).all() and (res[0].raw == ref.raw).all()
+                    else:
+                        assert (res[0].indices == ref.indices).mean() > 0.99
+        finally:
+            for var in ("MVF_HOST_ZC_QUERY", "MVF_HOST_ZC_RESULTS"):
+                monkeypatch.delenv(var, raising=False)
+            for s in shards:
+                s.close()
