@@ -157,3 +157,20 @@ def test_repair_feedback_blames_the_prefilter_first_and_drops_its_stale_sample()
     # fewer than four repairs never trigger, whatever the ratio (single streamed queries)
     assert _feedback([[1, 1, 0, 1]] * 3) == dict(seen=3, redone=3, bias_off=False, qs_off=False)
     assert _feedback([[1, 1, 0, 1]] * 4)["qs_off"]
+
+
+def test_search_entry_points_refuse_null_arguments_before_touching_a_device():
+    """mvfgpu_search / mvfgpu_search_fetch / mvfgpu_corpus_gather_rows: a NULL handle or buffer is MVF_ERR_INVALID_ARGUMENT
+    (code 12) with a message, on a box without a GPU too (checked before any HIP call)."""
+    import ctypes as C
+    lib = _lib.gpu()
+    buf = (C.c_float * 16)()
+    idx = (C.c_uint64 * 4)()
+    rc = lib.mvfgpu_search_fetch(None, 0, buf, 0, 4, 1, 4, buf, idx, None, buf)
+    assert rc != 0 and b"NULL" in lib.mvfgpu_last_error_message()
+    rc2 = lib.mvfgpu_search(None, 0, buf, 0, 4, 1, 4, buf, idx, None)
+    assert rc2 == rc
+    assert lib.mvfgpu_search_fetch(None, 0, buf, 0, 4, 1, 4, buf, idx, None, None) == rc      # no payload buffer
+    assert lib.mvfgpu_corpus_gather_rows(None, idx, 4, buf) == rc
+    with pytest.raises(E.InvalidArgument):
+        _lib.gpu_check(rc)
