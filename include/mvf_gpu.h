@@ -52,11 +52,16 @@ extern "C" {
 
 typedef struct mvfgpu_corpus mvfgpu_corpus;
 
-#define MVFGPU_MAX_K 16384u       /* largest k a search accepts (the reference takes any usize, similarity_search.rs:143) */
-#define MVFGPU_K_PER_PASS 1024u   /* results one pass over the rows selects: k beyond it costs ceil(k / 1024) passes of the
-                                     streaming kernel per 1..4 queries, each returning the rows ranked strictly behind the
-                                     last one of the pass before (exact, whatever the batch size; the cross-shard merges keep
-                                     their own limit n_shards * k <= 8192) */
+#define MVFGPU_MAX_K 0x80000000u  /* largest k a search accepts (the reference takes any usize, similarity_search.rs:143);
+                                     entries beyond the shard's live rows are the padding result */
+#define MVFGPU_K_PER_PASS 1024u   /* results one pass over the rows selects.  Beyond it a search either runs ceil(k / 1024)
+                                     passes of the streaming kernel per 1..4 queries, each returning the rows ranked strictly
+                                     behind the last one of the pass before, or -- when that is cheaper, and always beyond
+                                     MVFGPU_K_BY_PASSES -- has the streaming kernel write every row's order key (8 bytes per
+                                     row) and ranks the WHOLE shard with a device-wide sort (16 bytes of scratch per row and
+                                     query of a pass).  Both exact, whatever the batch size, no host wait; the cross-shard
+                                     merges keep their own limit n_shards * k <= 8192 */
+#define MVFGPU_K_BY_PASSES 16384u /* largest k the pass formulation serves (the fallback when the sort's scratch does not fit) */
 #define MVFGPU_MAX_INT_DIM 33025u /* d*255^2 < 2^31 */
 
 /*
@@ -103,7 +108,8 @@ typedef struct mvfgpu_timing {
                              corpus (scan path 4); MFMA batched (K2): 2 = f32 kernel on Float32 rows,
                              3 = f16/int8 kernel on the stored rows, 4 = f16 kernel on the f16 shadow,
                              6 = int8 kernel on the int8 shadow of a Float32 / Float16 corpus (scan path 5);
-                             7 = K1 on the int8 shadow (scan path 6; one query once the shadow exists) */
+                             7 = K1 on the int8 shadow (scan path 6; one query once the shadow exists);
+                             8 = K1 writing every row's order key + the whole-shard sort (k > MVFGPU_K_PER_PASS) */
     uint32_t scan_launches; /* scan launches of one search (timing covers the first) */
     uint64_t scan_bytes; /* algorithmic bytes one scan launch reads */
     uint64_t scan_flops; /* algorithmic flops of one scan launch (2*nq*rows*dim) */
@@ -267,7 +273,8 @@ int mvfgpu_search_fetch(const mvfgpu_corpus* corpus, uint8_t metric,
  * search two calls later consumes that sample before it picks its path, waiting for it if it has not arrived: which path
  * a search takes then depends on the sequence of searches alone, never on how far the host runs ahead.  A caller that
  * pipelines three or more batched searches on one handle has its third enqueue wait for the first search to finish.
- * k > MVFGPU_K_PER_PASS: ceil(k / 1024) passes of the streaming kernel, no host wait (the floor travels on the device).
+ * k > MVFGPU_K_PER_PASS: ceil(k / 1024) passes of the streaming kernel (the floor travels on the device) or one dump pass +
+ * a device-wide sort of the shard's order keys, whichever is cheaper (see MVFGPU_K_PER_PASS); no host wait either way.
  * Small batches run the streaming kernel (below 32 queries on corpora under
  * 1 GiB; on larger ones a single query, below 5 for Int8/UInt8 and below 9 for Float32 without the f16 shadow -- the
  * measured crossovers: the streaming kernel takes up to 4 queries per pass over the rows, the MFMA path uses a
@@ -433,7 +440,7 @@ int mvfgpu_corpus_reload_tuning(mvfgpu_corpus* corpus);
 /*
  * ABI version of the library: bumped whenever a struct layout or a function signature of this header changes in a way
  * an older caller would misread (2: every out-struct starts with struct_size, round 3; 3: corpus_info.selection_state,
- * reload_tuning, k up to MVFGPU_MAX_K = 16384).  A binding compares it with the MVFGPU_ABI_VERSION it was built against
+ * reload_tuning, k beyond 1024; the later lift of the k <= 16384 limit changed no layout and no signature).  A binding compares it with the MVFGPU_ABI_VERSION it was built against
  * at load time.
  */
 #define MVFGPU_ABI_VERSION 3u

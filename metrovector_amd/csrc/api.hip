@@ -130,6 +130,7 @@ Tuning read_tuning() {
     t.k1_rank_merge = (uint32_t)std::min(256l, std::max(0l, num("MVF_K1_RANK_MERGE", 128)));
     t.host_zc_query = (size_t)std::max(0l, num("MVF_HOST_ZC_QUERY", 64l << 10));
     t.host_zc_results = (size_t)std::max(0l, num("MVF_HOST_ZC_RESULTS", 256l << 10));
+    t.large_k = (int)std::min(2l, std::max(0l, num("MVF_LARGE_K", 0)));
     return t;
 }
 }  // namespace mvf
@@ -151,6 +152,7 @@ struct mvfgpu_corpus {
     mutable DevBuf blk;                   // K2 narrow types: per-block candidate regions + their counts (scan_mfma.h)
     mutable DevBuf repair;                // K2 overflow repair: gathered queries + their results
     mutable DevBuf floor1;                // k > MVFGPU_K_PER_PASS: per query, the last composite the pass before returned, + 1
+    mutable DevBuf rank_a, rank_b, rank_tmp;  // k > MVFGPU_K_PER_PASS by the whole-shard sort: the composites of every row (x the queries of a pass), twice, + the sort's scratch
     mutable DevBuf shadow, xscale;        // Float32 corpora: scaled-f16 shadow rows (selection only) + 2^-s_r per row
     DevBuf tomb, ids;                     // deletion bitmap (u32 words over local rows) / vector ids (u64 per local row)
     uint64_t deleted = 0;                 // bits set in the bitmap
@@ -281,6 +283,15 @@ const void* scan_kernel(uint8_t dtype, int metric, int G, int nqv, bool redo = f
 
 // Streaming over the scaled-f16 shadow of a Float32 corpus (scan path 4): K1 reads the shadow rows instead of the stored
 // ones and hands the k best COMPOSITES per query to the margin compaction instead of formatting results.
+// Buffers of the whole-shard sort (search_sorted_k): a / b hold `nqv` x n composites each, tmp the sort's scratch.
+struct RankAll {
+    uint64_t *a, *b;
+    void* tmp;
+    size_t tmp_bytes;
+    int nqv;         // queries per dump pass the buffers hold: 4 or 1
+    uint32_t k_out;  // the caller's k
+};
+
 struct ShadowStream {
     const unsigned char* rows;
     const float* xscale;
@@ -303,8 +314,11 @@ struct ShadowStream {
 int search_stream_path(const mvfgpu_corpus* c, uint8_t metric, const void* d_queries, uint32_t nq, uint32_t k,
                        float* d_scores, uint64_t* d_indices, int32_t* d_raw, hipStream_t s, bool profile = true,
                        const ShadowStream* alt = nullptr, const uint64_t* floor1 = nullptr, uint64_t* out_floor1 = nullptr,
-                       uint32_t out_stride = 0, uint32_t out_offset = 0) {
+                       uint32_t out_stride = 0, uint32_t out_offset = 0, const RankAll* rank = nullptr) {
     // floor1 / out_floor1 / out_stride / out_offset: one pass of a k > MVFGPU_K_PER_PASS search (search_large_k)
+    // rank: the whole-shard sort (search_sorted_k) -- the scan DUMPS every row's composite, the selection kernel is replaced
+    // by a device-wide sort of each query's n composites + the formatting of its first k_out; `k` is then only the (small)
+    // list length the kernel's LDS layout is sized for
     const uint32_t kcap = next_pow2(k);
     const uint32_t ostride = out_stride ? out_stride : k;
     const bool alt8 = alt && alt->i8;
@@ -323,7 +337,7 @@ int search_stream_path(const mvfgpu_corpus* c, uint8_t metric, const void* d_que
     }
 
     for (uint32_t q0 = 0; q0 < nq;) {
-        int nqv = (nq - q0) >= 2 && (!alt || alt8) ? 4 : 1;
+        int nqv = (nq - q0) >= 2 && (!alt || alt8) && !(rank && rank->nqv == 1) ? 4 : 1;
         int G;
         uint32_t J;
         choose_group(kV, nqv, &G, &J, c->tune.k1_g);  // the lane-group width depends on the queries per pass
@@ -345,7 +359,7 @@ int search_stream_path(const mvfgpu_corpus* c, uint8_t metric, const void* d_que
         if (nchunks > 0) {
             const void* kfn = alt8  ? scan_stream_kernel_ptr_dt2x(metric, G, nqv)
                               : alt ? scan_stream_kernel_ptr_dt1x(metric, G, nqv)
-                                    : scan_kernel(c->dtype, metric, G, nqv, /*redo=*/false, floor1 != nullptr);
+                                    : scan_kernel(c->dtype, metric, G, nqv, /*redo=*/false, floor1 != nullptr || rank != nullptr);
             if (lds > 48 * 1024)
                 HIP_TRY(hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             int occ = 0;
@@ -382,7 +396,7 @@ int search_stream_path(const mvfgpu_corpus* c, uint8_t metric, const void* d_que
             // passes in one launch, pass = blockIdx.y: the passes of a small batch were launch pairs in a row, ~40 us each
             // (10k x 128 f32, 16 queries: 165 -> 50 us; profiles/r04_host_api_latency.txt).  Up to 8 passes = every batch the
             // small-corpus rule of use_batched_path leaves to this kernel.
-            if (nqv == 4 && !alt && !floor1 && nblocks == nchunks && 2u * nblocks <= (uint32_t)occ * (uint32_t)c->num_cus) {
+            if (nqv == 4 && !alt && !floor1 && !rank && nblocks == nchunks && 2u * nblocks <= (uint32_t)occ * (uint32_t)c->num_cus) {
                 npass = std::min<uint32_t>(8u, (nq - q0 + 3u) / 4u);
                 nq_here = std::min<uint32_t>(npass * 4u, nq - q0);
             }
@@ -415,6 +429,7 @@ int search_stream_path(const mvfgpu_corpus* c, uint8_t metric, const void* d_que
             sp.nchunks = nchunks;
             sp.rank_merge_max = c->tune.k1_rank_merge;
             sp.floor1 = floor1;
+            sp.dump = rank ? rank->a : nullptr;
             if (ps && first) HIP_TRY(hipEventRecord(ps->e[0], s));
             if (alt8) HIP_TRY(scan_stream_launch_dt2x(sp, metric, G, nqv, dim3(nblocks), lds, s));
             else if (alt) HIP_TRY(scan_stream_launch_dt1x(sp, metric, G, nqv, dim3(nblocks), lds, s));
@@ -428,7 +443,25 @@ int search_stream_path(const mvfgpu_corpus* c, uint8_t metric, const void* d_que
             }
             tm.scan_launches++;
         }
-        {
+        if (rank) {  // every row of these queries is ranked: sort each query's n composites, format the first k_out
+            SelectParams fp{};
+            fp.k = rank->k_out;
+            fp.metric = metric;
+            fp.dtype = c->dtype;
+            fp.index_base = c->index_base;
+            fp.ids = static_cast<const uint64_t*>(c->ids.p);
+            fp.out_scores = d_scores;
+            fp.out_indices = d_indices;
+            fp.out_raw = d_raw;
+            for (uint32_t q = 0; q < nq_here; q++) {
+                uint64_t* sorted = rank->a + (size_t)q * c->n;
+                if (c->n > 0) {
+                    size_t tb = rank->tmp_bytes;
+                    HIP_TRY(sort_composites(rank->tmp, &tb, rank->a + (size_t)q * c->n, rank->b + (size_t)q * c->n, (size_t)c->n, &sorted, s));
+                }
+                HIP_TRY(launch_write_sorted(fp, sorted, (uint32_t)c->n, (size_t)(q0 + q) * rank->k_out, s));
+            }
+        } else {
             SelectParams fp{};
             fp.lists = static_cast<const uint64_t*>(c->cand.p);
             fp.nlists = nblocks;
@@ -1511,13 +1544,70 @@ int search_large_k(const mvfgpu_corpus* c, uint8_t metric, const void* d_queries
     return MVF_OK;
 }
 
+// k beyond what passes are worth -- and any k beyond MVFGPU_K_BY_PASSES: ONE pass of the streaming kernel per 1-4 queries
+// that writes every row's composite (8 bytes per row) instead of selecting, a device-wide sort of each query's composites
+// (sort_topk.hip) and the formatting of the first k.  Exact, no host wait, any k (entries beyond the live rows pad); costs
+// the scan + ~130 bytes of sort traffic per row, i.e. less than a second pass whenever rows are longer than that.
+// Returns MVF_ERR_DEVICE with *no_room set when the buffers (16 bytes per row and query of a pass + scratch) do not fit.
+int search_sorted_k(const mvfgpu_corpus* c, uint8_t metric, const void* d_queries, uint32_t nq, uint32_t k, float* d_scores,
+                    uint64_t* d_indices, int32_t* d_raw, hipStream_t s, bool* no_room) {
+    *no_room = false;
+    size_t tmp_bytes = 0;
+    if (c->n > 0) HIP_TRY(sort_composites(nullptr, &tmp_bytes, nullptr, nullptr, (size_t)c->n, nullptr, s));
+    tmp_bytes = std::max<size_t>(tmp_bytes, 256);
+    RankAll ra{};
+    for (int nqv = nq >= 2 ? 4 : 1;; nqv = 1) {
+        const size_t bytes = std::max<size_t>((size_t)nqv * c->n * 8, 256);
+        const bool ok = c->rank_a.reserve(bytes) == hipSuccess && c->rank_b.reserve(bytes) == hipSuccess &&
+                        c->rank_tmp.reserve(tmp_bytes) == hipSuccess;
+        if (ok) {
+            ra.nqv = nqv;
+            break;
+        }
+        (void)hipGetLastError();
+        c->rank_a.release();
+        c->rank_b.release();
+        c->rank_tmp.release();
+        if (nqv == 1) {
+            *no_room = true;
+            return fail(MVF_ERR_DEVICE, "no device memory for the whole-shard sort of a large-k search (16 bytes per row)");
+        }
+    }
+    ra.a = static_cast<uint64_t*>(c->rank_a.p);
+    ra.b = static_cast<uint64_t*>(c->rank_b.p);
+    ra.tmp = c->rank_tmp.p;
+    ra.tmp_bytes = c->rank_tmp.bytes;
+    ra.k_out = k;
+    // the kernel's own list length: nothing is selected, so the smallest the LDS layout takes
+    return search_stream_path(c, metric, d_queries, nq, 16, d_scores, d_indices, d_raw, s, /*profile=*/true, nullptr, nullptr, nullptr, 0,
+                              0, &ra);
+}
+
+// Passes or the sort?  Measured in one process on every benchmark shape (profiles/r04_any_k.txt): the sort wins from the
+// second pass on nearly everywhere (10M x 768 f32, k = 16384: 72.6 -> 5.5 ms; four queries: 269 -> 8.0) -- a pass reads the
+// rows again and its 1024-entry lists are heavy (doubly so four queries at a time), the sort moves 8-byte keys only.  Passes
+// keep the one case a model of the two costs gives them: two passes of a batch over a small corpus (10k rows, four queries,
+// k = 2048: 0.14 against 0.17 ms).  The model errs towards the sort: where it is wrong that way the sort loses 4-27 % (two passes
+// of ONE query over 50M 16-byte rows: 2.0 against 2.6 ms), the other way round passes lost 2-4x.
+// MVF_LARGE_K forces one of them (A/B, tests).
+bool large_k_by_sort(const mvfgpu_corpus* c, uint32_t nq, uint32_t k) {
+    if (k > MVFGPU_K_BY_PASSES) return true;
+    if (c->tune.large_k) return c->tune.large_k == 2;
+    const double npass = (double)((k + MVFGPU_K_PER_PASS - 1) / MVFGPU_K_PER_PASS), scans = nq >= 2 ? (double)((nq + 3) / 4) : 1.0;
+    const double row_bytes = std::max(128.0, (double)c->dim * elem_size(c->dtype));             // short rows scan no faster than 128-byte ones
+    const double pass_us = std::max(40.0, (double)c->n * row_bytes / 5.0e6);                   // 5 TB/s = 5e6 bytes per us
+    const double sort_us = scans * pass_us + (double)nq * (35.0 + (double)c->n / 100.0e3);  // the sort: 0.1-0.9 ms per 10M rows, by how many key bits vary
+    const double passes_us = npass * scans * pass_us * (nq >= 2 ? 2.0 : 1.0);
+    return sort_us < passes_us;
+}
+
 int check_query_args(const mvfgpu_corpus* c, uint8_t metric, const void* queries, uint8_t query_dtype,
                      uint32_t query_dim, uint32_t nq, uint32_t k, const void* out_scores, const void* out_indices) {
     if (!c) return fail(MVF_ERR_INVALID_ARGUMENT, "corpus is NULL");
     if (metric != MVF_METRIC_L2 && metric != MVF_METRIC_INNER_PRODUCT && metric != MVF_METRIC_COSINE)
         return fail(MVF_ERR_INVALID_ARGUMENT, "unsupported distance metric code " + std::to_string(metric));
     if (nq == 0) return fail(MVF_ERR_INVALID_ARGUMENT, "nq must be > 0");
-    if (k == 0 || k > MVFGPU_MAX_K) return fail(MVF_ERR_INVALID_ARGUMENT, "k must be in 1..16384");
+    if (k == 0 || k > MVFGPU_MAX_K) return fail(MVF_ERR_INVALID_ARGUMENT, "k must be in 1..2^31");
     if (!queries || !out_scores || !out_indices) return fail(MVF_ERR_INVALID_ARGUMENT, "NULL buffer");
     const uint8_t want = is_int_dtype(c->dtype) ? c->dtype : (uint8_t)MVF_DTYPE_FLOAT32;
     if (query_dtype != want)
@@ -1661,6 +1751,9 @@ void mvfgpu_corpus_destroy(mvfgpu_corpus* c) {
         c->xnorm.release();
         c->repair.release();
         c->floor1.release();
+        c->rank_a.release();
+        c->rank_b.release();
+        c->rank_tmp.release();
         c->shadow.release();
         c->xscale.release();
         c->tomb.release();
@@ -1705,7 +1798,7 @@ int mvfgpu_corpus_get_info(const mvfgpu_corpus* c, mvfgpu_corpus_info* out) {
         inf.shadows = (uint8_t)((c->shadow8_state == 1 ? 1 : 0) | (c->shadow_state == 1 ? 2 : 0));
         inf.selection_state = (uint8_t)((c->qs_disabled ? 1 : 0) | (c->bias_disabled ? 2 : 0));
         inf.device_bytes = c->tomb.bytes + c->ids.bytes + c->rows_bytes + c->cand.bytes + c->bq.bytes + c->bstate.bytes + c->bcand.bytes +
-                           c->xnorm.bytes + c->repair.bytes + c->floor1.bytes + c->blk.bytes + c->shadow8.bytes + c->xscale8.bytes + c->qs_stats.bytes +
+                           c->xnorm.bytes + c->repair.bytes + c->floor1.bytes + c->rank_a.bytes + c->rank_b.bytes + c->rank_tmp.bytes + c->blk.bytes + c->shadow8.bytes + c->xscale8.bytes + c->qs_stats.bytes +
                            c->shadow.bytes + c->xscale.bytes + c->h_q.bytes + c->h_s.bytes + c->h_i.bytes + c->h_r.bytes + c->h_v.bytes;
     }
     return copy_out_struct(out, inf);
@@ -1891,13 +1984,25 @@ int mvfgpu_search_device(const mvfgpu_corpus* c, uint8_t metric, const void* d_q
             }
         }
     } done_guard{c, s};
-    if (k > MVFGPU_K_PER_PASS) {  // more results than one pass selects: passes of the exact streaming kernel
-        rc = search_large_k(c, metric, d_queries, nq, k, d_scores, d_indices, d_raw, s);
-        if (rc != MVF_OK) return rc;
+    if (k > MVFGPU_K_PER_PASS) {  // more results than one pass selects: the whole shard ranked by a sort, or passes of the exact streaming kernel
+        uint32_t scans = 1;
+        bool sorted = false;
+        if (large_k_by_sort(c, nq, k)) {
+            bool no_room = false;
+            rc = search_sorted_k(c, metric, d_queries, nq, k, d_scores, d_indices, d_raw, s, &no_room);
+            sorted = rc == MVF_OK;
+            if (!sorted && !(no_room && k <= MVFGPU_K_BY_PASSES)) return rc;
+        }
+        if (!sorted) {
+            rc = search_large_k(c, metric, d_queries, nq, k, d_scores, d_indices, d_raw, s);
+            if (rc != MVF_OK) return rc;
+            scans = (k + MVFGPU_K_PER_PASS - 1) / MVFGPU_K_PER_PASS;
+        }
         if (wps && c->prof_next == prof_before + 1) {
             HIP_TRY(hipEventRecord(wps->e[4], s));
             wps->whole = true;
-            c->timing.search_flops = 2ull * nq * c->n * c->dim * ((k + MVFGPU_K_PER_PASS - 1) / MVFGPU_K_PER_PASS);
+            c->timing.search_flops = 2ull * nq * c->n * c->dim * scans;
+            if (sorted) c->timing.scan_kernel = 8u;  // the streaming kernel as a dump + the whole-shard sort
         }
         return MVF_OK;
     }

@@ -16,7 +16,7 @@
 namespace mvf {
 namespace {
 
-__device__ __forceinline__ void write_result(uint64_t comp, uint32_t o, const SelectParams& p) {
+__device__ __forceinline__ void write_result(uint64_t comp, size_t o, const SelectParams& p) {
     const uint32_t key = (uint32_t)(comp >> 32);
     if (comp == kPadComposite) {
         p.out_scores[o] = pad_score(p.metric);
@@ -212,6 +212,15 @@ __global__ void __launch_bounds__(1024) select_final_kernel(SelectParams p) {
     if (p.out_floor1 && tid == 0) p.out_floor1[qout] = m >= p.k ? buf[p.k - 1] + 1ull : ~0ull;
 }
 
+// The tail of a search that ranked the WHOLE shard (api.hip: search_sorted_k): `sorted` holds the n composites of one query in
+// ascending order (deleted rows as the padding value, hence last); the first k become the query's result row at
+// out[out_base ...], entries beyond the rows that exist the padding result.  Only metric / dtype / index_base / ids / out_* / k
+// of the parameter block are read.
+__global__ void __launch_bounds__(256) write_sorted_kernel(SelectParams p, const uint64_t* sorted, uint32_t n, size_t out_base) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < p.k; i += (size_t)gridDim.x * 256)
+        write_result(i < n ? sorted[i] : kPadComposite, out_base + i, p);
+}
+
 // The K2 compactions flag queries whose candidate budget overflowed (overflow[q] != 0).  One block turns the flags into
 // a dense list for the repair launches and clears them.  Order within the list is irrelevant.
 __global__ void __launch_bounds__(1024) flag_compact_kernel(uint32_t* overflow, uint32_t nq, uint32_t* redo_list, uint32_t* redo_cnt) {
@@ -354,6 +363,12 @@ __global__ void synth_packed_kernel(void* out, uint64_t nelem, uint8_t dtype, ui
 
 hipError_t launch_select_final(const SelectParams& p, uint32_t nq, hipStream_t s) {
     hipLaunchKernelGGL(select_final_kernel, dim3(nq), dim3(1024), (size_t)p.P * 8 + 16, s, p);
+    return hipGetLastError();
+}
+
+hipError_t launch_write_sorted(const SelectParams& p, const uint64_t* sorted, uint32_t n, size_t out_base, hipStream_t s) {
+    const uint32_t blocks = (uint32_t)std::min<size_t>(((size_t)p.k + 255) / 256, 4096);
+    hipLaunchKernelGGL(write_sorted_kernel, dim3(blocks), dim3(256), 0, s, p, sorted, n, out_base);
     return hipGetLastError();
 }
 

@@ -42,10 +42,14 @@ struct ScanParams {
     // passes, each returning the best k composites STRICTLY BEHIND the last one the pass before returned.
     // floor1[query] = that composite + 1 (0: no floor; ~0: the rows are exhausted, nothing may pass); NULL = none.
     const uint64_t* floor1;
+    // k beyond what passes are worth (api.hip: search_sorted_k): the floor instantiation run as a DUMP -- no threshold, no
+    // candidates; the composite of every row of query q0 + q goes to dump[q * n + row] (~0 for a deleted row) and a
+    // device-wide sort of the n composites ranks the whole shard.  NULL = none.
+    uint64_t* dump;
 };
 
 // nqv: queries per pass, 1 or 4; p.redo_list != NULL selects the repair variant of the kernel, p.floor1 != NULL the
-// floor variant (stored rows only: units 0..3)
+// floor variant, which p.dump != NULL selects as well (stored rows only: units 0..3)
 #define MVF_DECL_SCAN(dt)                                                                          \
     hipError_t scan_stream_launch_dt##dt(const ScanParams& p, int metric, int G, int nqv, dim3 grid, \
                                          size_t lds, hipStream_t s);                               \

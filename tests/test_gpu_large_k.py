@@ -1,0 +1,164 @@
+"""-m gpu tests of a search for ANY k (round 4, second session).
+
+The reference takes `k: usize` without a limit (examples/similarity_search.rs:143; its heap holds k + 1 entries whatever k
+is, :166-168, and what is left is sorted, :172-173).  Beyond MVFGPU_K_PER_PASS = 1024 the library has two exact
+formulations: passes of the streaming kernel behind a floor (k <= MVFGPU_K_BY_PASSES = 16384) and the WHOLE-SHARD SORT
+(the streaming kernel writes every row's order key, a device-wide sort ranks them; any k).  It picks the cheaper one;
+MVF_LARGE_K = 1 | 2 forces passes | the sort.  Here: both against the oracle and against each other, on every dump site of
+the kernel (lane-group widths 1 / 4 / 8 / 16 / 64, one and four queries per pass), every data type and metric, with ties,
+deletions, vector ids, k at, beyond and far beyond the rows.  Everything through the C ABI; the oracle is the checker."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from metrovector_amd import _lib, errors as E, gpu as G
+
+from _util import assert_exact, assert_float_topk
+
+pytestmark = pytest.mark.gpu
+SEED = 0x4D564631
+PAD = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+
+def forced(c, monkeypatch, mode):
+    """mode: 1 = passes, 2 = the whole-shard sort, 0 = the library's choice."""
+    if mode:
+        monkeypatch.setenv("MVF_LARGE_K", str(mode))
+    else:
+        monkeypatch.delenv("MVF_LARGE_K", raising=False)
+    c.reload_tuning()
+
+
+def same(a, b):
+    return (a.indices == b.indices).all() and (a.raw == b.raw).all() and \
+        (a.scores.view(np.uint32) == b.scores.view(np.uint32)).all()
+
+
+# dim per (dtype): row sizes that take the lane groups 1, 4, 8, 16 and 64 of the streaming kernel
+SHAPES = [(2, 16), (2, 64), (3, 128), (1, 96), (0, 96), (0, 768), (1, 100)]
+
+
+@pytest.mark.parametrize("dtype,dim", SHAPES)
+@pytest.mark.parametrize("metric", [G.L2, G.INNER_PRODUCT, G.COSINE])
+def test_sort_and_passes_agree_and_match_the_oracle(oracle, monkeypatch, dtype, dim, metric):
+    n, k = (60_000 if dim < 768 else 20_000), 3000
+    rows = oracle.synth_rows(SEED, 0, n, dim, dtype)
+    q = oracle.synth_queries(SEED + 1, 6, dim, dtype)
+    with G.GpuCorpus.from_array(rows, index_base=5_000_000_000) as c:
+        c.set_profiling(True)
+        forced(c, monkeypatch, 2)
+        s6 = c.search(q, k, metric)               # four queries + two
+        assert c.last_timing().scan_kernel == 8
+        s1 = c.search(q[5], k, metric)            # one query per pass
+        forced(c, monkeypatch, 1)
+        p6 = c.search(q, k, metric)
+        assert c.last_timing().scan_kernel == 1
+    assert same(s6, p6), "whole-shard sort and passes differ"
+    if dtype in (2, 3) or dim != 768:             # (3-KiB float rows: one query sums on 64 lanes, four on 16 -- other last bits)
+        assert same(G.SearchResult(s6.scores[5:], s6.indices[5:], s6.raw[5:]), s1)
+    osc, oidx, oraw = oracle.search(rows, dtype, metric, q, k, index_base=5_000_000_000)
+    if dtype in (2, 3):
+        assert_exact(s6, osc, oidx, oraw)
+    else:
+        rows32 = rows.astype(np.float32)
+        for qi in (0, 3, 5):
+            sc = oracle.scores(rows, dtype, metric, q[qi])[0]
+            assert_float_topk(metric, s6.scores[qi], s6.indices[qi], sc, rows32, q[qi], k, index_base=5_000_000_000)
+        assert_float_topk(metric, s1.scores[0], s1.indices[0], sc, rows32, q[5], k, index_base=5_000_000_000)
+
+
+@pytest.mark.parametrize("dtype", [0, 1, 2, 3])
+def test_k_far_beyond_the_pass_formulation(oracle, dtype):
+    """k = 50 000, k = n and k = n + 1000 on 120k rows: only the sort serves these (the library's own choice)."""
+    n, dim = 120_000, 48
+    metric = [G.COSINE, G.L2, G.INNER_PRODUCT, G.L2][dtype]
+    rows = oracle.synth_rows(SEED, 0, n, dim, dtype)
+    q = oracle.synth_queries(SEED + 1, 2, dim, dtype)
+    all_sc = [oracle.scores(rows, dtype, metric, q[qi])[0] for qi in range(2)]
+    rows32 = rows.astype(np.float32)
+    with G.GpuCorpus.from_array(rows) as c:
+        for k in (50_000, n, n + 1000):
+            got = c.search(q, k, metric)
+            if dtype in (2, 3):
+                assert_exact(got, *oracle.search(rows, dtype, metric, q, k))
+            else:
+                for qi in range(2):
+                    assert_float_topk(metric, got.scores[qi], got.indices[qi], all_sc[qi], rows32, q[qi], k)
+            if k > n:
+                assert (got.indices[:, n:] == PAD).all()
+                assert sorted(got.indices[0, :n].tolist()) == list(range(n))    # a full ranking: every row exactly once
+
+
+def test_ties_deletions_ids_and_exhaustion_on_the_sort_path(oracle, monkeypatch):
+    """Few distinct scores (ties everywhere: the order inside a tie group is the row position), 40 % of the rows deleted,
+    vector ids, k beyond the live rows -- the sort path against the oracle on the live rows and against the passes."""
+    rng = np.random.default_rng(11)
+    n, dim = 30_000, 32
+    rows = rng.integers(-3, 4, (n, dim)).astype(np.int8)
+    q = rng.integers(-3, 4, (6, dim)).astype(np.int8)
+    dead = np.zeros(n, bool)
+    dead[rng.choice(n, 12_000, replace=False)] = True
+    ids = rng.permutation(n).astype(np.uint64) + np.uint64(10**12)
+    live = np.nonzero(~dead)[0]
+    with G.GpuCorpus.from_array(rows) as c:
+        forced(c, monkeypatch, 2)
+        for k in (1025, 5000, 16384, 16385, 29_999):
+            got = c.search(q, k, G.INNER_PRODUCT)
+            assert_exact(got, *oracle.search(rows, 2, 1, q, k))
+        c.set_tombstones(np.packbits(dead, bitorder="little"))
+        c.set_vector_ids(ids)
+        for k, metric in ((16384, G.L2), (20_000, G.COSINE), (18_000, G.INNER_PRODUCT)):
+            got = c.search(q, k, metric)
+            osc, oidx, oraw = oracle.search(rows[live], 2, metric, q, k)
+            kk = min(k, len(live))
+            assert (got.indices[:, :kk] == ids[live[oidx[:, :kk].astype(np.int64)]]).all()
+            assert (got.raw[:, :kk] == oraw[:, :kk]).all()
+            assert (got.scores[:, :kk].view(np.uint32) == osc[:, :kk].view(np.uint32)).all()
+            assert (got.indices[:, kk:] == PAD).all()                # deleted rows are never returned: padding behind the live ones
+            if k <= 16384:
+                forced(c, monkeypatch, 1)
+                assert same(got, c.search(q, k, metric))
+                forced(c, monkeypatch, 2)
+
+
+def test_nan_scores_rank_behind_every_number_and_in_front_of_the_padding(oracle, monkeypatch):
+    rng = np.random.default_rng(5)
+    n, dim, k = 5000, 24, 6000
+    rows = rng.standard_normal((n, dim)).astype(np.float32)
+    bad = rng.choice(n, 40, replace=False)
+    rows[bad, 3] = np.nan
+    q = rng.standard_normal(dim).astype(np.float32)
+    with G.GpuCorpus.from_array(rows) as c:
+        forced(c, monkeypatch, 2)
+        got = c.search(q, k, G.L2)
+    assert np.isfinite(got.scores[0, :n - 40]).all()
+    assert np.isnan(got.scores[0, n - 40:n]).all() and sorted(got.indices[0, n - 40:n].tolist()) == sorted(bad.tolist())
+    assert (got.indices[0, n - 40:n] == np.sort(bad).astype(np.uint64)).all()      # ties (all NaN) by row position
+    assert (got.indices[0, n:] == PAD).all() and (got.scores[0, n:] == np.inf).all()
+
+
+def test_a_search_after_the_sort_path_is_unchanged(oracle, monkeypatch):
+    """The dump launches use the floor instantiation of the kernel and the handle's candidate buffers: ordinary searches
+    before and after return the same bits."""
+    n, dim = 80_000, 128
+    rows = oracle.synth_rows(SEED, 0, n, dim, 0)
+    q = oracle.synth_queries(SEED + 1, 4, dim, 0)
+    with G.GpuCorpus.from_array(rows) as c:
+        before = c.search(q, 100, G.COSINE)
+        forced(c, monkeypatch, 2)
+        big = c.search(q, 2000, G.COSINE)
+        after = c.search(q, 100, G.COSINE)
+        forced(c, monkeypatch, 1)
+        big_p = c.search(q, 2000, G.COSINE)
+    assert same(before, after) and same(big, big_p)
+    assert (big.indices[:, :100] == before.indices).all()
+
+
+def test_k_beyond_the_abi_limit_is_refused_before_any_device_call():
+    rows = np.zeros((8, 16), np.float32)
+    with G.GpuCorpus.from_array(rows) as c:
+        with pytest.raises(E.InvalidArgument):
+            c.search_device(1, 0, 16, 1, 2**31 + 1, G.L2, 1, 1)    # MVFGPU_MAX_K = 2^31; the pointers are never touched
+        rc = _lib.gpu().mvfgpu_search_device(c._h, 0, C.c_void_p(1), 0, 16, 1, 0, C.c_void_p(1), C.c_void_p(1), None, None)
+        assert rc != 0

@@ -193,7 +193,7 @@ def test_error_codes_mirror_reference():
         with pytest.raises(E.InvalidArgument):
             c.search(np.zeros(16, np.float32), 0)
         with pytest.raises(E.InvalidArgument):
-            c.search(np.zeros(16, np.float32), 16385)   # MVFGPU_MAX_K = 16384
+            c.search_device(1, 0, 16, 1, 2**31 + 1, 0, 1, 1)   # MVFGPU_MAX_K = 2^31: refused before any pointer is touched
         with pytest.raises(E.InvalidArgument):
             c.search(np.zeros(16, np.float32), 2, metric=255)
         with pytest.raises(E.IndexOutOfBounds):
