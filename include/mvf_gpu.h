@@ -59,8 +59,7 @@ typedef struct mvfgpu_corpus mvfgpu_corpus;
                                      behind the last one of the pass before, or -- when that is cheaper, and always beyond
                                      MVFGPU_K_BY_PASSES -- has the streaming kernel write every row's order key (8 bytes per
                                      row) and ranks the WHOLE shard with a device-wide sort (16 bytes of scratch per row and
-                                     query of a pass).  Both exact, whatever the batch size, no host wait; the cross-shard
-                                     merges keep their own limit n_shards * k <= 8192 */
+                                     query of a pass).  Both exact, whatever the batch size, no host wait */
 #define MVFGPU_K_BY_PASSES 16384u /* largest k the pass formulation serves (the fallback when the sort's scratch does not fit) */
 #define MVFGPU_MAX_INT_DIM 33025u /* d*255^2 < 2^31 */
 
@@ -296,7 +295,9 @@ int mvfgpu_search_device(const mvfgpu_corpus* corpus, uint8_t metric,
  * come in ASCENDING ROW-RANGE ORDER (the rank order of an all-gather): each is
  * sorted by (score order, row position), so ties come out in ascending global
  * row position -- also when the shards report vector ids instead of positions
- * (mvfgpu_corpus_set_vector_ids).  nlists * k <= 8192.  data_type tells whether `raw`
+ * (mvfgpu_corpus_set_vector_ids).  nlists * k < 2^32: up to 8192 entries per query merge in one block's LDS, more by a
+ * device-wide sort of the query's entries (the _device forms take their scratch from the stream-ordered allocator:
+ * hipMallocAsync / hipFreeAsync on hip_stream).  data_type tells whether `raw`
  * carries the exact integer score (Int8/UInt8 with L2/InnerProduct).
  * _host: plain host buffers, no GPU needed.  _device: device buffers on
  * `device` (e.g. the output of an RCCL all-gather), async on hip_stream.
@@ -342,7 +343,7 @@ int mvfgpu_merge_topk_packed_device(const void* d_packed, uint32_t nlists,
  *            a device (rehearsing the protocol on fewer GPUs than shards; RCCL refuses duplicate devices), or
  *            MVF_SHARDSET_NO_RCCL=1, exchange their lists with device-to-device copies instead.
  * RCCL is loaded lazily (dlopen librccl.so) by the first mvfgpu_shardset_create; MVF_ERR_DEVICE if it is needed and
- * cannot be loaded.  n_shards * k <= 8192.  One search at a time per set (calls serialise); results as mvfgpu_search.
+ * cannot be loaded.  Any k the shards take (n_shards * k < 2^32).  One search at a time per set (calls serialise); results as mvfgpu_search.
  */
 typedef struct mvfgpu_shardset mvfgpu_shardset;
 typedef struct mvfgpu_shardset_info {

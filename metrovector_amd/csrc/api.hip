@@ -2187,8 +2187,10 @@ int merge_topk_device_impl(const float* d_scores, const uint64_t* d_indices, con
     if (metric != MVF_METRIC_L2 && metric != MVF_METRIC_INNER_PRODUCT && metric != MVF_METRIC_COSINE)
         return fail(MVF_ERR_INVALID_ARGUMENT, "unsupported distance metric code");
     if (nlists == 0 || nq == 0 || k == 0) return fail(MVF_ERR_INVALID_ARGUMENT, "nlists, nq and k must be > 0");
-    if ((uint64_t)nlists * k > kMergeMaxEntries) return fail(MVF_ERR_INVALID_ARGUMENT, "nlists * k exceeds 8192");
-    const uint32_t P = next_pow2(std::max(2u, nlists * k));
+    const uint64_t total = (uint64_t)nlists * k;
+    if (total > 0xFFFFFFFFull) return fail(MVF_ERR_INVALID_ARGUMENT, "nlists * k exceeds 2^32 - 1");
+    const bool large = total > kMergeMaxEntries;  // beyond one block's LDS: a device-wide sort per query
+    const uint32_t P = large ? 0u : next_pow2(std::max(2u, nlists * k));
     DeviceGuard guard(device);
     if (!guard.ok) return fail(MVF_ERR_DEVICE, "hipSetDevice failed");
     ShardMergeParams p{};
@@ -2207,7 +2209,31 @@ int merge_topk_device_impl(const float* d_scores, const uint64_t* d_indices, con
     p.out_scores = d_out_scores;
     p.out_indices = d_out_indices;
     p.out_raw = d_out_raw;
-    HIP_TRY(launch_merge_shards(p, static_cast<hipStream_t>(hip_stream)));
+    hipStream_t s = static_cast<hipStream_t>(hip_stream);
+    if (!large) {
+        HIP_TRY(launch_merge_shards(p, s));
+        return MVF_OK;
+    }
+    // the sort's buffers live for this call only, in stream order (this entry point has no handle to keep them in)
+    size_t tmp_bytes = 0;
+    HIP_TRY(sort_composites(nullptr, &tmp_bytes, nullptr, nullptr, (size_t)total, nullptr, s));
+    tmp_bytes = std::max<size_t>(tmp_bytes, 256);
+    const size_t cb = ((size_t)total * 8 + 255) & ~(size_t)255;
+    void* scratch = nullptr;
+    HIP_TRY(hipMallocAsync(&scratch, 2 * cb + tmp_bytes, s));
+    uint64_t *a = static_cast<uint64_t*>(scratch), *b = reinterpret_cast<uint64_t*>(static_cast<unsigned char*>(scratch) + cb);
+    void* tmp = static_cast<unsigned char*>(scratch) + 2 * cb;
+    hipError_t e = hipSuccess;
+    for (uint32_t q = 0; q < nq && e == hipSuccess; q++) {
+        uint64_t* sorted = a;
+        size_t tb = tmp_bytes;
+        e = launch_merge_build(p, q, a, s);
+        if (e == hipSuccess) e = sort_composites(tmp, &tb, a, b, (size_t)total, &sorted, s);
+        if (e == hipSuccess) e = launch_merge_write(p, q, sorted, s);
+    }
+    const hipError_t ef = hipFreeAsync(scratch, s);
+    HIP_TRY(e);
+    HIP_TRY(ef);
     return MVF_OK;
 }
 }  // namespace

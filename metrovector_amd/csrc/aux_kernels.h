@@ -64,6 +64,9 @@ constexpr uint32_t kMergeMaxEntries = 8192;  // nlists * k of one cross-shard me
 
 hipError_t launch_select_final(const SelectParams& p, uint32_t nq, hipStream_t s);
 hipError_t launch_merge_shards(const ShardMergeParams& p, hipStream_t s);
+// nlists * k beyond kMergeMaxEntries: query q's composites to HBM / the first k of the sorted composites gathered (api.hip)
+hipError_t launch_merge_build(const ShardMergeParams& p, uint32_t q, uint64_t* comps, hipStream_t s);
+hipError_t launch_merge_write(const ShardMergeParams& p, uint32_t q, const uint64_t* sorted, hipStream_t s);
 // result row of a query from the ascending composites of ALL its rows (sort_topk.hip); reads metric, dtype, index_base, ids,
 // out_*, k of `p`; the row starts at element out_base of the output arrays
 hipError_t launch_write_sorted(const SelectParams& p, const uint64_t* sorted, uint32_t n, size_t out_base, hipStream_t s);

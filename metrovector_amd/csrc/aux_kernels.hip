@@ -266,7 +266,7 @@ __global__ void __launch_bounds__(256) merge_shards_kernel(ShardMergeParams p) {
     __syncthreads();
     bitonic_sort_u64<256>(buf, p.P, tid);
     for (uint32_t i = tid; i < p.k; i += 256) {
-        const uint32_t o = q * p.k + i;
+        const size_t o = (size_t)q * p.k + i;
         const uint64_t comp = i < p.P ? buf[i] : kPadComposite;
         if (comp == kPadComposite) {
             p.out_scores[o] = pad_score(p.metric);
@@ -275,6 +275,41 @@ __global__ void __launch_bounds__(256) merge_shards_kernel(ShardMergeParams p) {
         } else {
             const uint32_t slot = (uint32_t)comp, l = slot / p.k, j = slot % p.k;
             const size_t rem = (size_t)q * p.k + j;
+            p.out_scores[o] = p.scores[l * p.ls_scores + rem];
+            p.out_indices[o] = p.indices[l * p.ls_indices + rem];
+            if (p.out_raw) p.out_raw[o] = p.raw ? p.raw[l * p.ls_raw + rem] : 0;
+        }
+    }
+}
+
+// The same merge for lists too long for one block's LDS (nlists * k > kMergeMaxEntries; any k since round 4): the composites
+// of ONE query go to HBM (merge_build_kernel), a device-wide sort orders them (sort_topk.hip) and merge_write_kernel gathers
+// the first k.  Same composite, same tie rule, same padding as merge_shards_kernel.
+__global__ void __launch_bounds__(256) merge_build_kernel(ShardMergeParams p, uint32_t q, uint64_t* comps) {
+    const size_t total = (size_t)p.nlists * p.k;
+    const bool use_raw = key_is_raw(p.dtype, p.metric) && p.raw != nullptr;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const size_t l = i / p.k, j = i % p.k, rem = (size_t)q * p.k + j;
+        uint64_t comp = kPadComposite;
+        if (p.indices[l * p.ls_indices + rem] != ~0ull) {
+            const uint32_t ky = use_raw ? key_from_raw(p.raw[l * p.ls_raw + rem], p.metric)
+                                        : key_from_score(p.scores[l * p.ls_scores + rem], p.metric);
+            comp = ((uint64_t)ky << 32) | (uint32_t)i;
+        }
+        comps[i] = comp;
+    }
+}
+
+__global__ void __launch_bounds__(256) merge_write_kernel(ShardMergeParams p, uint32_t q, const uint64_t* sorted) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < p.k; i += (size_t)gridDim.x * 256) {
+        const size_t o = (size_t)q * p.k + i;
+        const uint64_t comp = sorted[i];  // nlists * k >= k entries
+        if (comp == kPadComposite) {
+            p.out_scores[o] = pad_score(p.metric);
+            p.out_indices[o] = ~0ull;
+            if (p.out_raw) p.out_raw[o] = 0;
+        } else {
+            const size_t slot = (uint32_t)comp, l = slot / p.k, j = slot % p.k, rem = (size_t)q * p.k + j;
             p.out_scores[o] = p.scores[l * p.ls_scores + rem];
             p.out_indices[o] = p.indices[l * p.ls_indices + rem];
             if (p.out_raw) p.out_raw[o] = p.raw ? p.raw[l * p.ls_raw + rem] : 0;
@@ -369,6 +404,17 @@ hipError_t launch_select_final(const SelectParams& p, uint32_t nq, hipStream_t s
 hipError_t launch_write_sorted(const SelectParams& p, const uint64_t* sorted, uint32_t n, size_t out_base, hipStream_t s) {
     const uint32_t blocks = (uint32_t)std::min<size_t>(((size_t)p.k + 255) / 256, 4096);
     hipLaunchKernelGGL(write_sorted_kernel, dim3(blocks), dim3(256), 0, s, p, sorted, n, out_base);
+    return hipGetLastError();
+}
+
+hipError_t launch_merge_build(const ShardMergeParams& p, uint32_t q, uint64_t* comps, hipStream_t s) {
+    const size_t total = (size_t)p.nlists * p.k;
+    hipLaunchKernelGGL(merge_build_kernel, dim3((uint32_t)std::min<size_t>((total + 255) / 256, 4096)), dim3(256), 0, s, p, q, comps);
+    return hipGetLastError();
+}
+
+hipError_t launch_merge_write(const ShardMergeParams& p, uint32_t q, const uint64_t* sorted, hipStream_t s) {
+    hipLaunchKernelGGL(merge_write_kernel, dim3((uint32_t)std::min<size_t>(((size_t)p.k + 255) / 256, 4096)), dim3(256), 0, s, p, q, sorted);
     return hipGetLastError();
 }
 

@@ -353,7 +353,7 @@ int mvfgpu_shardset_search(mvfgpu_shardset* ss, uint8_t metric, const void* quer
     // against their own handle)
     if (!ss) return set_fail(MVF_ERR_INVALID_ARGUMENT, "shard set is NULL");
     if (!queries || !out_scores || !out_indices) return set_fail(MVF_ERR_INVALID_ARGUMENT, "NULL buffer");
-    if (nq == 0 || k == 0 || k > MVFGPU_K_PER_PASS) return set_fail(MVF_ERR_INVALID_ARGUMENT, "nq must be > 0 and k in 1..1024 (a shard set merges n_shards * k <= 8192 entries)");
+    if (nq == 0 || k == 0 || k > MVFGPU_MAX_K) return set_fail(MVF_ERR_INVALID_ARGUMENT, "nq must be > 0 and k in 1..2^31");
     if (metric != MVF_METRIC_L2 && metric != MVF_METRIC_INNER_PRODUCT && metric != MVF_METRIC_COSINE)
         return set_fail(MVF_ERR_INVALID_ARGUMENT, "unsupported distance metric code");
     const bool int_space = ss->dtype == MVF_DTYPE_INT8 || ss->dtype == MVF_DTYPE_UINT8;
@@ -363,7 +363,7 @@ int mvfgpu_shardset_search(mvfgpu_shardset* ss, uint8_t metric, const void* quer
     if (query_dim != ss->dim)
         return set_fail(MVF_ERR_DIMENSION_MISMATCH, "Dimension mismatch: expected " + std::to_string(ss->dim) + ", got " + std::to_string(query_dim));
     const int S = (int)ss->shards.size();
-    if ((uint64_t)S * k > 8192) return set_fail(MVF_ERR_INVALID_ARGUMENT, "n_shards * k exceeds 8192 (the cross-shard merge's capacity)");
+    if ((uint64_t)S * k > 0xFFFFFFFFull) return set_fail(MVF_ERR_INVALID_ARGUMENT, "n_shards * k exceeds 2^32 - 1 (the cross-shard merge's capacity)");
     std::lock_guard<std::mutex> lk(ss->mu);
     int prev = -1;
     (void)hipGetDevice(&prev);

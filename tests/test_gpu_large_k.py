@@ -162,3 +162,60 @@ def test_k_beyond_the_abi_limit_is_refused_before_any_device_call():
             c.search_device(1, 0, 16, 1, 2**31 + 1, G.L2, 1, 1)    # MVFGPU_MAX_K = 2^31; the pointers are never touched
         rc = _lib.gpu().mvfgpu_search_device(c._h, 0, C.c_void_p(1), 0, 16, 1, 0, C.c_void_p(1), C.c_void_p(1), None, None)
         assert rc != 0
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Cross-shard merges beyond one block's LDS (nlists * k > 8192): a device-wide sort per query.  Same order as the LDS merge
+# and the host merge: (score order, list order, rank in the list).
+# ---------------------------------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("dtype,metric", [(0, G.L2), (2, G.INNER_PRODUCT), (3, G.COSINE)])
+@pytest.mark.parametrize("packed", [False, True])
+def test_device_merge_of_long_lists(oracle, dtype, metric, packed):
+    import torch
+    rng = np.random.default_rng(3)
+    n, dim, nq, nl = 60_000, 16, 3, 5
+    rows = oracle.synth_rows(SEED, 0, n, dim, dtype) if dtype == 0 else rng.integers(-2, 3, (n, dim)).astype([None, None, np.int8, np.uint8][dtype])
+    q = oracle.synth_queries(SEED + 1, nq, dim, dtype) if dtype == 0 else rng.integers(0, 3, (nq, dim)).astype(rows.dtype)
+    cuts = [0, 9000, 9000, 31_000, 52_500, n]                   # ragged shards, one of them empty
+    for k in (1700, 9000, 20_000):                              # 5 x 1700 = 8500 > 8192: the first size the sort serves
+        parts = [oracle.search(rows[a:b], dtype, metric, q, k, index_base=int(a)) for a, b in zip(cuts[:-1], cuts[1:])]
+        S, I, R = (np.stack([p[j] for p in parts]) for j in range(3))
+        want_s, want_i, want_r = oracle.search(rows, dtype, metric, q, k)
+        oS = torch.empty((nq, k), dtype=torch.float32, device="cuda")
+        oI = torch.empty((nq, k), dtype=torch.int64, device="cuda")
+        oR = torch.empty((nq, k), dtype=torch.int32, device="cuda")
+        if packed:   # one list = { u64 indices | f32 scores | i32 raw } (MVFGPU_PACKED_LIST_BYTES): what the all-gather delivers
+            buf = np.concatenate([np.concatenate([I[l].view(np.uint8).ravel(), S[l].view(np.uint8).ravel(), R[l].view(np.uint8).ravel()])
+                                  for l in range(nl)])
+            dP = torch.from_numpy(buf).cuda()
+            _lib.gpu_check(_lib.gpu().mvfgpu_merge_topk_packed_device(dP.data_ptr(), nl, nq, k, metric, dtype, oS.data_ptr(),
+                                                                      oI.data_ptr(), oR.data_ptr(), 0, None))
+        else:
+            dS, dI, dR = torch.from_numpy(S).cuda(), torch.from_numpy(I.view(np.int64)).cuda(), torch.from_numpy(R).cuda()
+            _lib.gpu_check(_lib.gpu().mvfgpu_merge_topk_device(dS.data_ptr(), dI.data_ptr(), dR.data_ptr(), nl, nq, k, metric, dtype,
+                                                               oS.data_ptr(), oI.data_ptr(), oR.data_ptr(), 0, None))
+        torch.cuda.synchronize()
+        got = G.SearchResult(oS.cpu().numpy(), oI.cpu().numpy().view(np.uint64), oR.cpu().numpy())
+        hm = G.merge_topk_host(S, I, R, metric, dtype)
+        assert same(got, hm), "device merge (sort) differs from the host merge"
+        assert_exact(got, want_s, want_i, want_r)               # merge(top-k per shard) == top-k(global), ties by position
+
+
+def test_shardset_with_k_in_the_thousands(oracle, monkeypatch):
+    """Three shards behind mvfgpu_shardset_search, k = 1024 (the LDS merge's last size), 5000 and 20 000 (per-shard searches
+    by the whole-shard sort, merge by the device-wide sort): the oracle's answer over all rows, bit for bit (Int8)."""
+    rng = np.random.default_rng(8)
+    n, dim, nq = 45_000, 48, 5
+    rows = rng.integers(-5, 6, (n, dim)).astype(np.int8)
+    q = rng.integers(-5, 6, (nq, dim)).astype(np.int8)
+    cuts = [0, 20_000, 21_000, n]
+    shards = [G.GpuCorpus.from_array(rows[a:b], index_base=int(a)) for a, b in zip(cuts[:-1], cuts[1:])]
+    try:
+        with G.ShardSet(shards) as ss:
+            for k in (1024, 5000, 20_000):
+                got = ss.search(q, k, G.L2)
+                assert_exact(got, *oracle.search(rows, 2, 0, q, k))
+    finally:
+        for c in shards:
+            c.close()
