@@ -16,6 +16,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstring>
+#include <chrono>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -131,6 +132,7 @@ Tuning read_tuning() {
     t.host_zc_query = (size_t)std::max(0l, num("MVF_HOST_ZC_QUERY", 64l << 10));
     t.host_zc_results = (size_t)std::max(0l, num("MVF_HOST_ZC_RESULTS", 256l << 10));
     t.large_k = (int)std::min(2l, std::max(0l, num("MVF_LARGE_K", 0)));
+    t.host_flag_wait = flag("MVF_HOST_FLAG_WAIT", true);
     return t;
 }
 }  // namespace mvf
@@ -184,6 +186,13 @@ struct mvfgpu_corpus {
     mutable bool xnorm_ready = false;
     mutable uint32_t bstate_slots = 0;    // queries the K2 state arrays are armed for
     mutable DevBuf h_q, h_s, h_i, h_r;    // device mirrors for the host-buffer API
+    // Completion of a small blocking search without the stream: the final select stores a sequence number into pinned host
+    // memory behind its results and search_host spins on it -- hipStreamSynchronize learns of a finished kernel ~5 us later
+    // (end-of-pipe flush, completion signal, wake-up; profiles/r04_flag_wait.txt).
+    mutable PinBuf pin_flag;
+    mutable DevBuf done_ticket;
+    mutable uint32_t flag_seq = 0;
+    mutable uint64_t work_gen = 0, confirmed_gen = ~0ull;  // searches enqueued on the handle / the newest one seen complete through the flag
     mutable PinBuf pin_q, pin_out, pin_vec;  // ... and its pinned host mirrors (small queries / results / payload rows: no copy engine at all)
     mutable DevBuf h_v;                   // payload rows of mvfgpu_search_fetch too large for that
     mutable hipStream_t own_stream = nullptr;
@@ -310,6 +319,17 @@ struct ShadowStream {
     uint32_t* cnt;    // [nq]
     uint32_t cand_cap;
 };
+
+// search_host's request to the search it is about to make ON THIS THREAD: "store `seq` to `flag` behind your results if your
+// last kernel can" (the streaming path's final select); `armed` comes back true if it will.
+struct HostFlagReq {
+    uint32_t* flag;
+    uint32_t* ticket;
+    uint32_t seq;
+    bool armed;
+    uint64_t gen;  // the handle's work_gen of this search
+};
+thread_local HostFlagReq* t_flag_req = nullptr;
 
 int search_stream_path(const mvfgpu_corpus* c, uint8_t metric, const void* d_queries, uint32_t nq, uint32_t k,
                        float* d_scores, uint64_t* d_indices, int32_t* d_raw, hipStream_t s, bool profile = true,
@@ -491,6 +511,12 @@ int search_stream_path(const mvfgpu_corpus* c, uint8_t metric, const void* d_que
                 fp.out_stride = out_stride;
                 fp.out_offset = out_offset;
                 fp.out_floor1 = out_floor1 ? out_floor1 + q0 : nullptr;
+                if (t_flag_req && !out_floor1 && q0 + nq_here == nq) {  // the search's last kernel
+                    fp.done_flag = t_flag_req->flag;
+                    fp.done_ticket = t_flag_req->ticket;
+                    fp.done_seq = t_flag_req->seq;
+                    t_flag_req->armed = true;
+                }
             }
             HIP_TRY(launch_select_final(fp, nq_here, s));
         }
@@ -1766,6 +1792,8 @@ void mvfgpu_corpus_destroy(mvfgpu_corpus* c) {
         c->h_i.release();
         c->h_r.release();
         c->pin_q.release();
+        c->pin_flag.release();
+        c->done_ticket.release();
         c->pin_out.release();
         c->pin_vec.release();
         c->h_v.release();
@@ -1959,6 +1987,8 @@ int mvfgpu_search_device(const mvfgpu_corpus* c, uint8_t metric, const void* d_q
     if (!guard.ok) return fail(MVF_ERR_DEVICE, "hipSetDevice failed");
     hipStream_t s = static_cast<hipStream_t>(hip_stream);
     std::lock_guard<std::mutex> lk(c->mu);
+    c->work_gen++;
+    if (t_flag_req) t_flag_req->gen = c->work_gen;
     // the scratch buffers are stream-ordered: a call on another stream waits for the previous one
     if (c->has_done && c->last_stream != s) HIP_TRY(hipStreamWaitEvent(s, c->ev_done, 0));
     mvfgpu_corpus::ProfSlot* wps = nullptr;  // whole-search events: every kernel of this call on the stream
@@ -2062,8 +2092,9 @@ int search_host(const mvfgpu_corpus* c, uint8_t metric, const void* queries, uin
     bool fused_fetch = false;
     {
         std::lock_guard<std::mutex> lk(c->mu);
-        // wait for any in-flight user of the mirrors before (re)allocating them
-        if (c->has_done) HIP_TRY(hipEventSynchronize(c->ev_done));
+        // wait for any in-flight user of the mirrors before (re)allocating them (nothing is in flight when the newest work
+        // was seen complete through the flag: its event would only be signalled a few microseconds from now)
+        if (c->has_done && c->confirmed_gen != c->work_gen) HIP_TRY(hipEventSynchronize(c->ev_done));
         fused_fetch = out_vectors && c->h_ids.empty();
         if (zc_q) {
             HIP_TRY(c->pin_q.reserve(qbytes));
@@ -2097,9 +2128,47 @@ int search_host(const mvfgpu_corpus* c, uint8_t metric, const void* queries, uin
             }
         }
     }
+    HostFlagReq req{};
+    if (zc_out && !out_vectors && c->tune.host_flag_wait) {
+        std::lock_guard<std::mutex> lk(c->mu);
+        if (!c->pin_flag.p) {
+            HIP_TRY(c->pin_flag.reserve(64));
+            *static_cast<volatile uint32_t*>(c->pin_flag.p) = 0;
+            HIP_TRY(c->done_ticket.reserve(256));
+            HIP_TRY(hipMemsetAsync(c->done_ticket.p, 0, 256, c->own_stream));
+        }
+        req.flag = static_cast<uint32_t*>(c->pin_flag.p);
+        req.ticket = static_cast<uint32_t*>(c->done_ticket.p);
+        req.seq = ++c->flag_seq;
+        if (req.seq == 0) req.seq = ++c->flag_seq;
+        t_flag_req = &req;
+    }
     rc = mvfgpu_search_device(c, metric, dq, query_dtype, query_dim, nq, k, static_cast<float*>(ds),
                               static_cast<uint64_t*>(di), static_cast<int32_t*>(dr), c->own_stream);
+    t_flag_req = nullptr;
     if (rc != MVF_OK) return rc;
+    if (req.armed) {
+        // the final select writes req.seq behind its results: spin on it (bounded: a long search falls back to the stream)
+        const auto t0 = std::chrono::steady_clock::now();
+        bool seen = false;
+        for (uint32_t spins = 0;; spins++) {
+            if (__atomic_load_n(req.flag, __ATOMIC_ACQUIRE) == req.seq) {
+                seen = true;
+                break;
+            }
+            if ((spins & 255u) == 255u && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(300)) break;
+            __builtin_ia32_pause();
+        }
+        if (!seen) HIP_TRY(hipStreamSynchronize(c->own_stream));
+        {
+            std::lock_guard<std::mutex> lk(c->mu);
+            c->confirmed_gen = req.gen;  // == work_gen unless another thread has enqueued a search meanwhile
+        }
+        memcpy(out_scores, ds, nres * 4);
+        memcpy(out_indices, di, nres * 8);
+        if (out_raw) memcpy(out_raw, dr, nres * 4);
+        return MVF_OK;
+    }
     if (fused_fetch)  // padding entries (index UINT64_MAX) give zero rows
         HIP_TRY(launch_gather_rows(c->d_rows, c->n, c->pitch, row_bytes, c->index_base, static_cast<const uint64_t*>(di), (uint32_t)nres,
                                    static_cast<unsigned char*>(dv), c->own_stream));

@@ -43,6 +43,12 @@ struct SelectParams {
     // + 1 -- the next pass's floor (ScanParams::floor1) -- or ~0 when fewer than k rows were left
     uint32_t out_stride, out_offset;
     uint64_t* out_floor1;  // nullable
+    // the blocking host call waits on a word of pinned host memory instead of the stream (api.hip: search_host): the block that
+    // finishes LAST (a ticket in *done_ticket, which it leaves at 0; one block: no ticket) stores done_seq to *done_flag behind
+    // its results, at system scope.  NULL = none.
+    uint32_t* done_flag;
+    uint32_t* done_ticket;
+    uint32_t done_seq;
 };
 
 // queries flagged by the K2 compactions -> a dense list + its length, flags cleared (one block)

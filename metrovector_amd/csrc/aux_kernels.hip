@@ -208,8 +208,21 @@ __global__ void __launch_bounds__(1024) select_final_kernel(SelectParams p) {
         return;
     }
     const uint32_t stride = p.out_stride ? p.out_stride : p.k;
-    for (uint32_t i = tid; i < p.k; i += 1024) write_result(i < m ? buf[i] : kPadComposite, qout * stride + p.out_offset + i, p);
+    for (uint32_t i = tid; i < p.k; i += 1024) write_result(i < m ? buf[i] : kPadComposite, (size_t)qout * stride + p.out_offset + i, p);
     if (p.out_floor1 && tid == 0) p.out_floor1[qout] = m >= p.k ? buf[p.k - 1] + 1ull : ~0ull;
+    if (p.done_flag) {  // block-uniform: tell the waiting host call (results in pinned host memory) that everything is there
+        __threadfence_system();
+        __syncthreads();
+        if (tid == 0) {
+            bool last = true;
+            if (gridDim.x > 1) {
+                const uint32_t t = __hip_atomic_fetch_add(p.done_ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+                last = t + 1 == gridDim.x;
+                if (last) __hip_atomic_store(p.done_ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (last) __hip_atomic_store(p.done_flag, p.done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
 }
 
 // The tail of a search that ranked the WHOLE shard (api.hip: search_sorted_k): `sorted` holds the n composites of one query in

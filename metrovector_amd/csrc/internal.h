@@ -49,6 +49,7 @@ struct Tuning {
     uint32_t k1_rank_merge = 128;  // MVF_K1_RANK_MERGE: a piece's survivors up to this many are merged by counting (0: always sorted; <= 256)
     size_t host_zc_query = 64u << 10;     // MVF_HOST_ZC_QUERY: mvfgpu_search reads queries up to this size in place (pinned host)
     size_t host_zc_results = 256u << 10;  // MVF_HOST_ZC_RESULTS: ... and writes results up to this size in place
+    bool host_flag_wait = true; // MVF_HOST_FLAG_WAIT=0: the blocking host call always waits on its stream (not on the flag the final select writes)
     int large_k = 0;            // MVF_LARGE_K=1|2: k beyond one pass always by passes (1; k <= 16384) / always by the whole-shard sort (2); 0: the cheaper one
 };
 Tuning read_tuning();
