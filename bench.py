@@ -985,6 +985,52 @@ def main():
                     gi = outs[1].cpu().numpy().view(np.uint64)[sel]
                     leg["recall_at_k"] = recall_of(gi, oidx, outs[0].cpu().numpy()[sel], osc, args.metric)
                 result[name] = leg
+        # ---- k beyond one pass (the reference takes any k: usize, examples/similarity_search.rs:143): the same query for its
+        # 16384 best rows, by 16 passes of the streaming kernel and by the whole-shard sort (one dump pass + a device-wide
+        # radix sort of the 10M order keys), and k = 1M by the sort (the only formulation beyond 16384)
+        if args.queries == 1 and not args.no_batched:
+            leg = {"workload": result["config"]["workload"].replace(f"top-{args.k}", "top-16384 / top-1000000")}
+            ref = None
+            for name, env, kk in (("k16384_passes", "1", 16384), ("k16384_sort", "2", 16384), ("k1000000_sort", None, 1_000_000)):
+                if kk > args.rows:
+                    continue
+                if env is None:
+                    os.environ.pop("MVF_LARGE_K", None)
+                else:
+                    os.environ["MVF_LARGE_K"] = env
+                corpus.reload_tuning()
+                ds = torch.empty((1, kk), dtype=torch.float32, device=dev)
+                di = torch.empty((1, kk), dtype=torch.int64, device=dev)
+
+                def big():
+                    corpus.search_device(dq.data_ptr(), qcode, args.dim, 1, kk, args.metric, ds.data_ptr(), di.data_ptr())
+
+                big()
+                torch.cuda.synchronize()
+                reps = 3
+                t0 = time.perf_counter()
+                for _ in range(reps):
+                    big()
+                torch.cuda.synchronize()
+                leg[name] = {"ms_per_search": (time.perf_counter() - t0) / reps * 1e3}
+                if kk == 16384:
+                    if ref is None:
+                        ref = (di.clone(), ds.clone())
+                    else:
+                        leg[name]["identical_to_passes"] = bool((ref[0] == di).all().item() and (ref[1] == ds).all().item())
+                else:
+                    leg[name]["first_16384_identical"] = bool((ref[0][0] == di[0, :16384]).all().item()) if ref is not None else None
+                    leg[name]["sorted_best_first"] = bool(((ds[0, 1:] - ds[0, :-1]) * (1 if args.metric == 0 else -1) >= 0).all().item())
+            os.environ.pop("MVF_LARGE_K", None)
+            corpus.reload_tuning()
+            if not args.no_recall and ref is not None:
+                t1 = time.perf_counter()
+                osc_k, oidx_k, _ = oracle_topk_rows(oracle, 0, args.rows, args.dim, args.dtype, args.metric, q[:1], 16384)
+                gi_k = ref[0].cpu().numpy().view(np.uint64)
+                leg["recall_at_16384"] = recall_of(gi_k, oidx_k, ref[1].cpu().numpy(), osc_k, args.metric)
+                leg["rows_identical_to_the_oracle_list"] = int((gi_k == oidx_k).sum())
+                leg["recall_oracle_s"] = time.perf_counter() - t1
+            result["any_k"] = leg
         # ---- the metric's second leg: the same resident corpus, 1024 batched queries (MFMA path) ----------
         # Three ways, same results: the default (int8 MFMA kernel selecting on the int8 shadow of the rows, every row inside
         # a proven bound of the k-th best re-scored exactly from the f32 rows), the f16 MFMA kernel on the scaled-f16
