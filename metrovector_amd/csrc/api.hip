@@ -153,6 +153,7 @@ struct mvfgpu_corpus {
     mutable DevBuf bq, bstate, bcand, xnorm;  // K2: padded queries + norms; tau/cnt/overflow; candidates; row norms
     mutable DevBuf blk;                   // K2 narrow types: per-block candidate regions + their counts (scan_mfma.h)
     mutable DevBuf repair;                // K2 overflow repair: gathered queries + their results
+    mutable std::vector<std::pair<uint64_t, int>> occ_cache;  // (kernel, dynamic LDS) -> blocks per CU (scan_occupancy)
     mutable DevBuf floor1;                // k > MVFGPU_K_PER_PASS: per query, the last composite the pass before returned, + 1
     mutable DevBuf rank_a, rank_b, rank_tmp;  // k > MVFGPU_K_PER_PASS by the whole-shard sort: the composites of every row (x the queries of a pass), twice, + the sort's scratch
     mutable DevBuf shadow, xscale;        // Float32 corpora: scaled-f16 shadow rows (selection only) + 2^-s_r per row
@@ -320,6 +321,24 @@ struct ShadowStream {
     uint32_t cand_cap;
 };
 
+// Blocks per CU of a streaming-kernel instantiation at a dynamic-LDS size: asked once per (kernel, LDS bytes) and handle -- the
+// runtime's answer costs 1-2 us and sits in front of the first launch of every search (a 10k-row search is 25 us in all).
+int scan_occupancy(const mvfgpu_corpus* c, const void* kfn, size_t lds, int* occ_out) {
+    const uint64_t key = (uint64_t)(reinterpret_cast<uintptr_t>(kfn)) * 0x9E3779B97F4A7C15ull ^ (uint64_t)lds;
+    for (const auto& e : c->occ_cache)
+        if (e.first == key) {
+            *occ_out = e.second;
+            return MVF_OK;
+        }
+    if (lds > 48 * 1024) HIP_TRY(hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    int occ = 0;
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kfn, 256, lds));
+    if (occ < 1) occ = 1;
+    if (c->occ_cache.size() < 64) c->occ_cache.emplace_back(key, occ);
+    *occ_out = occ;
+    return MVF_OK;
+}
+
 // search_host's request to the search it is about to make ON THIS THREAD: "store `seq` to `flag` behind your results if your
 // last kernel can" (the streaming path's final select); `armed` comes back true if it will.
 struct HostFlagReq {
@@ -380,11 +399,11 @@ int search_stream_path(const mvfgpu_corpus* c, uint8_t metric, const void* d_que
             const void* kfn = alt8  ? scan_stream_kernel_ptr_dt2x(metric, G, nqv)
                               : alt ? scan_stream_kernel_ptr_dt1x(metric, G, nqv)
                                     : scan_kernel(c->dtype, metric, G, nqv, /*redo=*/false, floor1 != nullptr || rank != nullptr);
-            if (lds > 48 * 1024)
-                HIP_TRY(hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            int occ = 0;
-            HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kfn, 256, lds));
-            if (occ < 1) occ = 1;
+            int occ = 1;
+            {
+                const int orc = scan_occupancy(c, kfn, lds, &occ);
+                if (orc != MVF_OK) return orc;
+            }
             {  // A corpus of fewer 512-row chunks than the GPU holds blocks (n < ~650K rows) would leave most of them idle:
                // smaller chunks, one per resident block -- n / blocks rounded up to the kernel's step (100K x 128 f32: 196
                // blocks -> 782, 52 -> 31 us per search).  Up to four chunks per block the last round is uneven (700K x 256:
@@ -782,10 +801,11 @@ int repair_flagged_queries(const mvfgpu_corpus* c, uint8_t metric, const void* d
     const uint32_t nchunks = (uint32_t)((c->n + chunk_rows - 1) / chunk_rows);
     if (lds > 160 * 1024) return fail(MVF_ERR_BUILD, "dimension too large for the streaming kernel's LDS query tile");
     const void* kfn = scan_kernel(c->dtype, metric, G, nqv, /*redo=*/true);
-    if (lds > 48 * 1024) HIP_TRY(hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    int occ = 0;
-    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kfn, 256, lds));
-    if (occ < 1) occ = 1;
+    int occ = 1;
+    {
+        const int orc = scan_occupancy(c, kfn, lds, &occ);
+        if (orc != MVF_OK) return orc;
+    }
     // Two blocks per CU at most: the repair is rare, and every block's list costs scratch for EVERY query a launch pair may
     // serve -- with fewer lists a pair serves more queries (up to 4096 within 256 MiB of lists: 512 at k = 100, all of a
     // 10,000-query batch in three pairs at k = 10), and a 1024-query search enqueues 2 (empty) pairs instead of 16
