@@ -1602,18 +1602,38 @@ int search_sorted_k(const mvfgpu_corpus* c, uint8_t metric, const void* d_querie
     if (c->n > 0) HIP_TRY(sort_composites(nullptr, &tmp_bytes, nullptr, nullptr, (size_t)c->n, nullptr, s));
     tmp_bytes = std::max<size_t>(tmp_bytes, 256);
     RankAll ra{};
+    ra.k_out = k;
+    // Up to 1 GiB the buffers stay with the handle; beyond it (50M rows x four queries: 3.2 GB) they come from the stream-ordered
+    // allocator for this search only -- memory a later shadow build or upload may need, and no host wait either way.
+    constexpr size_t kKeep = 1ull << 30;
     for (int nqv = nq >= 2 ? 4 : 1;; nqv = 1) {
-        const size_t bytes = std::max<size_t>((size_t)nqv * c->n * 8, 256);
-        const bool ok = c->rank_a.reserve(bytes) == hipSuccess && c->rank_b.reserve(bytes) == hipSuccess &&
-                        c->rank_tmp.reserve(tmp_bytes) == hipSuccess;
-        if (ok) {
+        const size_t bytes = (std::max<size_t>((size_t)nqv * c->n * 8, 256) + 255) & ~(size_t)255;
+        if (2 * bytes + tmp_bytes > kKeep) {
+            void* scratch = nullptr;
+            if (hipMallocAsync(&scratch, 2 * bytes + tmp_bytes, s) == hipSuccess) {
+                ra.nqv = nqv;
+                ra.a = static_cast<uint64_t*>(scratch);
+                ra.b = reinterpret_cast<uint64_t*>(static_cast<unsigned char*>(scratch) + bytes);
+                ra.tmp = static_cast<unsigned char*>(scratch) + 2 * bytes;
+                ra.tmp_bytes = tmp_bytes;
+                const int rc = search_stream_path(c, metric, d_queries, nq, 16, d_scores, d_indices, d_raw, s, /*profile=*/true, nullptr,
+                                                  nullptr, nullptr, 0, 0, &ra);
+                const hipError_t ef = hipFreeAsync(scratch, s);
+                if (rc != MVF_OK) return rc;
+                HIP_TRY(ef);
+                return MVF_OK;
+            }
+            (void)hipGetLastError();
+        } else if (c->rank_a.reserve(bytes) == hipSuccess && c->rank_b.reserve(bytes) == hipSuccess &&
+                   c->rank_tmp.reserve(tmp_bytes) == hipSuccess) {
             ra.nqv = nqv;
             break;
+        } else {
+            (void)hipGetLastError();
+            c->rank_a.release();
+            c->rank_b.release();
+            c->rank_tmp.release();
         }
-        (void)hipGetLastError();
-        c->rank_a.release();
-        c->rank_b.release();
-        c->rank_tmp.release();
         if (nqv == 1) {
             *no_room = true;
             return fail(MVF_ERR_DEVICE, "no device memory for the whole-shard sort of a large-k search (16 bytes per row)");
@@ -1623,7 +1643,6 @@ int search_sorted_k(const mvfgpu_corpus* c, uint8_t metric, const void* d_querie
     ra.b = static_cast<uint64_t*>(c->rank_b.p);
     ra.tmp = c->rank_tmp.p;
     ra.tmp_bytes = c->rank_tmp.bytes;
-    ra.k_out = k;
     // the kernel's own list length: nothing is selected, so the smallest the LDS layout takes
     return search_stream_path(c, metric, d_queries, nq, 16, d_scores, d_indices, d_raw, s, /*profile=*/true, nullptr, nullptr, nullptr, 0,
                               0, &ra);

@@ -219,3 +219,19 @@ def test_shardset_with_k_in_the_thousands(oracle, monkeypatch):
     finally:
         for c in shards:
             c.close()
+
+
+def test_buffers_beyond_a_gib_come_from_the_stream_ordered_allocator(oracle):
+    """20M x 16 Int8 rows, two queries (a four-query dump pass): 1.28 GB of composites -- not kept with the handle but taken
+    from hipMallocAsync for the search and given back behind it.  Bit-exact against the oracle over all 20M rows; a second
+    search (the pool hands the block out again) returns the same bits; the handle's scratch stays small."""
+    from _util import oracle_topk_all_rows
+    n, dim, k = 20_000_000, 16, 3000
+    q = oracle.synth_queries(SEED + 1, 2, dim, 2)
+    with G.GpuCorpus.synthetic(n, dim, 2, SEED) as c:
+        before = c.info().device_bytes
+        a = c.search(q, k, G.INNER_PRODUCT)
+        b = c.search(q, k, G.INNER_PRODUCT)
+        assert c.info().device_bytes - before < (64 << 20)
+    assert same(a, b)
+    assert_exact(a, *oracle_topk_all_rows(oracle, SEED, 0, n, dim, 2, 1, q, k))
