@@ -58,6 +58,9 @@ __device__ __forceinline__ void merge_ranked_u64(uint64_t* buf, uint32_t kp, uin
     const uint64_t nv = has_new ? buf[kp + (uint32_t)tid] : 0ull;
     uint32_t orank = (uint32_t)tid, nrank = 0;
     const uint64_t* nb = buf + kp;
+    // (eight broadcast reads in flight: one dependent LDS read per step made a first piece's 64 survivors a 2-us merge -- a
+    // quarter of a 10k-row scan, and four of them in a row on the four-query pass)
+#pragma unroll 8
     for (uint32_t n = 0; n < c; n++) {
         const uint64_t e = nb[n];
         orank += e < ov ? 1u : 0u;
@@ -65,6 +68,7 @@ __device__ __forceinline__ void merge_ranked_u64(uint64_t* buf, uint32_t kp, uin
     }
     if ((uint32_t)(tid & ~63) < c) {  // the waves that hold new elements
         if (kp <= 128u) {
+#pragma unroll 8
             for (uint32_t j = 0; j < kp; j++) nrank += buf[j] < nv ? 1u : 0u;
         } else {
             uint32_t lo = 0, hi = kp;
