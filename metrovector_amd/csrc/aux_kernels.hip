@@ -68,16 +68,6 @@ __global__ void __launch_bounds__(1024) select_final_kernel(SelectParams p) {
     // largest key, and a threshold that lands on one means "everything")
     const uint32_t H = p.nlists * p.heads;
     for (uint32_t i = tid; i < H; i += 1024) buf[i] = lists[(size_t)(i / p.heads) * p.kcap + (i % p.heads)];
-    // The first four entries of "this thread's" list ride along with the heads: the gather below (step 2) walks a list entry by
-    // entry, each a dependent round trip to L2 / HBM at one block per query -- and a small search is made of round trips
-    // (10k x 128: the select 5.5 of 26 us).  Lists that contribute more than four entries read on from memory.
-    uint64_t pre[4] = {kPadComposite, kPadComposite, kPadComposite, kPadComposite};
-    const bool has_pre = (uint32_t)tid < p.nlists && p.kcap >= 4 && (reinterpret_cast<uintptr_t>(lists) & 15u) == 0;
-    if (has_pre) {
-        const ulonglong2* l2 = reinterpret_cast<const ulonglong2*>(lists + (size_t)tid * p.kcap);  // 16-byte aligned: kcap is a power of two >= 4
-        const ulonglong2 a = l2[0], b = l2[1];
-        pre[0] = a.x, pre[1] = a.y, pre[2] = b.x, pre[3] = b.y;
-    }
     if (tid == 0) *cnt = 0, sel_prefix = 0, sel_remaining = p.k;
     __syncthreads();
     uint64_t tau = kPadComposite;
@@ -142,9 +132,8 @@ __global__ void __launch_bounds__(1024) select_final_kernel(SelectParams p) {
     // 2. gather every list's prefix <= tau
     for (uint32_t l = tid; l < p.nlists; l += 1024) {
         const uint64_t* li = lists + (size_t)l * p.kcap;
-        const bool mine = has_pre && l == (uint32_t)tid;
         for (uint32_t i = 0; i < p.kcap; i++) {
-            const uint64_t c = (mine && i < 4) ? (i == 0 ? pre[0] : i == 1 ? pre[1] : i == 2 ? pre[2] : pre[3]) : li[i];
+            const uint64_t c = li[i];
             if (c > tau || c == kPadComposite) break;
             const uint32_t slot = atomicAdd(cnt, 1u);
             if (slot < p.P) buf[slot] = c;
