@@ -1393,7 +1393,23 @@ bool use_batched_path(const mvfgpu_corpus* c, uint8_t metric, uint32_t nq) {
     const bool shadowed = qs_wanted(c) ||  // int8 selection, else the f16 shadow (runs as Float16)
                           (c->dtype == MVF_DTYPE_FLOAT32 && (c->scan_path == 3 || shadow_enabled(c)) && c->shadow_state >= 0 &&
                            (size_t)((c->dim + 7u) & ~7u) * 4 + kBatchCap * 4 <= 64 * 1024);
-    const uint32_t threshold = bytes < (16ull << 20)                          ? 32u
+    // Mid-size corpora, a pass or two of K1 (profiles/r04_small_corpora_crossover.txt, round 4: K1's four-query pass got its
+    // counting merge and batched staging; the batched route costs 70-100 us before its first row): two to four queries stay
+    // on K1 up to 256 MB of float rows (100k x 128 f32: 46 against 95 us; 300k x 128 f16: 101 against 129), up to eight on
+    // <= 64 MB of rows of >= 512 B; Int8 / UInt8 rows of >= 512 B up to eight queries on <= 96 MB and sixteen on <= 32 MB
+    // (30k x 768: 54 against 101 us).
+    if (bytes >= (16ull << 20)) {
+        const uint32_t row_bytes = c->dim * elem_size(c->dtype);
+        if (!is_int_dtype(c->dtype)) {
+            if (shadowed && nq <= 4 && bytes <= (256ull << 20)) return false;
+            if (shadowed && nq <= 8 && bytes <= (64ull << 20) && row_bytes >= 512u) return false;
+        } else if (row_bytes >= 512u) {
+            if (nq <= 8 && bytes <= (96ull << 20)) return false;
+            if (nq <= 16 && bytes <= (32ull << 20)) return false;
+        }
+    }
+    const uint32_t threshold = bytes < (8ull << 20)                           ? 33u  // (32 queries = 8 fused passes: 37-39 us against 73-85)
+                               : bytes < (16ull << 20)                        ? 32u
                                : c->dtype == MVF_DTYPE_FLOAT32 && !shadowed ? (bytes < (1ull << 30) ? 32u : 9u)
                                : is_int_dtype(c->dtype)                     ? (bytes < ((c->pitch <= 256u ? 2ull : 4ull) << 29) ? 5u : 2u)
                                                                             : 2u;
