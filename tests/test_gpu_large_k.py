@@ -235,3 +235,42 @@ def test_buffers_beyond_a_gib_come_from_the_stream_ordered_allocator(oracle):
         assert c.info().device_bytes - before < (64 << 20)
     assert same(a, b)
     assert_exact(a, *oracle_topk_all_rows(oracle, SEED, 0, n, dim, 2, 1, q, k))
+
+
+def test_sharded_searcher_with_k_in_the_thousands_over_rccl(oracle, tmp_path):
+    """One process per GPU (metrovector_amd/sharded.py) at k = 3000 and k = 12 000: the local search by the whole-shard sort, the
+    packed list through a 1-rank nccl (= RCCL) all-gather, the merge in LDS (3000 entries) and by the device-wide sort (12 000 >
+    8192).  Same bits as the plain search; Int8 rows bit-exact against the oracle."""
+    import os
+    import subprocess
+    import sys
+    script = tmp_path / "rank.py"
+    script.write_text('''
+import os, sys, numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, %r)
+from metrovector_amd import gpu as G
+from metrovector_amd.sharded import ShardedSearcher
+from oracle import mvf_oracle as O
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+n, dim, dtype, metric = 30011, 48, 2, 1
+rows = O.synth_rows(777, 0, n, dim, dtype)
+q = O.synth_queries(778, 3, dim, dtype)
+c = G.GpuCorpus.from_array(rows, index_base=5, device=0)
+tq = torch.from_numpy(q.copy()).cuda()
+for k in (3000, 12000):
+    plain = [t.clone() for t in ShardedSearcher(c).search(tq, k, metric)]
+    got = ShardedSearcher(c, always_exchange=True).search(tq, k, metric)
+    torch.cuda.synchronize()
+    for a, b in zip(plain, got):
+        assert torch.equal(a.view(torch.int32) if a.dtype == torch.float32 else a, b.view(torch.int32) if b.dtype == torch.float32 else b), k
+    osc, oidx, oraw = O.search(rows, dtype, metric, q, k, index_base=5)
+    assert (got[1].cpu().numpy().view(np.uint64) == oidx).all() and (got[2].cpu().numpy() == oraw).all(), k
+c.close()
+dist.destroy_process_group()
+print("rccl ok")
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29743", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    out = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    assert "rccl ok" in out.stdout
