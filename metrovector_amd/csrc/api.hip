@@ -465,6 +465,10 @@ int search_stream_path(const mvfgpu_corpus* c, uint8_t metric, const void* d_que
             sp.pmax = pmax;
             sp.chunk_rows = chunk_rows;
             sp.chunk_safe = std::min(scan_chunk_safe(G), chunk_rows);
+            {
+                const uint32_t step = 16u * 64u / (uint32_t)G, want = std::max(k, 64u);
+                sp.first_piece = std::min(sp.chunk_safe, (want + step - 1) / step * step);
+            }
             sp.nchunks = nchunks;
             sp.rank_merge_max = c->tune.k1_rank_merge;
             sp.floor1 = floor1;
@@ -839,6 +843,10 @@ int repair_flagged_queries(const mvfgpu_corpus* c, uint8_t metric, const void* d
         sp.pmax = pmax;
         sp.chunk_rows = chunk_rows;
         sp.chunk_safe = std::min(scan_chunk_safe(G), chunk_rows);
+        {
+            const uint32_t step = 16u * 64u / (uint32_t)G, want = std::max(k, 64u);
+            sp.first_piece = std::min(sp.chunk_safe, (want + step - 1) / step * step);
+        }
         sp.nchunks = nchunks;
         sp.rank_merge_max = c->tune.k1_rank_merge;
         sp.redo_list = redo_list;
@@ -1394,18 +1402,18 @@ bool use_batched_path(const mvfgpu_corpus* c, uint8_t metric, uint32_t nq) {
                           (c->dtype == MVF_DTYPE_FLOAT32 && (c->scan_path == 3 || shadow_enabled(c)) && c->shadow_state >= 0 &&
                            (size_t)((c->dim + 7u) & ~7u) * 4 + kBatchCap * 4 <= 64 * 1024);
     // Mid-size corpora, a pass or two of K1 (profiles/r04_small_corpora_crossover.txt, round 4: K1's four-query pass got its
-    // counting merge and batched staging; the batched route costs 70-100 us before its first row): two to four queries stay
-    // on K1 up to 256 MB of float rows (100k x 128 f32: 46 against 95 us; 300k x 128 f16: 101 against 129), up to eight on
-    // <= 64 MB of rows of >= 512 B; Int8 / UInt8 rows of >= 512 B up to eight queries on <= 96 MB and sixteen on <= 32 MB
-    // (30k x 768: 54 against 101 us).
+    // counting merge, batched staging and a short first piece; the batched route costs 70-100 us before its first row): two to
+    // four queries stay on K1 up to 512 MB of float rows (100k x 128 f32: 41 against 90 us; 300k x 768 f16: 135 against 167),
+    // up to eight on <= 160 MB; Int8 / UInt8 rows up to eight queries on <= 96 MB (<= 256 MB when rows are >= 512 B) and
+    // sixteen on <= 32 MB of such rows (30k x 768: 54 against 97 us).
     if (bytes >= (16ull << 20)) {
         const uint32_t row_bytes = c->dim * elem_size(c->dtype);
         if (!is_int_dtype(c->dtype)) {
-            if (shadowed && nq <= 4 && bytes <= (256ull << 20)) return false;
-            if (shadowed && nq <= 8 && bytes <= (64ull << 20) && row_bytes >= 512u) return false;
-        } else if (row_bytes >= 512u) {
-            if (nq <= 8 && bytes <= (96ull << 20)) return false;
-            if (nq <= 16 && bytes <= (32ull << 20)) return false;
+            if (shadowed && nq <= 4 && bytes <= (512ull << 20)) return false;
+            if (shadowed && nq <= 8 && bytes <= (160ull << 20)) return false;
+        } else {
+            if (nq <= 8 && bytes <= ((row_bytes >= 512u ? 256ull : 96ull) << 20)) return false;
+            if (nq <= 16 && bytes <= (32ull << 20) && row_bytes >= 512u) return false;
         }
     }
     const uint32_t threshold = bytes < (8ull << 20)                           ? 33u  // (32 queries = 8 fused passes: 37-39 us against 73-85)

@@ -30,6 +30,8 @@ struct ScanParams {
     uint32_t pmax;              // next_pow2(k + chunk_safe): LDS buffer entries per query
     uint32_t chunk_rows;        // rows per chunk (blocks take chunks in turn); a multiple of 16*64/G
     uint32_t chunk_safe;        // rows per piece that cannot overflow the buffer (<= chunk_rows)
+    uint32_t first_piece;       // rows per piece while a threshold is still unset (<= chunk_safe; a multiple of 16*64/G, >= k when that fits):
+                                // EVERY row of such a piece is a survivor, so it is kept short enough for the counting merge
     uint32_t nchunks;
     uint32_t rank_merge_max;    // a piece's survivors up to this many join the list by counting (bitonic.h); 0: always the sort network
     // REPAIR launches (api.hip: queries whose K2 candidate budget overflowed are redone exactly, decided ON THE DEVICE):
