@@ -243,6 +243,9 @@ int mvfgpu_corpus_set_vector_ids(mvfgpu_corpus* corpus, const void* ids_le, uint
  * copy engine: the kernels read the query from and write the results into pinned host memory of the handle, the CPU
  * copies to / from the caller's (pageable) buffers -- one query on 10k x 128 f32: 61 -> 33 us per call
  * (profiles/r04_host_api_latency.txt).  MVF_HOST_ZC_QUERY / MVF_HOST_ZC_RESULTS (bytes; 0 = always copy) move the limits.
+ * Such a call (results in place, no payload) does not wait on its stream either: the final select stores a sequence number into
+ * pinned host memory behind its results and the call spins on that word (up to 300 us, then the stream) -- the host learns of a
+ * finished kernel ~5 us sooner that way (profiles/r04_flag_wait.txt; MVF_HOST_FLAG_WAIT=0 waits on the stream).
  */
 int mvfgpu_search(const mvfgpu_corpus* corpus, uint8_t metric,
                   const void* queries, uint8_t query_dtype, uint32_t query_dim,
@@ -432,7 +435,7 @@ int mvfgpu_set_scan_path(mvfgpu_corpus* corpus, int path);
 
 /*
  * The tuning switches of the environment (MVF_K1_G, MVF_K1_RANK_MERGE, MVF_K2_*, MVF_I8_SHADOW, MVF_F16_SHADOW, MVF_QS_REFINE,
- * MVF_STREAM_*, MVF_REPAIR_WINDOW, MVF_UPLOAD_THREADS, MVF_HOST_ZC_*, MVF_DEBUG_REPAIR; INTEGRATION.md lists them) are read ONCE per
+ * MVF_STREAM_*, MVF_REPAIR_WINDOW, MVF_UPLOAD_THREADS, MVF_HOST_ZC_*, MVF_HOST_FLAG_WAIT, MVF_LARGE_K, MVF_DEBUG_REPAIR; INTEGRATION.md lists them) are read ONCE per
  * handle, when it is created: a search never calls getenv.  An A/B script that changes the environment of a live handle
  * calls this to have it read again.
  */
