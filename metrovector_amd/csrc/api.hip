@@ -128,7 +128,7 @@ Tuning read_tuning() {
     t.stream_i8 = flag("MVF_STREAM_I8", false);
     t.stream_shadow = flag("MVF_STREAM_SHADOW", false);
     t.upload_threads = (unsigned)std::max(0l, num("MVF_UPLOAD_THREADS", 0));
-    t.k1_rank_merge = (uint32_t)std::min(256l, std::max(0l, num("MVF_K1_RANK_MERGE", 128)));
+    t.k1_rank_merge = (uint32_t)std::min(256l, std::max(0l, num("MVF_K1_RANK_MERGE", 256)));
     t.host_zc_query = (size_t)std::max(0l, num("MVF_HOST_ZC_QUERY", 64l << 10));
     t.host_zc_results = (size_t)std::max(0l, num("MVF_HOST_ZC_RESULTS", 256l << 10));
     t.large_k = (int)std::min(2l, std::max(0l, num("MVF_LARGE_K", 0)));

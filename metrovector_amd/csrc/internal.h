@@ -46,7 +46,7 @@ struct Tuning {
     bool stream_i8 = false;     // MVF_STREAM_I8=1
     bool stream_shadow = false; // MVF_STREAM_SHADOW=1
     unsigned upload_threads = 0;  // MVF_UPLOAD_THREADS
-    uint32_t k1_rank_merge = 128;  // MVF_K1_RANK_MERGE: a piece's survivors up to this many are merged by counting (0: always sorted; <= 256)
+    uint32_t k1_rank_merge = 256;  // MVF_K1_RANK_MERGE: a piece's survivors up to this many are merged by counting (0: always sorted; <= 256; 128 until the counting loops got eight reads in flight: profiles/r04_k1_merge_ab.txt)
     size_t host_zc_query = 64u << 10;     // MVF_HOST_ZC_QUERY: mvfgpu_search reads queries up to this size in place (pinned host)
     size_t host_zc_results = 256u << 10;  // MVF_HOST_ZC_RESULTS: ... and writes results up to this size in place
     bool host_flag_wait = true; // MVF_HOST_FLAG_WAIT=0: the blocking host call always waits on its stream (not on the flag the final select writes)

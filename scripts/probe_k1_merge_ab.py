@@ -11,10 +11,13 @@ ES = {0: 4, 1: 2, 2: 1, 3: 1}
 SHAPES = [(0, 768), (0, 128), (0, 32), (0, 8), (1, 1024), (1, 64), (1, 16), (2, 768), (2, 128), (2, 64), (2, 32), (3, 256)]
 if len(sys.argv) > 1 and sys.argv[1] == "headline":
     SHAPES = [(0, 768)]
-print("dtype dim row_bytes nq k : sort-network ms -> counting ms (GB/s)  ratio", flush=True)
+# optional: MVF_AB_MODES=a,b (two values of MVF_K1_RANK_MERGE instead of 0,128), MVF_AB_ROWS=n (rows per corpus instead of 4 GiB worth)
+MA, MB = (os.environ.get("MVF_AB_MODES") or "0,128").split(",")
+ROWS = int(os.environ.get("MVF_AB_ROWS") or 0)
+print(f"dtype dim row_bytes nq k : MVF_K1_RANK_MERGE={MA} ms -> ={MB} ms (GB/s)  ratio", flush=True)
 for dt, dim in SHAPES:
     rb = dim * ES[dt]
-    n = 10_000_000 if (dt, dim) == (0, 768) else min(100_000_000, (4 << 30) // rb)
+    n = ROWS or (10_000_000 if (dt, dim) == (0, 768) else min(100_000_000, (4 << 30) // rb))
     c = G.GpuCorpus.synthetic(n, dim, dt, 0x4D564631)
     c.set_scan_path(1)
     tdt = torch.float32 if dt in (0, 1) else (torch.int8 if dt == 2 else torch.uint8)
@@ -26,7 +29,7 @@ for dt, dim in SHAPES:
             di = torch.empty((nq, k), dtype=torch.int64, device="cuda:0")
             out = {}
             ref = None
-            for mode in ("0", "128", "0", "128"):
+            for mode in (MA, MB, MA, MB):
                 os.environ["MVF_K1_RANK_MERGE"] = mode
                 c.reload_tuning()
                 best = 1e9
@@ -41,7 +44,7 @@ for dt, dim in SHAPES:
                     ref = cur
                 elif not (torch.equal(ref[0].view(torch.int32), cur[0].view(torch.int32)) and torch.equal(ref[1], cur[1])):
                     print("  RESULTS DIFFER", dt, dim, nq, k, flush=True)
-            gbs = n * rb / out["128"] / 1e6
-            print(f"{dt} {dim:5d} {rb:5d} nq={nq} k={k:3d}: {out['0']:8.3f} -> {out['128']:8.3f} ms ({gbs:7.1f} GB/s)  {out['0'] / out['128']:.3f}", flush=True)
+            gbs = n * rb / out[MB] / 1e6
+            print(f"{dt} {dim:5d} {rb:5d} nq={nq} k={k:3d}: {out[MA]:8.3f} -> {out[MB]:8.3f} ms ({gbs:7.1f} GB/s)  {out[MA] / out[MB]:.3f}", flush=True)
     c.close()
 os.environ.pop("MVF_K1_RANK_MERGE", None)
