@@ -76,7 +76,8 @@ hipError_t launch_merge_write(const ShardMergeParams& p, uint32_t q, const uint6
 // result row of a query from the ascending composites of ALL its rows (sort_topk.hip); reads metric, dtype, index_base, ids,
 // out_*, k of `p`; the row starts at element out_base of the output arrays
 hipError_t launch_write_sorted(const SelectParams& p, const uint64_t* sorted, uint32_t n, size_t out_base, hipStream_t s);
-// device-wide ascending sort of n u64 composites (rocPRIM radix sort over all 64 bits, stream-ordered, no host wait).
+// device-wide sort of n rank entries (mvf_common.h: position << 32 | key) that arrive in ascending position: a stable rocPRIM radix
+// sort of the key half = the order of the composites (key << 32 | position); stream-ordered, no host wait.
 // tmp == NULL: only *tmp_bytes is written.  The sorted keys end up in `a` or `b` (the other is scratch): *sorted says which.
 hipError_t sort_composites(void* tmp, size_t* tmp_bytes, uint64_t* a, uint64_t* b, size_t n, uint64_t** sorted, hipStream_t s);
 hipError_t launch_synth_rows(unsigned char* rows, uint64_t n, uint32_t dim, uint32_t pitch, uint8_t dtype,

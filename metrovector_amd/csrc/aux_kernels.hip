@@ -225,13 +225,13 @@ __global__ void __launch_bounds__(1024) select_final_kernel(SelectParams p) {
     }
 }
 
-// The tail of a search that ranked the WHOLE shard (api.hip: search_sorted_k): `sorted` holds the n composites of one query in
-// ascending order (deleted rows as the padding value, hence last); the first k become the query's result row at
+// The tail of a search that ranked the WHOLE shard (api.hip: search_sorted_k): `sorted` holds the n rank entries of one query in
+// result order (deleted rows dead, hence last); the first k become the query's result row at
 // out[out_base ...], entries beyond the rows that exist the padding result.  Only metric / dtype / index_base / ids / out_* / k
 // of the parameter block are read.
 __global__ void __launch_bounds__(256) write_sorted_kernel(SelectParams p, const uint64_t* sorted, uint32_t n, size_t out_base) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < p.k; i += (size_t)gridDim.x * 256)
-        write_result(i < n ? sorted[i] : kPadComposite, out_base + i, p);
+        write_result(i < n ? composite_of_rank_entry(sorted[i]) : kPadComposite, out_base + i, p);
 }
 
 // The K2 compactions flag queries whose candidate budget overflowed (overflow[q] != 0).  One block turns the flags into
@@ -303,20 +303,18 @@ __global__ void __launch_bounds__(256) merge_build_kernel(ShardMergeParams p, ui
     const bool use_raw = key_is_raw(p.dtype, p.metric) && p.raw != nullptr;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
         const size_t l = i / p.k, j = i % p.k, rem = (size_t)q * p.k + j;
-        uint64_t comp = kPadComposite;
-        if (p.indices[l * p.ls_indices + rem] != ~0ull) {
-            const uint32_t ky = use_raw ? key_from_raw(p.raw[l * p.ls_raw + rem], p.metric)
-                                        : key_from_score(p.scores[l * p.ls_scores + rem], p.metric);
-            comp = ((uint64_t)ky << 32) | (uint32_t)i;
-        }
-        comps[i] = comp;
+        uint32_t ky = 0;
+        const bool live = p.indices[l * p.ls_indices + rem] != ~0ull;
+        if (live)
+            ky = use_raw ? key_from_raw(p.raw[l * p.ls_raw + rem], p.metric) : key_from_score(p.scores[l * p.ls_scores + rem], p.metric);
+        comps[i] = rank_entry(ky, (uint32_t)i, !live);
     }
 }
 
 __global__ void __launch_bounds__(256) merge_write_kernel(ShardMergeParams p, uint32_t q, const uint64_t* sorted) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < p.k; i += (size_t)gridDim.x * 256) {
         const size_t o = (size_t)q * p.k + i;
-        const uint64_t comp = sorted[i];  // nlists * k >= k entries
+        const uint64_t comp = composite_of_rank_entry(sorted[i]);  // nlists * k >= k entries
         if (comp == kPadComposite) {
             p.out_scores[o] = pad_score(p.metric);
             p.out_indices[o] = ~0ull;

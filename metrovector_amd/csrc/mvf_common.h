@@ -84,6 +84,24 @@ MVF_HD int32_t raw_from_key(uint32_t k, uint8_t metric) {
     return (int32_t)(u ^ 0x80000000u);
 }
 
+// Entries of the device-wide sorts (sort_topk.hip): (position << 32 | key'), sorted on the KEY half only -- the radix sort is
+// stable and the entries are produced in ascending position, so equal keys keep the position order: the order of the
+// composites (key << 32 | position) at half the digit passes.  (Not bits 32..63 of the composite itself: rocPRIM's small-input
+// path builds its bit-range mask as (1 << (begin + bits)) - 1, which is undefined for begin + bits = 64 and compares the LOW
+// word there.)  key' tells what the composite's low word did: a dead entry (deleted row, padding) is 0xFFFFFFFF and sorts last,
+// a live NaN score -- kNanKey = 0xFFFFFFFF in a composite -- becomes 0xFFFFFFFE, a value no score and no exact integer maps to
+// (float keys end at 0xFF800000 = +inf; |raw| < 2^31 - 2^16 by MVFGPU_MAX_INT_DIM).
+MVF_HD uint64_t rank_entry(uint32_t key, uint32_t pos, bool dead) {
+    const uint32_t kq = dead ? 0xFFFFFFFFu : (key == kNanKey ? 0xFFFFFFFEu : key);
+    return ((uint64_t)pos << 32) | kq;
+}
+
+MVF_HD uint64_t composite_of_rank_entry(uint64_t e) {
+    const uint32_t kq = (uint32_t)e;
+    if (kq == 0xFFFFFFFFu) return kPadComposite;
+    return ((uint64_t)(kq == 0xFFFFFFFEu ? kNanKey : kq) << 32) | (uint32_t)(e >> 32);
+}
+
 MVF_HD float pad_score(uint8_t metric) {
     return metric == MVF_METRIC_L2 ? bits_f32(0x7F800000u) : bits_f32(0xFF800000u);
 }

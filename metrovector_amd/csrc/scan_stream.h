@@ -45,8 +45,8 @@ struct ScanParams {
     // floor1[query] = that composite + 1 (0: no floor; ~0: the rows are exhausted, nothing may pass); NULL = none.
     const uint64_t* floor1;
     // k beyond what passes are worth (api.hip: search_sorted_k): the floor instantiation run as a DUMP -- no threshold, no
-    // candidates; the composite of every row of query q0 + q goes to dump[q * n + row] (~0 for a deleted row) and a
-    // device-wide sort of the n composites ranks the whole shard.  NULL = none.
+    // candidates; the rank entry (mvf_common.h) of every row of query q0 + q goes to dump[q * n + row] (a deleted row marked
+    // dead) and a device-wide sort of the n entries ranks the whole shard.  NULL = none.
     uint64_t* dump;
 };
 

@@ -136,6 +136,23 @@ def test_nan_scores_rank_behind_every_number_and_in_front_of_the_padding(oracle,
     assert np.isnan(got.scores[0, n - 40:n]).all() and sorted(got.indices[0, n - 40:n].tolist()) == sorted(bad.tolist())
     assert (got.indices[0, n - 40:n] == np.sort(bad).astype(np.uint64)).all()      # ties (all NaN) by row position
     assert (got.indices[0, n:] == PAD).all() and (got.scores[0, n:] == np.inf).all()
+    # ... and with deletions in between (dead rows and NaN rows must not tie: the sort orders by key only)
+    dead = np.zeros(n, bool)
+    dead[rng.choice(n, 1500, replace=False)] = True
+    dead[bad[:10]] = True
+    live_bad = np.sort(np.setdiff1d(bad, np.nonzero(dead)[0]))
+    nlive = int((~dead).sum())
+    with G.GpuCorpus.from_array(rows) as c:
+        c.set_tombstones(np.packbits(dead, bitorder="little"))
+        forced(c, monkeypatch, 2)
+        got = c.search(q, k, G.L2)
+        forced(c, monkeypatch, 1)
+        by_passes = c.search(q, k, G.L2)
+    assert same(got, by_passes)
+    nb = len(live_bad)
+    assert np.isfinite(got.scores[0, :nlive - nb]).all() and not dead[got.indices[0, :nlive].astype(np.int64)].any()
+    assert (got.indices[0, nlive - nb:nlive] == live_bad.astype(np.uint64)).all() and np.isnan(got.scores[0, nlive - nb:nlive]).all()
+    assert (got.indices[0, nlive:] == PAD).all()
 
 
 def test_a_search_after_the_sort_path_is_unchanged(oracle, monkeypatch):
