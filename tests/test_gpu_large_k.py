@@ -291,3 +291,19 @@ print("rccl ok")
     out = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=600, env=env)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
     assert "rccl ok" in out.stdout
+
+
+def test_whole_shard_sort_of_a_hundred_million_rows(oracle, monkeypatch):
+    """n = 100M (16-byte Int8 rows): the sort's scratch for a four-query pass is 6.4 GB from the stream-ordered allocator, the
+    radix sort runs on 10^8 entries per query.  Sort and passes must agree at k = 16384; k = 50 000 continues the same list."""
+    n, dim = 100_000_000, 16
+    q = oracle.synth_queries(SEED + 1, 2, dim, 2)
+    with G.GpuCorpus.synthetic(n, dim, 2, SEED) as c:
+        forced(c, monkeypatch, 2)
+        a = c.search(q, 16384, G.INNER_PRODUCT)
+        big = c.search(q[0], 50_000, G.INNER_PRODUCT)
+        forced(c, monkeypatch, 1)
+        b = c.search(q, 16384, G.INNER_PRODUCT)
+    assert same(a, b)
+    assert (big.indices[0, :16384] == a.indices[0]).all() and (big.raw[0, :16384] == a.raw[0]).all()
+    assert (np.diff(big.raw[0].astype(np.int64)) <= 0).all() and len(set(big.indices[0].tolist())) == 50_000
