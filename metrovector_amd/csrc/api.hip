@@ -132,6 +132,7 @@ Tuning read_tuning() {
     t.host_zc_query = (size_t)std::max(0l, num("MVF_HOST_ZC_QUERY", 64l << 10));
     t.host_zc_results = (size_t)std::max(0l, num("MVF_HOST_ZC_RESULTS", 256l << 10));
     t.large_k = (int)std::min(2l, std::max(0l, num("MVF_LARGE_K", 0)));
+    t.k1_first_piece = flag("MVF_K1_FIRST_PIECE", true);
     t.host_flag_wait = flag("MVF_HOST_FLAG_WAIT", true);
     return t;
 }
@@ -467,7 +468,10 @@ int search_stream_path(const mvfgpu_corpus* c, uint8_t metric, const void* d_que
             sp.chunk_safe = std::min(scan_chunk_safe(G), chunk_rows);
             {
                 const uint32_t step = 16u * 64u / (uint32_t)G, want = std::max(k, 64u);
-                sp.first_piece = std::min(sp.chunk_safe, (want + step - 1) / step * step);
+                // (not under the long chunks of short rows: a threshold from 128 rows lets too many of the next 4000 through --
+                // 4 GB of <= 128-byte rows at k = 100 lost 5-8 %, profiles/r04_k1_first_piece_ab.txt)
+                sp.first_piece = (c->tune.k1_first_piece && chunk_rows <= scan_chunk_safe(G)) ? std::min(sp.chunk_safe, (want + step - 1) / step * step)
+                                                                                             : sp.chunk_safe;
             }
             sp.nchunks = nchunks;
             sp.rank_merge_max = c->tune.k1_rank_merge;
@@ -845,7 +849,8 @@ int repair_flagged_queries(const mvfgpu_corpus* c, uint8_t metric, const void* d
         sp.chunk_safe = std::min(scan_chunk_safe(G), chunk_rows);
         {
             const uint32_t step = 16u * 64u / (uint32_t)G, want = std::max(k, 64u);
-            sp.first_piece = std::min(sp.chunk_safe, (want + step - 1) / step * step);
+            sp.first_piece = (c->tune.k1_first_piece && chunk_rows <= scan_chunk_safe(G)) ? std::min(sp.chunk_safe, (want + step - 1) / step * step)
+                                                                                         : sp.chunk_safe;
         }
         sp.nchunks = nchunks;
         sp.rank_merge_max = c->tune.k1_rank_merge;

@@ -50,6 +50,7 @@ struct Tuning {
     size_t host_zc_query = 64u << 10;     // MVF_HOST_ZC_QUERY: mvfgpu_search reads queries up to this size in place (pinned host)
     size_t host_zc_results = 256u << 10;  // MVF_HOST_ZC_RESULTS: ... and writes results up to this size in place
     bool host_flag_wait = true; // MVF_HOST_FLAG_WAIT=0: the blocking host call always waits on its stream (not on the flag the final select writes)
+    bool k1_first_piece = true; // MVF_K1_FIRST_PIECE=0: pieces of chunk_safe rows while a threshold is unset (as before round 4's short first piece)
     int large_k = 0;            // MVF_LARGE_K=1|2: k beyond one pass always by passes (1; k <= 16384) / always by the whole-shard sort (2); 0: the cheaper one
 };
 Tuning read_tuning();

@@ -13,8 +13,9 @@ if len(sys.argv) > 1 and sys.argv[1] == "headline":
     SHAPES = [(0, 768)]
 # optional: MVF_AB_MODES=a,b (two values of MVF_K1_RANK_MERGE instead of 0,128), MVF_AB_ROWS=n (rows per corpus instead of 4 GiB worth)
 MA, MB = (os.environ.get("MVF_AB_MODES") or "0,128").split(",")
+VAR = os.environ.get("MVF_AB_VAR") or "MVF_K1_RANK_MERGE"  # the switch the two modes are values of
 ROWS = int(os.environ.get("MVF_AB_ROWS") or 0)
-print(f"dtype dim row_bytes nq k : MVF_K1_RANK_MERGE={MA} ms -> ={MB} ms (GB/s)  ratio", flush=True)
+print(f"dtype dim row_bytes nq k : {VAR}={MA} ms -> ={MB} ms (GB/s)  ratio", flush=True)
 for dt, dim in SHAPES:
     rb = dim * ES[dt]
     n = ROWS or (10_000_000 if (dt, dim) == (0, 768) else min(100_000_000, (4 << 30) // rb))
@@ -30,7 +31,7 @@ for dt, dim in SHAPES:
             out = {}
             ref = None
             for mode in (MA, MB, MA, MB):
-                os.environ["MVF_K1_RANK_MERGE"] = mode
+                os.environ[VAR] = mode
                 c.reload_tuning()
                 best = 1e9
                 for _ in range(3):
@@ -47,4 +48,4 @@ for dt, dim in SHAPES:
             gbs = n * rb / out[MB] / 1e6
             print(f"{dt} {dim:5d} {rb:5d} nq={nq} k={k:3d}: {out[MA]:8.3f} -> {out[MB]:8.3f} ms ({gbs:7.1f} GB/s)  {out[MA] / out[MB]:.3f}", flush=True)
     c.close()
-os.environ.pop("MVF_K1_RANK_MERGE", None)
+os.environ.pop(VAR, None)
