@@ -348,6 +348,8 @@ struct HostFlagReq {
     uint32_t seq;
     bool armed;
     uint64_t gen;  // the handle's work_gen of this search
+    unsigned char* gather_out;  // mvfgpu_search_fetch: the final select copies the payload rows here too (pinned host memory); NULL = none
+    bool gathered;              // ... and did, for every query
 };
 thread_local HostFlagReq* t_flag_req = nullptr;
 
@@ -538,6 +540,13 @@ int search_stream_path(const mvfgpu_corpus* c, uint8_t metric, const void* d_que
                 fp.out_stride = out_stride;
                 fp.out_offset = out_offset;
                 fp.out_floor1 = out_floor1 ? out_floor1 + q0 : nullptr;
+                if (t_flag_req && !out_floor1 && t_flag_req->gather_out && !c->ids.p) {  // payload rows behind the results, by the same block
+                    fp.gather_rows = c->d_rows;
+                    fp.gather_out = t_flag_req->gather_out + (size_t)q0 * ostride * (c->dim * elem_size(c->dtype));
+                    fp.gather_pitch = c->pitch;
+                    fp.gather_row_bytes = c->dim * elem_size(c->dtype);
+                    if (q0 + nq_here == nq) t_flag_req->gathered = true;
+                }
                 if (t_flag_req && !out_floor1 && q0 + nq_here == nq) {  // the search's last kernel
                     fp.done_flag = t_flag_req->flag;
                     fp.done_ticket = t_flag_req->ticket;
@@ -2197,7 +2206,7 @@ int search_host(const mvfgpu_corpus* c, uint8_t metric, const void* queries, uin
         }
     }
     HostFlagReq req{};
-    if (zc_out && !out_vectors && c->tune.host_flag_wait) {
+    if (zc_out && c->tune.host_flag_wait && (!out_vectors || (fused_fetch && zc_vec))) {
         std::lock_guard<std::mutex> lk(c->mu);
         if (!c->pin_flag.p) {
             HIP_TRY(c->pin_flag.reserve(64));
@@ -2209,14 +2218,15 @@ int search_host(const mvfgpu_corpus* c, uint8_t metric, const void* queries, uin
         req.ticket = static_cast<uint32_t*>(c->done_ticket.p);
         req.seq = ++c->flag_seq;
         if (req.seq == 0) req.seq = ++c->flag_seq;
+        req.gather_out = out_vectors ? static_cast<unsigned char*>(dv) : nullptr;  // the select copies the payload rows as well
         t_flag_req = &req;
     }
     rc = mvfgpu_search_device(c, metric, dq, query_dtype, query_dim, nq, k, static_cast<float*>(ds),
                               static_cast<uint64_t*>(di), static_cast<int32_t*>(dr), c->own_stream);
     t_flag_req = nullptr;
     if (rc != MVF_OK) return rc;
-    if (req.armed) {
-        // the final select writes req.seq behind its results: spin on it (bounded: a long search falls back to the stream)
+    if (req.armed && (!out_vectors || req.gathered)) {
+        // the final select writes req.seq behind its results (and the payload rows it copied): spin on it (bounded: a long search falls back to the stream)
         const auto t0 = std::chrono::steady_clock::now();
         bool seen = false;
         for (uint32_t spins = 0;; spins++) {
@@ -2235,6 +2245,7 @@ int search_host(const mvfgpu_corpus* c, uint8_t metric, const void* queries, uin
         memcpy(out_scores, ds, nres * 4);
         memcpy(out_indices, di, nres * 8);
         if (out_raw) memcpy(out_raw, dr, nres * 4);
+        if (out_vectors) memcpy(out_vectors, dv, vec_bytes);
         return MVF_OK;
     }
     if (fused_fetch)  // padding entries (index UINT64_MAX) give zero rows

@@ -49,6 +49,13 @@ struct SelectParams {
     uint32_t* done_flag;
     uint32_t* done_ticket;
     uint32_t done_seq;
+    // the payload rows of the results (mvfgpu_search_fetch on small results: the reference's ScoredVector.vector): the block
+    // copies its query's k rows rows[local row * pitch .. + row_bytes) to gather_out[(query * stride + offset + rank) *
+    // row_bytes ..) behind the results -- no third kernel, and the host waits on the flag.  Padding results give zero rows.
+    // NULL = none.
+    const unsigned char* gather_rows;
+    unsigned char* gather_out;
+    uint32_t gather_pitch, gather_row_bytes;
 };
 
 // queries flagged by the K2 compactions -> a dense list + its length, flags cleared (one block)

@@ -210,6 +210,22 @@ __global__ void __launch_bounds__(1024) select_final_kernel(SelectParams p) {
     const uint32_t stride = p.out_stride ? p.out_stride : p.k;
     for (uint32_t i = tid; i < p.k; i += 1024) write_result(i < m ? buf[i] : kPadComposite, (size_t)qout * stride + p.out_offset + i, p);
     if (p.out_floor1 && tid == 0) p.out_floor1[qout] = m >= p.k ? buf[p.k - 1] + 1ull : ~0ull;
+    if (p.gather_out) {  // block-uniform: the k rows behind the k results (buf[0 .. m) is the sorted list; one wave per row)
+        const uint32_t lane = (uint32_t)tid & 63u, wave = (uint32_t)tid >> 6;
+        const uint32_t rb = p.gather_row_bytes;
+        const bool wide = ((rb | (uint32_t)reinterpret_cast<uintptr_t>(p.gather_out)) & 15u) == 0;  // stored rows start on 16-byte pitches
+        for (uint32_t i = wave; i < p.k; i += 16) {
+            const bool ok = i < m;
+            const unsigned char* src = p.gather_rows + (size_t)(ok ? (uint32_t)buf[i] : 0u) * p.gather_pitch;
+            unsigned char* dst = p.gather_out + ((size_t)qout * stride + p.out_offset + i) * rb;
+            if (wide) {
+                for (uint32_t b = lane; b < rb / 16; b += 64)
+                    reinterpret_cast<uint4*>(dst)[b] = ok ? reinterpret_cast<const uint4*>(src)[b] : uint4{0, 0, 0, 0};
+            } else {
+                for (uint32_t b = lane; b < rb; b += 64) dst[b] = ok ? src[b] : (unsigned char)0;
+            }
+        }
+    }
     if (p.done_flag) {  // block-uniform: tell the waiting host call (results in pinned host memory) that everything is there
         __threadfence_system();
         __syncthreads();

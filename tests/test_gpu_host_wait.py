@@ -88,3 +88,29 @@ def test_threads_sharing_a_handle_and_device_searches_in_between(oracle):
         for t in ts:
             t.join()
     assert not bad, bad[:5]
+
+
+@pytest.mark.parametrize("dtype,dim", [(0, 128), (1, 100), (2, 64), (3, 33)])
+def test_search_fetch_rows_copied_by_the_final_select(oracle, monkeypatch, dtype, dim):
+    """mvfgpu_search_fetch on small results: the final select copies the k payload rows behind the results (no third kernel)
+    and the call waits on the flag.  Same results and rows as the three-kernel path (MVF_HOST_FLAG_WAIT=0); the rows ARE the
+    corpus' rows; padding results (k beyond the rows) come with zero rows; row sizes that are no multiple of 16 / 4 bytes."""
+    n = 3000
+    rows = oracle.synth_rows(SEED, 0, n, dim, dtype)
+    q = oracle.synth_queries(SEED + 1, 5, dim, dtype)
+    with G.GpuCorpus.from_array(rows, index_base=40) as c:
+        for nq, k in ((1, 10), (1, 1), (4, 7), (5, 100)):
+            monkeypatch.setenv("MVF_HOST_FLAG_WAIT", "1")
+            c.reload_tuning()
+            res, vec = c.search_fetch(q[:nq], k, G.L2)
+            monkeypatch.setenv("MVF_HOST_FLAG_WAIT", "0")
+            c.reload_tuning()
+            res0, vec0 = c.search_fetch(q[:nq], k, G.L2)
+            assert same(res, res0) and (vec.view(np.uint8) == vec0.view(np.uint8)).all()
+            li = (res.indices - np.uint64(40)).astype(np.int64)
+            assert (vec.view(np.uint8) == rows[li].view(np.uint8)).all()
+            assert same(res, c.search(q[:nq], k, G.L2))
+    with G.GpuCorpus.from_array(rows[:6]) as c:           # k beyond the rows: padding results carry zero rows
+        res, vec = c.search_fetch(q[0], 9, G.L2)
+        assert (res.indices[0, 6:] == np.uint64(0xFFFFFFFFFFFFFFFF)).all() and not vec[0, 6:].view(np.uint8).any()
+        assert (vec[0, :6].view(np.uint8) == rows[:6][res.indices[0, :6].astype(np.int64)].view(np.uint8)).all()
