@@ -155,6 +155,8 @@ struct mvfgpu_corpus {
     mutable DevBuf blk;                   // K2 narrow types: per-block candidate regions + their counts (scan_mfma.h)
     mutable DevBuf repair;                // K2 overflow repair: gathered queries + their results
     mutable std::vector<std::pair<uint64_t, int>> occ_cache;  // (kernel, dynamic LDS) -> blocks per CU (scan_occupancy)
+    mutable const unsigned char* bq_zeros = nullptr;  // where the prepared-query buffer's 64 zero bytes were last set ...
+    mutable size_t bq_zero_bytes = 0;                 // ... and the buffer's size then
     mutable DevBuf floor1;                // k > MVFGPU_K_PER_PASS: per query, the last composite the pass before returned, + 1
     mutable DevBuf rank_a, rank_b, rank_tmp;  // k > MVFGPU_K_PER_PASS by the whole-shard sort: the composites of every row (x the queries of a pass), twice, + the sort's scratch
     mutable DevBuf shadow, xscale;        // Float32 corpora: scaled-f16 shadow rows (selection only) + 2^-s_r per row
@@ -941,7 +943,11 @@ int search_batched_path(const mvfgpu_corpus* c, uint8_t metric, const void* d_qu
     float* qaux1 = qaux0 + nq_pad;
     unsigned char* zeros = reinterpret_cast<unsigned char*>(qaux1 + nq_pad);  // 64 zero bytes
     float* qdelta = reinterpret_cast<float*>(zeros + 64);                       // [nq_pad] int8-shadow selection: bound per query
-    HIP_TRY(hipMemsetAsync(zeros, 0, 64, s));
+    if (c->bq_zeros != zeros || c->bq_zero_bytes != c->bq.bytes) {  // nothing in this path writes them: set once per allocation and layout, not
+        HIP_TRY(hipMemsetAsync(zeros, 0, 64, s));                      // once per search (a fill kernel is 4.8 us); the streaming paths, which lay
+        c->bq_zeros = zeros;                                            // the buffer out differently, forget the mark
+        c->bq_zero_bytes = c->bq.bytes;
+    }
     {
         int rc = ensure_bstate(c, nq_pad, s);
         if (rc != MVF_OK) return rc;
@@ -1229,6 +1235,7 @@ int search_stream_shadow_path(const mvfgpu_corpus* c, uint8_t metric, const void
     // |q| per query for the margins: the f16 query preparation computes it (its planes are not used here)
     const uint32_t KPB = ((c->dim * 2u + 63u) / 64u) * 64u;
     HIP_TRY(c->bq.reserve((size_t)nq_pad * KPB + (size_t)nq_pad * 8 + 64));
+    c->bq_zeros = nullptr;  // another layout of the buffer: the batched path's zero bytes may be overwritten
     unsigned char* qprep = static_cast<unsigned char*>(c->bq.p);
     float* qaux0 = reinterpret_cast<float*>(qprep + (size_t)nq_pad * KPB);
     float* qaux1 = qaux0 + nq_pad;
@@ -1313,6 +1320,7 @@ int search_stream_qs_path(const mvfgpu_corpus* c, uint8_t metric, const void* d_
     HIP_TRY(c->bcand.reserve((size_t)nq_pad * cap * 8));
     const uint32_t KPB = shadow8_pitch(c->dim);
     HIP_TRY(c->bq.reserve((size_t)nq_pad * KPB + (size_t)nq_pad * 12 + 64));
+    c->bq_zeros = nullptr;  // another layout of the buffer: the batched path's zero bytes may be overwritten
     unsigned char* qprep = static_cast<unsigned char*>(c->bq.p);
     float* qaux0 = reinterpret_cast<float*>(qprep + (size_t)nq_pad * KPB);
     float* qaux1 = qaux0 + nq_pad;
