@@ -461,6 +461,16 @@ uint32_t mvfgpu_abi_version(void);
  */
 int mvfgpu_selftest_feedback(const uint32_t* samples, uint32_t n_samples, uint32_t* out_state);
 
+/*
+ * Self-test of the route a search takes (no GPU needed): which kernels serve `nq` queries for `k` results on a corpus of
+ * `rows` x `dimension` of `data_type` under the default tuning, scan path 0 and no history -- a function of these numbers
+ * alone (the thresholds come from the measured crossover tables under profiles/).
+ * *out_route: 0 = the streaming kernel K1 (one pass per 1..4 queries), 1 = the batched MFMA route; for k >
+ * MVFGPU_K_PER_PASS: 2 = passes of K1 behind a floor, 3 = K1 as a dump + the whole-shard sort.
+ */
+int mvfgpu_selftest_route(uint64_t rows, uint32_t dimension, uint8_t data_type, uint8_t metric, uint32_t nq, uint32_t k,
+                          uint32_t* out_route);
+
 #ifdef __cplusplus
 }
 #endif

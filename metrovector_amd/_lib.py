@@ -124,6 +124,7 @@ def gpu() -> C.CDLL:
     lib.mvfgpu_set_scan_path.argtypes = [vp, i32]
     lib.mvfgpu_corpus_reload_tuning.argtypes = [vp]
     lib.mvfgpu_selftest_feedback.argtypes = [vp, u32, vp]
+    lib.mvfgpu_selftest_route.argtypes = [u64, u32, u8, u8, u32, u32, vp]
     lib.mvfgpu_abi_version.restype = u32
     lib.mvfgpu_abi_version.argtypes = []
     if lib.mvfgpu_abi_version() != ABI_VERSION:
@@ -136,7 +137,7 @@ def gpu() -> C.CDLL:
                  "mvfgpu_merge_topk_host", "mvfgpu_merge_topk_device", "mvfgpu_merge_topk_packed_device",
                  "mvfgpu_synth_queries_device",
                  "mvfgpu_set_profiling", "mvfgpu_last_timing", "mvfgpu_set_scan_path", "mvfgpu_corpus_reload_tuning",
-                 "mvfgpu_selftest_feedback"):
+                 "mvfgpu_selftest_feedback", "mvfgpu_selftest_route"):
         getattr(lib, name).restype = C.c_int
     _gpu = lib
     return lib

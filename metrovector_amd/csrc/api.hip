@@ -17,6 +17,7 @@
 #include <cstdio>
 #include <cstring>
 #include <chrono>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -2511,6 +2512,25 @@ int mvfgpu_selftest_feedback(const uint32_t* samples, uint32_t n_samples, uint32
     out_state[1] = redone;
     out_state[2] = bias_off;
     out_state[3] = qs_off;
+    return MVF_OK;
+}
+
+int mvfgpu_selftest_route(uint64_t rows, uint32_t dimension, uint8_t data_type, uint8_t metric, uint32_t nq, uint32_t k, uint32_t* out_route) {
+    if (!out_route) return fail(MVF_ERR_INVALID_ARGUMENT, "NULL buffer");
+    if (elem_size(data_type) == 0 || dimension == 0 || nq == 0 || k == 0 || k > MVFGPU_MAX_K)
+        return fail(MVF_ERR_INVALID_ARGUMENT, "unsupported type or empty dimension / batch / k");
+    if (metric != MVF_METRIC_L2 && metric != MVF_METRIC_INNER_PRODUCT && metric != MVF_METRIC_COSINE)
+        return fail(MVF_ERR_INVALID_ARGUMENT, "unsupported distance metric code");
+    // a handle that owns nothing on a device: the route is a function of these fields and the DEFAULT tuning (not the environment)
+    std::unique_ptr<mvfgpu_corpus> c(new mvfgpu_corpus());
+    c->n = rows;
+    c->dim = dimension;
+    c->dtype = data_type;
+    c->pitch = (dimension * elem_size(data_type) + 15u) & ~15u;
+    c->V = c->pitch / 16;
+    c->tune = Tuning{};
+    if (k > MVFGPU_K_PER_PASS) *out_route = large_k_by_sort(c.get(), nq, k) ? 3u : 2u;
+    else *out_route = use_batched_path(c.get(), metric, nq) ? 1u : 0u;
     return MVF_OK;
 }
 

@@ -174,3 +174,51 @@ def test_search_entry_points_refuse_null_arguments_before_touching_a_device():
     assert lib.mvfgpu_corpus_gather_rows(None, idx, 4, buf) == rc
     with pytest.raises(E.InvalidArgument):
         _lib.gpu_check(rc)
+
+
+def _route(rows, dim, dtype, metric, nq, k):
+    out = C.c_uint32(99)
+    _lib.gpu_check(_lib.gpu().mvfgpu_selftest_route(rows, dim, dtype, metric, nq, k, C.byref(out)))
+    return out.value
+
+
+def test_the_route_of_a_search_is_a_function_of_its_shape():
+    """Which kernels serve a search (no GPU): 0 = the streaming kernel K1, 1 = the batched MFMA route, 2 = passes of K1 behind a
+    floor (k > 1024), 3 = K1 as a dump + the whole-shard sort.  The BASELINE configs, the measured crossovers of
+    profiles/r04_small_corpora_crossover.txt and profiles/r04_any_k.txt -- a change of a threshold has to show up here."""
+    K1, K2, PASSES, SORT = 0, 1, 2, 3
+    F32, F16, I8, U8 = 0, 1, 2, 3
+    L2, IP, COS = 0, 1, 2
+    # BASELINE.json configs
+    assert _route(10_000, 128, F32, L2, 1, 10) == K1                 # configs[0]
+    assert _route(10_000_000, 768, F32, COS, 1, 100) == K1           # configs[1]: the headline
+    assert _route(10_000_000, 768, F32, COS, 1024, 100) == K2        # configs[2]
+    assert _route(50_000_000, 768, I8, IP, 256, 100) == K2           # configs[3]
+    assert _route(12_500_000, 1024, F16, L2, 1024, 100) == K2        # a shard of configs[4]
+    # small batches: K1 takes four queries per pass, the batched route costs 70-100 us before its first row
+    assert [_route(10_000, 128, F32, L2, nq, 10) for nq in (4, 16, 32, 33)] == [K1, K1, K1, K2]          # < 8 MiB: up to 32 queries
+    assert [_route(30_000, 128, F32, L2, nq, 10) for nq in (16, 31, 32)] == [K1, K1, K2]                 # < 16 MiB: up to 31
+    assert [_route(100_000, 128, F32, L2, nq, 10) for nq in (2, 4, 8, 9, 16)] == [K1, K1, K1, K2, K2]    # 51 MB
+    assert [_route(300_000, 128, F32, L2, nq, 10) for nq in (4, 8, 9)] == [K1, K1, K2]                   # 154 MB
+    assert [_route(1_000_000, 128, F32, L2, nq, 10) for nq in (4, 5, 8)] == [K1, K2, K2]                 # 512 MB: one pass only
+    assert [_route(1_000_000, 768, F32, COS, nq, 100) for nq in (1, 2, 4)] == [K1, K2, K2]               # 3 GB: from two queries on
+    assert [_route(300_000, 768, F16, COS, nq, 10) for nq in (4, 5)] == [K1, K2]                         # 461 MB
+    assert [_route(10_000_000, 768, F32, COS, nq, 100) for nq in (2, 4, 16)] == [K2, K2, K2]
+    # Int8 / UInt8 rows: K1's v_dot4 pass holds its own longer
+    assert [_route(30_000, 768, I8, IP, nq, 10) for nq in (8, 16, 17)] == [K1, K1, K2]                   # 23 MB of 768-byte rows
+    assert [_route(300_000, 768, U8, L2, nq, 10) for nq in (4, 8, 9)] == [K1, K1, K2]                    # 230 MB
+    assert [_route(1_000_000, 128, I8, IP, nq, 10) for nq in (4, 8)] == [K1, K2]                         # 128 MB of 128-byte rows
+    assert [_route(50_000_000, 768, I8, IP, nq, 100) for nq in (1, 2)] == [K1, K2]                       # 38 GB: from two queries on
+    # k beyond one pass: the sort from the second pass on nearly everywhere, passes for a two-pass batch on a small corpus,
+    # the sort alone beyond 16384
+    assert _route(10_000_000, 768, F32, COS, 1, 1025) == SORT and _route(10_000_000, 768, F32, COS, 4, 16384) == SORT
+    assert _route(10_000, 128, F32, L2, 4, 2048) == PASSES and _route(10_000, 128, F32, L2, 4, 4096) == SORT
+    assert _route(10_000, 128, F32, L2, 1, 1025) == SORT
+    assert _route(10_000, 128, F32, L2, 1, 16385) == SORT and _route(60, 4, F32, L2, 300, 1 << 20) == SORT
+    # refused shapes
+    out = C.c_uint32(0)
+    lib = _lib.gpu()
+    assert lib.mvfgpu_selftest_route(10, 4, 9, 0, 1, 1, C.byref(out)) != 0          # unknown data type
+    assert lib.mvfgpu_selftest_route(10, 4, 0, 7, 1, 1, C.byref(out)) != 0          # unknown metric
+    assert lib.mvfgpu_selftest_route(10, 4, 0, 0, 1, 0, C.byref(out)) != 0          # k = 0
+    assert lib.mvfgpu_selftest_route(10, 4, 0, 0, 1, 1, None) != 0
