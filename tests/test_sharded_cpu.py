@@ -70,7 +70,8 @@ def _run_world(oracle, world, dtype, metric, n, k, dim=32, nq=3):
         assert (raw == wr).all()
 
 
-@pytest.mark.parametrize("dtype,metric,n,k", [(0, 2, 5000, 100), (2, 1, 3001, 64), (1, 0, 40, 100), (3, 0, 999, 10)])
+@pytest.mark.parametrize("dtype,metric,n,k", [(0, 2, 5000, 100), (2, 1, 3001, 64), (1, 0, 40, 100), (3, 0, 999, 10),
+                                             (2, 0, 30_000, 12_000)])   # any k: 2 x 12 000 entries per query through the host merge
 def test_two_rank_gloo_merge_equals_global(oracle, dtype, metric, n, k):
     _run_world(oracle, 2, dtype, metric, n, k)
 
