@@ -86,4 +86,60 @@ __device__ __forceinline__ void merge_ranked_u64(uint64_t* buf, uint32_t kp, uin
     __syncthreads();
 }
 
+// The same merge by ONE wave (the four-query pass: wave w merges query w's survivors while the other three waves merge theirs --
+// one barrier for the four lists instead of eight in a row).  buf[0 .. kp) ascending (kp <= 256), buf[kp .. kp + c) in any
+// order (c <= 256); each lane carries four old and four new elements.  No barrier inside: a wave's LDS operations execute in
+// order, and every read of the list comes before the first write.
+__device__ __forceinline__ void merge_ranked_u64_wave(uint64_t* buf, uint32_t kp, uint32_t c, uint32_t k, uint32_t lane) {
+    uint64_t ov[4], nv[4];
+    uint32_t orank[4], nrank[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const uint32_t i = lane + 64u * (uint32_t)j;
+        ov[j] = i < kp ? buf[i] : 0ull;  // 0: nothing ranks below it
+        nv[j] = i < c ? buf[kp + i] : 0ull;
+        orank[j] = i;
+        nrank[j] = 0;
+    }
+    const uint64_t* nb = buf + kp;
+#pragma unroll 4
+    for (uint32_t n = 0; n < c; n++) {
+        const uint64_t e = nb[n];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            orank[j] += e < ov[j] ? 1u : 0u;
+            nrank[j] += e < nv[j] ? 1u : 0u;
+        }
+    }
+    if (kp <= 128u) {
+#pragma unroll 4
+        for (uint32_t i = 0; i < kp; i++) {
+            const uint64_t e = buf[i];
+#pragma unroll
+            for (int j = 0; j < 4; j++) nrank[j] += e < nv[j] ? 1u : 0u;
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            uint32_t lo = 0, hi = kp;
+            while (lo < hi) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (buf[mid] < nv[j]) lo = mid + 1;
+                else hi = mid;
+            }
+            nrank[j] += lo;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const uint32_t i = lane + 64u * (uint32_t)j;
+        if (i < kp && orank[j] != i && orank[j] < k) buf[orank[j]] = ov[j];
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const uint32_t i = lane + 64u * (uint32_t)j;
+        if (i < c && nrank[j] < k) buf[nrank[j]] = nv[j];
+    }
+}
+
 }  // namespace mvf
