@@ -81,7 +81,12 @@ template <int BMQ_> struct CfT {
     // for them (4 x 36 KB of ring) and keeps the loads.
     static constexpr bool RC_LDS = BMQ != 64;
     static constexpr int NRC = 8;                               // >= NSTAGE + 1 (one k-tile per tile) with room for waves that lag inside the epilogue
-    static constexpr size_t LDS = (size_t)NSTAGE * STAGE_B + 4 * BMQ * 4 + (RC_LDS ? NRC * 2 * BR * 4 + 2 * BMQ * 4 : 0) + 16;  // ring + qaux0 + tau + qaux1 + prefilter [+ row constants + the L2 bounds' per-query pair] + candidate counter
+    // The int8 shadow's tile-invariant bounds (scan_mfma16_bias.inc, round 5; 256-query tile): R per row and query half, NRB
+    // buffers by tile ordinal, + the halves' threshold extremes and the block's reference point
+    static constexpr bool INV_LDS = BMQ == 256;
+    static constexpr int NRB = 4;
+    static constexpr size_t LDS = (size_t)NSTAGE * STAGE_B + 4 * BMQ * 4 + (RC_LDS ? NRC * 2 * BR * 4 + 2 * BMQ * 4 : 0) + 16 +  // ring + qaux0 + tau + qaux1 + prefilter [+ row constants + the L2 bounds' per-query pair] + candidate counter
+                                  (INV_LDS ? NRB * 2 * BR * 4 + 64 + BMQ * 4 : 0);  // ... and -B per query
 };
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -113,6 +118,10 @@ __global__ void __launch_bounds__(512, 2) scan_mfma16_dma_kernel(Batch16Params p
     uint32_t* bc_s = rc_s + (Cf::RC_LDS ? Cf::NRC * 2 * Cf::BR : 0);  // records in the block's candidate region
     float* thu_s = reinterpret_cast<float*>(bc_s + 4);                // [BMQ] int8 shadow, L2: (th - |th| 1e-6) / (2 s_q) ...
     float* u_s = thu_s + BMQ;                                         // [BMQ] ... and 1 / (2 s_q) (scan_mfma16_bias.inc)
+    int32_t* rb_s = reinterpret_cast<int32_t*>(u_s + BMQ);            // [NRB][2][BR] tile-invariant bounds: R(row) per query half
+    float* ext_s = reinterpret_cast<float*>(rb_s + (Cf::INV_LDS ? Cf::NRB * 2 * Cf::BR : 0));  // [2][4] {Pmin, Pmax, Wmin, Wmax} per half
+    uint32_t* ref_s = reinterpret_cast<uint32_t*>(ext_s + 8);         // u_ref, v_ref (bit patterns; +inf = not set)
+    int32_t* nbq_s = reinterpret_cast<int32_t*>(ref_s + 8);           // [BMQ] -B per query (the block's reference point: the same for every lane)
     // per-row constants the epilogue needs (scan_mfma16_common.inc): array 0 = norms, array 1 = shadow scale / UInt8 bias
     constexpr bool QSF = DT == MVF_DTYPE_FLOAT16 || (DT == MVF_DTYPE_INT8 && XS);  // float scores
     constexpr bool NEED0 = METRIC != MVF_METRIC_INNER_PRODUCT;
@@ -123,6 +132,20 @@ __global__ void __launch_bounds__(512, 2) scan_mfma16_dma_kernel(Batch16Params p
 
     // i32 accumulators behind a threshold: the pre-filter is folded into the accumulators (scan_mfma16_bias.inc)
     constexpr bool BIAS = !DIRECT && DT != MVF_DTYPE_FLOAT16 && Cf::RC_LDS && REG;
+    // The k-tile's barrier in the MIDDLE of its MFMAs (256-query tile, Int8 rows / the int8 shadow): the next k-tile's B
+    // fragments and first A fragment are read under the second half of this one's MFMAs, so no wave starts a k-tile with an LDS
+    // round trip in the open and the eight waves' fragment bursts no longer collide behind the barrier.  Round 5, one process,
+    // 12 rotated rounds (profiles/r05_k2_shadow_ladder.txt): cfg3's last phase 5.65 -> 5.46 ms, the cfg5 shard's 9.16 -> 8.75,
+    // cfg4's 7.60 -> 7.53; the bare k-loop (scripts/probe_k2_w1.hip, W8N -> W8NP) 4.97 -> 4.75 / 8.25 -> 7.88.  14 registers more
+    // (the fragments in hand): UInt8 rows under cosine spill with them and lose 3 %, so they -- and Float16 rows, whose long
+    // phases take the ping-pong kernel -- keep the barrier at the k-tile's end.
+#ifdef MVF_K2_ENDBARRIER  // A/B builds only
+    constexpr bool MIDB = false;
+#else
+    constexpr bool MIDB = BMQ_ == 256 && DT == MVF_DTYPE_INT8;
+#endif
+    // ... and on the int8 shadow with the 256-query tile the query half of the bound does not change from tile to tile
+    constexpr bool INVB = BIAS && DT == MVF_DTYPE_INT8 && XS && Cf::INV_LDS;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -142,7 +165,10 @@ __global__ void __launch_bounds__(512, 2) scan_mfma16_dma_kernel(Batch16Params p
     }
     if (my_tiles == 0) return;
     const uint32_t G = my_tiles * p.KT;
-    if (tid == 0) *bc_s = 0;  // published by the barrier after the prologue
+    if (tid == 0) {           // published by the barrier after the prologue
+        *bc_s = 0;
+        if constexpr (INVB) ref_s[0] = ref_s[1] = 0x7F800000u;
+    }
 
     // ---- DMA: 1-KB pieces (16 rows x 64 B); wave w fills A pieces [w APW, (w+1) APW) and B pieces [w BPW, (w+1) BPW) ----
     const uint32_t rl = (uint32_t)lane >> 2;                              // row inside a piece
@@ -252,7 +278,7 @@ __global__ void __launch_bounds__(512, 2) scan_mfma16_dma_kernel(Batch16Params p
     };
 
     // ---- pre-filter folded into the accumulators (scan_mfma16_bias.inc): per-lane state ------------------------------
-    [[maybe_unused]] AccT negb[NI];        // -B of the tile being multiplied, one 4-query vector per group
+    [[maybe_unused]] AccT negb[INVB ? 1 : NI];  // -B of the tile being multiplied, one 4-query vector per group (INVB: in LDS, nbq_s)
     [[maybe_unused]] int32_t br_cur[NJ];   // R(row) of that tile
     // the lane's smallest threshold (float thresholds; L2 on the int8 shadow: the smallest (th - |th| 1e-6) / (2 s_q)) and,
     // L2 on the shadow, its smallest 1 / (2 s_q)
@@ -262,11 +288,12 @@ __global__ void __launch_bounds__(512, 2) scan_mfma16_dma_kernel(Batch16Params p
     [[maybe_unused]] const uint32_t wcap = p.blk_cap / (uint32_t)NW;
     [[maybe_unused]] uint4* const wbase = p.blk_cand + ((size_t)blockIdx.x * NW + (uint32_t)wave) * wcap;
     [[maybe_unused]] uint32_t wcnt = 0;
+    [[maybe_unused]] uint32_t flagged = 0;  // wave-uniform: bit i = query group i of the tile being finished holds a maximum >= 0
     constexpr bool L2Q = QSF && METRIC == MVF_METRIC_L2;
     auto rc_of = [&](uint32_t n) __attribute__((always_inline)) { return rc_s + (n & (Cf::NRC - 1)) * 2 * Cf::BR; };
     // int8 shadow: the rows' factors 1 / m_j replace the shadow scales in tile n's LDS copy, once per row (scan_mfma16_bias.inc:
     // lane_rows16's PRE form).  Called for a tile whose constants have landed and that no wave reads yet (see the call sites).
-    constexpr bool RC_PRE = BIAS && QSF;
+    constexpr bool RC_PRE = BIAS && QSF && !INVB;
     auto rc_transform = [&](uint32_t n) __attribute__((always_inline)) {
         if constexpr (RC_PRE) {
             if (n < my_tiles) {
@@ -359,40 +386,195 @@ __global__ void __launch_bounds__(512, 2) scan_mfma16_dma_kernel(Batch16Params p
 #ifdef MVF_DIAG_NOBIAS  // diagnostic build only (with MVF_DIAG_NOEPI): the tile's bounds are not computed, the sums start from zero
 #define MVF_BIAS_ALL(n)                                         \
     do {                                                        \
-        for (int i_ = 0; i_ < NI; i_++) negb[i_] = AccT{0, 0, 0, 0}; \
+        for (int i_ = 0; i_ < (INVB ? 1 : NI); i_++) negb[i_] = AccT{0, 0, 0, 0}; \
     } while (0)
 #else
 #define MVF_BIAS_ALL(n) bias_all(n)
 #endif
+    // ---- tile-invariant bounds (INVB; scan_mfma16_bias.inc): -B per lane and query once per query tile, R per row and
+    // query half once per tile by the block, one tile ahead ----------------------------------------------------------------
+    static_assert(!INVB || (Cf::BR == 256 && NW * 64 == 2 * Cf::BR && WQ == 128), "one thread per (row, query half)");
+    auto tile_mt = [&](uint32_t n) __attribute__((always_inline)) -> uint32_t {
+        uint32_t nt, mt;
+        slot_tile(n, nt, mt);
+        return mt;
+    };
+    auto ref_val = [&](int i) __attribute__((always_inline)) -> float {
+        const uint32_t b = ref_s[i];
+        return b == 0x7F800000u ? 0.0f : __uint_as_float(b);  // no row of the first tile had a finite factor: any point serves
+    };
+    // R of every row of block tile m, both query halves.  The tile's constants have landed (see the call sites) and no wave
+    // reads buffer m mod NRB before the next barrier.
+    auto inv_transform = [&](uint32_t m) __attribute__((always_inline)) {
+        if constexpr (INVB) {
+            uint32_t nt, mt;
+            slot_tile(m, nt, mt);
+            const uint32_t* rc = rc_of(m);
+            const int row = tid & (Cf::BR - 1), half = tid >> 8;
+            float u, v;
+            inv_row_uv<METRIC>(NEED0 ? rc[row] : 0u, rc[Cf::BR + row], u, v);
+            rb_s[((m & (Cf::NRB - 1)) * 2 + half) * Cf::BR + row] =
+                inv_row_bound<METRIC>(u, v, ref_val(0), ref_val(1), ext_s + 4 * half, p.row_begin + nt * Cf::BR + (uint32_t)row < p.row_end);
+        }
+    };
+    auto inv_rows = [&](uint32_t n) __attribute__((always_inline)) {
+        if constexpr (INVB) {
+            const int32_t* rb = rb_s + ((n & (Cf::NRB - 1)) * 2 + wm) * Cf::BR + wn * WR + (lane & (SH - 1));
+#pragma unroll
+            for (int j = 0; j < NJ; j++) br_cur[j] = rb[j * SH];
+        }
+    };
+    // once per query tile (the caller has published thr_s / qa_s): the per-query pair (P, W), the extremes of each half,
+    // -B of the lane's queries; `first`: the block's reference point from the rows of its first tile
+    auto inv_query_prep = [&](bool first) {
+        if constexpr (INVB) {
+            const float inf = __builtin_inff();
+            if constexpr (L2Q) {
+                if (tid < BMQ) {
+                    const float th = thr_s[tid], w = 0.5f * __builtin_amdgcn_rcpf(qa_s[tid]);
+                    thu_s[tid] = fabsf(th) < 3.0e38f ? (th - fabsf(th) * 1e-6f) * w : th;
+                    u_s[tid] = w;
+                }
+            }
+            if (first && tid < Cf::BR) {
+                uint32_t nt, mt;
+                slot_tile(0, nt, mt);
+                const uint32_t* rc = rc_of(0);
+                float u, v;
+                inv_row_uv<METRIC>(NEED0 ? rc[tid] : 0u, rc[Cf::BR + tid], u, v);
+                if (p.row_begin + nt * Cf::BR + (uint32_t)tid < p.row_end) {
+                    if (u >= 0.0f && u < inf) atomicMin(&ref_s[0], __float_as_uint(u));
+                    if (METRIC == MVF_METRIC_L2 && v >= 0.0f && v < inf) atomicMin(&ref_s[1], __float_as_uint(v));
+                }
+            }
+            __syncthreads();
+            const float* parr = L2Q ? thu_s : thr_s;
+            float pmin = inf, pmax = -inf, wmin = inf, wmax = 0.0f;
+#pragma unroll
+            for (int h = 0; h < WQ / 64; h++) {
+                const int ql = wm * WQ + h * 64 + lane;
+                const float P = parr[ql], W = L2Q ? u_s[ql] : 0.0f;
+                if (fabsf(P) < 3.0e38f && (!L2Q || (W >= 0.0f && W < 3.0e38f))) {
+                    pmin = fminf(pmin, P), pmax = fmaxf(pmax, P);
+                    wmin = fminf(wmin, W), wmax = fmaxf(wmax, W);
+                }
+            }
+            for (int off = 32; off > 0; off >>= 1) {
+                pmin = fminf(pmin, __shfl_xor(pmin, off, 64)), pmax = fmaxf(pmax, __shfl_xor(pmax, off, 64));
+                wmin = fminf(wmin, __shfl_xor(wmin, off, 64)), wmax = fmaxf(wmax, __shfl_xor(wmax, off, 64));
+            }
+            if (!(pmin <= pmax)) pmin = pmax = wmin = wmax = 0.0f;  // no query of the half has finite constants: B decides alone
+            if (wn == 0 && lane == 0) ext_s[4 * wm + 0] = pmin, ext_s[4 * wm + 1] = pmax, ext_s[4 * wm + 2] = wmin, ext_s[4 * wm + 3] = wmax;
+            if (tid < BMQ) nbq_s[tid] = inv_bias_query<METRIC>(parr[tid], L2Q ? u_s[tid] : 0.0f, ref_val(0), ref_val(1));
+            __syncthreads();  // the extremes and -B are published
+        }
+    };
     if constexpr (BIAS) {
-        if constexpr (RC_PRE) {  // tile 0 (and 1, see below): their constants were requested in front of k-tile 0, which has landed
-            rc_transform(0);
-            if (p.KT == 1) rc_transform(1);
+#ifdef MVF_DIAG_NOBIAS
+        MVF_BIAS_ALL(0);
+        if constexpr (INVB) {
+            if (tid < BMQ) nbq_s[tid] = 0;
             __syncthreads();
         }
-        query_prep();
-        MVF_BIAS_ALL(0);
+#else
+        if constexpr (INVB) {  // tile 0 (and 1, see below): their constants were requested in front of k-tile 0, which has landed
+            inv_query_prep(true);
+            inv_transform(0);
+            if (p.KT == 1 && 1 < my_tiles && tile_mt(1) == c_mt) inv_transform(1);
+            __syncthreads();
+            inv_rows(0);
+        } else {
+            if constexpr (RC_PRE) {  // tile 0 (and 1, see below): their constants were requested in front of k-tile 0, which has landed
+                rc_transform(0);
+                if (p.KT == 1) rc_transform(1);
+                __syncthreads();
+            }
+            query_prep();
+            MVF_BIAS_ALL(0);
+        }
+#endif
     }
 
+    // MIDB: the B fragments and the first A fragment of the k-tile about to be multiplied (read during the k-tile before)
+    [[maybe_unused]] u32x4 fbc[NJ], fa_first;
+    if constexpr (MIDB) {
+        static_assert(!MIDB || (NI == 8 && Cf::PIECES == NI / 2 && NJ == NI / 2), "one DMA piece and one B fragment per group of the second half");
+#pragma unroll
+        for (int j = 0; j < NJ; j++) fbc[j] = read_b(smem, j);
+        fa_first = read_a(smem, 0);
+    }
     uint32_t cs = 0, ds = NSTAGE - 1;  // compute stage (k-tile g), DMA target (k-tile g + NSTAGE - 1: the stage g - 1 read)
+    // the flagged query groups of a finished wave tile: element walk, raw records into the wave's region
+    auto walk_tile = [&](uint32_t flags, uint32_t nt, uint32_t mt) {
+        if constexpr (BIAS) {
+#pragma unroll
+            for (int i = 0; i < NI; i++) {
+                if (!(flags & (1u << i))) continue;
+                auto nb_of = [&](int e) __attribute__((always_inline)) -> int32_t {
+                    if constexpr (INVB) return nbq_s[wm * WQ + 4 * (lane / SH) + i * SH + e];
+                    else return negb[i][e];
+                };
+                epilogue_group16<SH, NJ>(p, acc[i], nb_of, br_cur, mt * BMQ + (uint32_t)(wm * WQ + 4 * (lane / SH) + i * SH),
+                                         p.row_begin + nt * Cf::BR + (uint32_t)(wn * WR + (lane & (SH - 1))), wbase, wcap, wcnt);
+            }
+            wcnt = __builtin_amdgcn_readfirstlane(wcnt);
+        }
+    };
     for (uint32_t g = 0; g < G; g++) {
         const unsigned char* st = smem + cs * STAGE_B;
         // NI groups of NJ MFMAs (one A fragment x NJ B fragments each, the whole 64-B k in one MFMA); the next group's
         // A fragment is read while this group's MFMAs run; the DMA pieces follow the groups; with BIAS the first k-tile
         // of a tile starts every accumulator from -B
+        const bool first_kt = BIAS && c_kt == 0;  // wave-uniform
+        // Query group i of the tile that finishes in this iteration: is its running maximum >= 0 somewhere in the wave?  One bit
+        // per group in a scalar register.
+        auto drain_group = [&](int i) __attribute__((always_inline)) {
+            if constexpr (BIAS) {
+#ifndef MVF_DIAG_NOEPI
+                const int32_t h = drain_group16<BiasTraits<DT, METRIC, XS>::HAS_BR, NJ>(acc[i], br_cur);
+                if (__builtin_amdgcn_ballot_w64(h >= 0) != 0) flagged |= 1u << i;
+#else
+#pragma unroll
+                for (int j = 0; j < NJ; j++) asm volatile("" ::"v"(acc[i][j]));
+#endif
+            }
+        };
         auto ktile = [&](auto first_c) __attribute__((always_inline)) {
             constexpr bool FIRST = decltype(first_c)::value;
             u32x4 fb[NJ], fa[2];
+            [[maybe_unused]] AccT nbv[2];  // INVB, first k-tile: -B of the group's four queries, from LDS just ahead of its MFMAs
+            auto read_nb = [&](int i) __attribute__((always_inline)) -> AccT {
+                return *reinterpret_cast<const AccT*>(nbq_s + wm * WQ + 4 * (lane / SH) + i * SH);
+            };
 #pragma unroll
             for (int j = 0; j < NJ; j++) fb[j] = read_b(st, j);
             fa[0] = read_a(st, 0);
+            if constexpr (INVB && FIRST) nbv[0] = read_nb(0);
 #pragma unroll
             for (int i = 0; i < NI; i++) {
+#ifdef MVF_K2_OLD_FRAG_ORDER  // A/B builds only: rounds 2-4 requested the next fragment in front of the group
                 if (i + 1 < NI) fa[(i + 1) & 1] = read_a(st, i + 1);
+#endif
 #pragma unroll
                 for (int j = 0; j < NJ; j++) {
-                    if constexpr (BIAS && FIRST) acc[i][j] = negb[i];  // the MFMA's C operand: no copy is emitted
+                    if constexpr (BIAS && FIRST) {  // the MFMA's C operand: no copy is emitted
+                        if constexpr (INVB) acc[i][j] = nbv[i & 1];
+                        else acc[i][j] = negb[i];
+                    }
                     mfma1(acc[i][j], fa[i & 1], fb[j]);
+#ifndef MVF_K2_OLD_FRAG_ORDER
+                    // The next group's A fragment is requested BEHIND this group's first MFMA, that is behind the wait for this
+                    // group's own fragment.  With an LDS-DMA pending hipcc waits for LDS reads with lgkmcnt(0) only (it counts the
+                    // DMA as a flat access that may return out of order); requested in front of the group, the new read was inside
+                    // that wait and every second group began with a full LDS round trip in the open.
+                    if (j == 0) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (i + 1 < NI) {
+                            fa[(i + 1) & 1] = read_a(st, i + 1);
+                            if constexpr (INVB && FIRST) nbv[(i + 1) & 1] = read_nb(i + 1);
+                        }
+                    }
+#endif
                 }
                 if (NI == 8 ? (i & 1) == 0 : true) dma_piece(ds, NI == 8 ? i / 2 : i);          // 4 pieces over 8 groups (a 5th behind group 1), or
                 if (NI == 8 && i == 1 && Cf::PIECES > 4) dma_piece(ds, 4);
@@ -400,16 +582,71 @@ __global__ void __launch_bounds__(512, 2) scan_mfma16_dma_kernel(Batch16Params p
                 __builtin_amdgcn_sched_barrier(0);
             }
         };
-        if (BIAS && c_kt == 0) {
+        // MIDB: [groups 0..3 on the fragments in hand] wait(k-tile g + 1 landed) barrier [groups 4..7, reading k-tile g + 1's B
+        // fragments and first A fragment underneath; the DMA of k-tile g + 3 goes into the stage k-tile g - 1 used: every wave is
+        // past its reads of that stage at this barrier].  One k-tile stays in flight across the barrier.
+        auto ktile_mid = [&](auto first_c) __attribute__((always_inline)) {
+            constexpr bool FIRST = decltype(first_c)::value;
+            const unsigned char* stn = smem + (cs + 1 == NSTAGE ? 0 : cs + 1) * STAGE_B;
+            u32x4 fbn[NJ], fa[2];
+            [[maybe_unused]] AccT nbv[2];
+            auto read_nb = [&](int i) __attribute__((always_inline)) -> AccT {
+                return *reinterpret_cast<const AccT*>(nbq_s + wm * WQ + 4 * (lane / SH) + i * SH);
+            };
+            fa[0] = fa_first;
+            if constexpr (INVB && FIRST) nbv[0] = read_nb(0);
+#pragma unroll
+            for (int i = 0; i < NI; i++) {
+                if (i == NI / 2) {
+                    __builtin_amdgcn_s_waitcnt(0x0F70 | Cf::PIECES);  // vmcnt(PIECES): k-tile g + 1 has landed (this wave's pieces)
+                    asm volatile("" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                    asm volatile("" ::: "memory");
+                }
+#pragma unroll
+                for (int j = 0; j < NJ; j++) {
+                    if constexpr (BIAS && FIRST) {
+                        if constexpr (INVB) acc[i][j] = nbv[i & 1];
+                        else acc[i][j] = negb[i];
+                    }
+                    mfma1(acc[i][j], fa[i & 1], fbc[j]);
+                    if (j == 0) {  // requests behind the group's first MFMA (see ktile)
+                        __builtin_amdgcn_sched_barrier(0);
+                        fa[(i + 1) & 1] = i + 1 < NI ? read_a(st, i + 1) : read_a(stn, 0);
+                        if (i >= NI / 2) fbn[i - NI / 2] = read_b(stn, i - NI / 2);
+                        if constexpr (INVB && FIRST) {
+                            if (i + 1 < NI) nbv[(i + 1) & 1] = read_nb(i + 1);
+                        }
+                    }
+                }
+                if (i >= NI / 2) dma_piece(ds, i - NI / 2);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int j = 0; j < NJ; j++) fbc[j] = fbn[j];
+            fa_first = fa[NI & 1];
+        };
+        if (first_kt) {
             // The NEXT tile's row constants: requested (set_dma_tile) in front of this tile's first k-tile, which the last wait
             // has seen land -- the constants are older -- and read at this tile's end, at least one barrier from here when a
             // tile has two k-tiles or more.  With ONE k-tile per tile the tile after the next is taken instead: the DMA cursor
             // runs NSTAGE - 1 tiles ahead then, its constants were requested behind the pieces of tile c_n + 1 at the latest,
             // and those are older than everything the last wait left in flight.
-            rc_transform(c_n + (p.KT == 1 ? 2u : 1u));
-            ktile(std::true_type{});
+            if constexpr (INVB) {
+#ifndef MVF_DIAG_NOBIAS
+                // R of the next tile (the one after it when a tile is ONE k-tile), if it is multiplied with the queries in place
+                // now; a change of the query tile computes its own (below)
+                const uint32_t m = c_n + (p.KT == 1 ? 2u : 1u);
+                if (m < my_tiles && tile_mt(m) == c_mt && (p.KT != 1 || tile_mt(c_n + 1) == c_mt)) inv_transform(m);
+#endif
+            } else {
+                rc_transform(c_n + (p.KT == 1 ? 2u : 1u));
+            }
+            if constexpr (MIDB) ktile_mid(std::true_type{});
+            else ktile(std::true_type{});
         } else {
-            ktile(std::false_type{});
+            if constexpr (MIDB) ktile_mid(std::false_type{});
+            else ktile(std::false_type{});
         }
         dma_advance();
         cs = cs + 1 == NSTAGE ? 0 : cs + 1;
@@ -418,7 +655,14 @@ __global__ void __launch_bounds__(512, 2) scan_mfma16_dma_kernel(Batch16Params p
             if constexpr (BIAS) {
 #ifndef MVF_DIAG_NOEPI
                 if (lane == 0) MVF_DIAG_ADD(0, 1);
-                epilogue_bias16<BiasTraits<DT, METRIC, XS>::HAS_BR, BMQ, SH, WQ, WR, Cf::BR>(p, acc, negb, br_cur, c_nt, c_mt, wm, wn, lane, wbase, wcap, wcnt);
+                // Every group's running maximum is taken HERE, behind the loop, and the rare walk in front of the barrier.  Round 5
+                // built both alternatives -- the maxima inside the tile's last k-tile, one group behind the MFMAs; the walk behind
+                // the barrier, beside the partner wave's next k-tile -- and each lost: VALU inside the MFMA stream +3.7...4.0 %, the
+                // deferred walk another +1.1...1.6 % (profiles/r05_k2_drain_walk_placement_ab.txt).
+#pragma unroll
+                for (int i = 0; i < NI; i++) drain_group(i);
+                if (flagged) walk_tile(flagged, c_nt, c_mt);
+                flagged = 0;
                 wcnt = __builtin_amdgcn_readfirstlane(wcnt);
 #else
 #pragma unroll
@@ -435,9 +679,25 @@ __global__ void __launch_bounds__(512, 2) scan_mfma16_dma_kernel(Batch16Params p
                         load_query_consts16<DT, METRIC, BMQ, (DT == MVF_DTYPE_INT8 && XS)>(p, nmt * BMQ, tid, qa_s, qb_s, tau_s, thr_s);
                         c_mt = nmt;
                         __syncthreads();
-                        query_prep();
+#ifndef MVF_DIAG_NOBIAS
+                        if constexpr (INVB) {
+                            inv_query_prep(false);
+                            inv_transform(c_n);
+                            if (p.KT == 1 && c_n + 1 < my_tiles && tile_mt(c_n + 1) == c_mt) inv_transform(c_n + 1);
+                            __syncthreads();
+                        } else
+#endif
+                        {
+                            query_prep();
+                        }
                     }
-                    MVF_BIAS_ALL(c_n);
+#ifndef MVF_DIAG_NOBIAS
+                    if constexpr (INVB) inv_rows(c_n);
+                    else
+#endif
+                    {
+                        MVF_BIAS_ALL(c_n);
+                    }
                 }
             } else {
 #ifdef MVF_DIAG_NOEPI  // diagnostic build only: the k-loop alone (the sums are kept alive, nothing is selected)
@@ -465,14 +725,17 @@ __global__ void __launch_bounds__(512, 2) scan_mfma16_dma_kernel(Batch16Params p
                 }
             }
         }
-        // k-tile g + 1 must have landed; the younger k-tile(s) stay in flight across the barrier
-        __builtin_amdgcn_s_waitcnt(0x0070 | Cf::INFLIGHT);  // vmcnt(INFLIGHT) lgkmcnt(0)
-        asm volatile("" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
+        if constexpr (!MIDB) {
+            // k-tile g + 1 must have landed; the younger k-tile(s) stay in flight across the barrier
+            __builtin_amdgcn_s_waitcnt(0x0070 | Cf::INFLIGHT);  // vmcnt(INFLIGHT) lgkmcnt(0)
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        }
     }
     // the DMAs issued for k-tiles past the end target this block's own LDS: let them land before the wave exits
     __builtin_amdgcn_s_waitcnt(0x0070 | 0x0F00);  // vmcnt(0)
+    if constexpr (MIDB && !BIAS) __syncthreads();  // the last epilogues lie behind the loop's last barrier
     if constexpr (BIAS) {
         if (lane == 0) p.blk_cnt[blockIdx.x * NW + (uint32_t)wave] = min(wcnt, wcap);  // one region per wave (scan_mfma16_dma_wave_regions)
     } else {

@@ -20,7 +20,7 @@ for f in cc:
         name[r["Dispatch_Id"]] = r["Kernel_Name"]
 best = {}
 for did, n in name.items():
-    if flt not in n or did not in dur:
+    if did not in dur or (flt not in n if flt else not ("scan_mfma16_dma_kernel" in n or "kloop_kernel" in n)):
         continue
     if n not in best or dur[did] > dur[best[n]]:
         best[n] = did

@@ -56,7 +56,11 @@ __device__ __forceinline__ uint32_t slot_swz(uint32_t x) { return (0x78u >> (2u 
 // s_waitcnt with vmcnt = v (6 bits: [3:0] and [15:14]), expcnt / lgkmcnt as given
 constexpr int waitcnt_imm(int vm, int lgkm) { return (vm & 0xF) | ((vm >> 4) << 14) | 0x0070 | ((lgkm & 0xF) << 8); }
 
-template <int NW, bool PIPE>
+// FA (round 5): the next group's A fragment is requested behind the group's FIRST MFMA (= behind the wait for the group's own
+// fragment) instead of in front of the group, where hipcc's lgkmcnt(0) -- the only LDS wait it emits while an LDS-DMA is
+// pending -- covered the read just issued.
+// PRIO: waves 4..7 (the second-dispatched partner on every SIMD) run at s_setprio 1.
+template <int NW, bool PIPE, bool FA = false, bool PRIO = false>
 __global__ void __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) kloop_kernel(P p) {
     constexpr int WN = NW == 8 ? 4 : 2;              // waves along the rows; 2 along the queries
     constexpr int WQ = 128, WR = BR / WN;            // wave tile
@@ -68,6 +72,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) kloop_kernel(P p) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
+    if (PRIO && wave >= NW / 2) __builtin_amdgcn_s_setprio(1);
 
     const uint32_t xcd = blockIdx.x & 7u, ls = blockIdx.x >> 3, nls = gridDim.x >> 3;
     auto slot_tile = [&](uint32_t n, uint32_t& nt, uint32_t& mt) {
@@ -171,9 +176,15 @@ __global__ void __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) kloop_kernel(P p) {
                 fa[0] = read_a(st, 0);
 #pragma unroll
                 for (int i = 0; i < NI; i++) {
-                    if (i + 1 < NI) fa[(i + 1) & 1] = read_a(st, i + 1);
+                    if (!FA && i + 1 < NI) fa[(i + 1) & 1] = read_a(st, i + 1);
 #pragma unroll
-                    for (int j = 0; j < NJ; j++) mfma1(acc[i][j], fa[i & 1], fb[j]);
+                    for (int j = 0; j < NJ; j++) {
+                        mfma1(acc[i][j], fa[i & 1], fb[j]);
+                        if (FA && j == 0) {
+                            __builtin_amdgcn_sched_barrier(0);
+                            if (i + 1 < NI) fa[(i + 1) & 1] = read_a(st, i + 1);
+                        }
+                    }
                     if (PIECES == 8) dma_piece(ds, i);
                     else if ((i & 1) == 0) dma_piece(ds, i / 2);
                     __builtin_amdgcn_sched_barrier(0);
@@ -209,17 +220,26 @@ __global__ void __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) kloop_kernel(P p) {
                         __builtin_amdgcn_s_barrier();
                         asm volatile("" ::: "memory");
                     }
-                    if (i + 1 < NI) fa[(i + 1) & 1] = read_a(st, i + 1);
-                    else fa[(i + 1) & 1] = read_a(stn, 0);  // the next k-tile's first A fragment
-                    if (i >= NI / 2) {  // the next k-tile's B fragments, two per group
+                    auto reads = [&]() __attribute__((always_inline)) {
+                        if (i + 1 < NI) fa[(i + 1) & 1] = read_a(st, i + 1);
+                        else fa[(i + 1) & 1] = read_a(stn, 0);  // the next k-tile's first A fragment
+                        if (i >= NI / 2) {  // the next k-tile's B fragments, NJ / (NI / 2) per group
 #pragma unroll
-                        for (int j = 0; j < NJ / (NI / 2); j++) fbn[(i - NI / 2) * (NJ / (NI / 2)) + j] = read_b(stn, (i - NI / 2) * (NJ / (NI / 2)) + j);
+                            for (int j = 0; j < NJ / (NI / 2); j++) fbn[(i - NI / 2) * (NJ / (NI / 2)) + j] = read_b(stn, (i - NI / 2) * (NJ / (NI / 2)) + j);
+                        }
+                    };
+                    if (!FA) reads();
+#pragma unroll
+                    for (int j = 0; j < NJ; j++) {
+                        mfma1(acc[i][j], fa[i & 1], fbc[j]);
+                        if (FA && j == 0) {
+                            __builtin_amdgcn_sched_barrier(0);
+                            reads();
+                        }
                     }
+                    if (i >= NI / 2) {  // all of the k-tile's DMA pieces behind the barrier, PIECES / (NI / 2) per group
 #pragma unroll
-                    for (int j = 0; j < NJ; j++) mfma1(acc[i][j], fa[i & 1], fbc[j]);
-                    if (i >= NI / 2) {  // all of the k-tile's DMA pieces behind the barrier, two per group
-                        dma_piece(ds, 2 * (i - NI / 2));
-                        dma_piece(ds, 2 * (i - NI / 2) + 1);
+                        for (int q = 0; q < PIECES / (NI / 2); q++) dma_piece(ds, (PIECES / (NI / 2)) * (i - NI / 2) + q);
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -265,51 +285,61 @@ __global__ void colsum_kernel(const unsigned char* rows, uint32_t n, uint32_t pi
     atomicAdd(reinterpret_cast<unsigned long long*>(out + d), (unsigned long long)s);
 }
 
-int main(int argc, char** argv) {
-    const uint32_t n = (argc > 1 ? (uint32_t)atoll(argv[1]) : 50000000u) / BR * BR;  // whole block tiles (the checksum counts every output)
-    const uint32_t dim = argc > 2 ? (uint32_t)atoi(argv[2]) : 768u;
-    const uint32_t nq = argc > 3 ? (uint32_t)atoi(argv[3]) : 256u;
-    const int reps = argc > 4 ? atoi(argv[4]) : 5;
-    const std::string variants = argc > 5 ? argv[5] : "8,4,4p";
-    if (nq % BMQ || dim % 16) {
-        fprintf(stderr, "nq must be a multiple of 256, dim of 16\n");
-        return 2;
-    }
+// One persistent set-up per process (the ladder of scripts/k2_ladder.py calls probe_k2_run between the library's searches):
+// rows / queries are filled once per shape, every call times `reps` launches of one variant and returns the mean ms (< 0: error
+// or a wrong checksum).
+struct ProbeState {
+    uint32_t n = 0, dim = 0, nq = 0, want = 0, grid = 0;
     P p{};
-    p.n = n;
-    p.pitch = dim;
-    p.V = dim / 16;
-    p.KT = (dim + DKB - 1) / DKB;
-    p.KPB = p.KT * DKB;
-    p.ntiles = (n + BR - 1) / BR;
-    p.mtiles = nq / BMQ;
-    unsigned char *rows, *q, *zeros;
-    HIP_OK(hipMalloc(&rows, (size_t)n * dim));
-    HIP_OK(hipMalloc(&q, (size_t)nq * p.KPB));
-    HIP_OK(hipMalloc(&zeros, 256));
-    HIP_OK(hipMemset(zeros, 0, 256));
-    HIP_OK(hipMemset(q, 0, (size_t)nq * p.KPB));
-    fill_kernel<<<4096, 256>>>(rows, (size_t)n * dim, 1234567);
+    unsigned char *rows = nullptr, *q = nullptr, *zeros = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+};
+static ProbeState g_ps;
+
+static void (*variant_fn(const std::string& t, int* threads, const char** name))(P) {
+    *threads = 512;
+    if (t == "8") { *name = "W8  (8 waves, 128x64, two per SIMD; rounds 2-4)"; return &kloop_kernel<8, false>; }
+    if (t == "8n") { *name = "W8N (W8, next A fragment requested behind the group's first MFMA)"; return &kloop_kernel<8, false, true>; }
+    if (t == "8p") { *name = "W8P (W8, mid-tile barrier, next k-tile's fragments read under the second half)"; return &kloop_kernel<8, true>; }
+    if (t == "8np") { *name = "W8NP (W8P + fragment requests behind the group's first MFMA)"; return &kloop_kernel<8, true, true>; }
+    if (t == "8ns") { *name = "W8NS (W8N + waves 4..7 at s_setprio 1)"; return &kloop_kernel<8, false, true, true>; }
+    *threads = 256;
+    if (t == "4") { *name = "W4  (4 waves, 128x128, one per SIMD)"; return &kloop_kernel<4, false>; }
+    if (t == "4n") { *name = "W4N (W4, next A fragment requested behind the group's first MFMA)"; return &kloop_kernel<4, false, true>; }
+    if (t == "4p") { *name = "W4P (W4 + mid-tile barrier, fragments prefetched)"; return &kloop_kernel<4, true>; }
+    return nullptr;
+}
+
+static int probe_setup(uint32_t n_in, uint32_t dim, uint32_t nq) {
+    ProbeState& S = g_ps;
+    const uint32_t n = n_in / BR * BR;
+    if (S.rows && S.n == n && S.dim == dim && S.nq == nq) return 0;
+    if (nq % BMQ || dim % 16) return 2;
+    if (S.rows) { (void)hipFree(S.rows); (void)hipFree(S.q); (void)hipFree(S.zeros); (void)hipFree(S.p.out); S.rows = nullptr; }
+    P& p = S.p;
+    p = P{};
+    p.n = n; p.pitch = dim; p.V = dim / 16; p.KT = (dim + DKB - 1) / DKB; p.KPB = p.KT * DKB;
+    p.ntiles = (n + BR - 1) / BR; p.mtiles = nq / BMQ;
+    HIP_OK(hipMalloc(&S.rows, (size_t)n * dim));
+    HIP_OK(hipMalloc(&S.q, (size_t)nq * p.KPB));
+    HIP_OK(hipMalloc(&S.zeros, 256));
+    HIP_OK(hipMemset(S.zeros, 0, 256));
+    HIP_OK(hipMemset(S.q, 0, (size_t)nq * p.KPB));
+    fill_kernel<<<4096, 256>>>(S.rows, (size_t)n * dim, 1234567);
     std::vector<signed char> hq((size_t)nq * p.KPB, 0);
     for (uint32_t i = 0; i < nq; i++)
         for (uint32_t d = 0; d < dim; d++) hq[(size_t)i * p.KPB + d] = (signed char)(mix64(77 + (uint64_t)i * dim + d) >> 56);
-    HIP_OK(hipMemcpy(q, hq.data(), hq.size(), hipMemcpyHostToDevice));
-    p.rows = rows;
-    p.qprep = q;
-    p.zeros = zeros;
+    HIP_OK(hipMemcpy(S.q, hq.data(), hq.size(), hipMemcpyHostToDevice));
+    p.rows = S.rows; p.qprep = S.q; p.zeros = S.zeros;
     int num_cus = 256;
-    {
-        hipDeviceProp_t prop;
-        HIP_OK(hipGetDeviceProperties(&prop, 0));
-        num_cus = prop.multiProcessorCount;
-    }
-    // expected total: sum_d (sum_q q[d]) * (sum_r x[d])  (mod 2^32)
+    { hipDeviceProp_t prop; HIP_OK(hipGetDeviceProperties(&prop, 0)); num_cus = prop.multiProcessorCount; }
     long long* colsum;
     HIP_OK(hipMalloc(&colsum, (size_t)dim * 8));
     HIP_OK(hipMemset(colsum, 0, (size_t)dim * 8));
-    colsum_kernel<<<dim3(2048, (dim + 255) / 256), 256>>>(rows, n, dim, dim, colsum);
+    colsum_kernel<<<dim3(2048, (dim + 255) / 256), 256>>>(S.rows, n, dim, dim, colsum);
     std::vector<long long> hx(dim);
     HIP_OK(hipMemcpy(hx.data(), colsum, (size_t)dim * 8, hipMemcpyDeviceToHost));
+    HIP_OK(hipFree(colsum));
     uint32_t want = 0;
     for (uint32_t d = 0; d < dim; d++) {
         long long sq = 0;
@@ -319,49 +349,71 @@ int main(int argc, char** argv) {
     const uint32_t total = ((p.ntiles + 7) / 8) * p.mtiles * 8;
     uint32_t nls = std::max(1u, (uint32_t)num_cus / 8u);
     if (nls > p.mtiles) nls -= nls % p.mtiles;
-    const uint32_t grid = std::min(total, nls * 8u);
-    HIP_OK(hipMalloc(&p.out, (size_t)grid * 512 * 4));
+    S.grid = std::min(total, nls * 8u);
+    HIP_OK(hipMalloc(&p.out, (size_t)S.grid * 512 * 4));
+    if (!S.e0) { HIP_OK(hipEventCreate(&S.e0)); HIP_OK(hipEventCreate(&S.e1)); }
+    S.n = n; S.dim = dim; S.nq = nq; S.want = want;
+    return 0;
+}
+
+extern "C" float probe_k2_run(uint32_t n, uint32_t dim, uint32_t nq, int reps, const char* variant) {
+    if (probe_setup(n, dim, nq)) return -2.f;
+    ProbeState& S = g_ps;
+    int threads; const char* name;
+    void (*fn)(P) = variant_fn(variant, &threads, &name);
+    if (!fn) return -3.f;
+    HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
+    HIP_OK(hipMemset(S.p.out, 0, (size_t)S.grid * 512 * 4));
+    HIP_OK(hipEventRecord(S.e0));
+    for (int r = 0; r < reps; r++) hipLaunchKernelGGL(fn, dim3(S.grid), dim3(threads), LDS_BYTES, 0, S.p);
+    HIP_OK(hipEventRecord(S.e1));
+    HIP_OK(hipEventSynchronize(S.e1));
+    float ms = 0;
+    HIP_OK(hipEventElapsedTime(&ms, S.e0, S.e1));
+    std::vector<uint32_t> ho((size_t)S.grid * threads);
+    HIP_OK(hipMemcpy(ho.data(), S.p.out, ho.size() * 4, hipMemcpyDeviceToHost));
+    uint32_t got = 0;
+    for (uint32_t x : ho) got += x;
+    return got == S.want ? ms / reps : -1.f;
+}
+
+extern "C" void probe_k2_free() {
+    ProbeState& S = g_ps;
+    if (S.rows) { (void)hipFree(S.rows); (void)hipFree(S.q); (void)hipFree(S.zeros); (void)hipFree(S.p.out); S.rows = nullptr; S.n = 0; }
+}
+
+#ifndef PROBE_K2_SHARED
+int main(int argc, char** argv) {
+    const uint32_t n = (argc > 1 ? (uint32_t)atoll(argv[1]) : 50000000u) / BR * BR;  // whole block tiles (the checksum counts every output)
+    const uint32_t dim = argc > 2 ? (uint32_t)atoi(argv[2]) : 768u;
+    const uint32_t nq = argc > 3 ? (uint32_t)atoi(argv[3]) : 256u;
+    const int reps = argc > 4 ? atoi(argv[4]) : 5;
+    const std::string variants = argc > 5 ? argv[5] : "8,8n,8ns,8p,8np,4,4n,4p";
+    if (probe_setup(n, dim, nq)) {
+        fprintf(stderr, "nq must be a multiple of 256, dim of 16\n");
+        return 2;
+    }
+    const P& p = g_ps.p;
     printf("rows %u x %u int8, %u queries: %u x %u block tiles of 256 x 256, %u k-tiles, grid %u; %.2f GB of rows, %.3e ops\n", n, dim, nq,
-           p.ntiles, p.mtiles, p.KT, grid, (double)n * dim / 1e9, 2.0 * nq * (double)n * dim);
-    hipEvent_t e0, e1;
-    HIP_OK(hipEventCreate(&e0));
-    HIP_OK(hipEventCreate(&e1));
-    struct V {
-        const char* name;
-        void (*fn)(P);
-        int threads;
-    };
-    std::vector<V> vs;
+           p.ntiles, p.mtiles, p.KT, g_ps.grid, (double)n * dim / 1e9, 2.0 * nq * (double)n * dim);
+    std::vector<std::string> vs;
     for (size_t a = 0; a <= variants.size();) {
         size_t b = variants.find(',', a);
         if (b == std::string::npos) b = variants.size();
-        const std::string t = variants.substr(a, b - a);
-        if (t == "8") vs.push_back({"W8  (8 waves, 128x64, two per SIMD; shipped)", &kloop_kernel<8, false>, 512});
-        if (t == "4") vs.push_back({"W4  (4 waves, 128x128, one per SIMD)", &kloop_kernel<4, false>, 256});
-        if (t == "4p") vs.push_back({"W4P (W4 + mid-tile barrier, fragments prefetched)", &kloop_kernel<4, true>, 256});
+        vs.push_back(variants.substr(a, b - a));
         a = b + 1;
     }
-    for (auto& v : vs) HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(v.fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
-    for (int round = 0; round < 2; round++) {  // interleaved: the boxes' clocks drift
+    for (int round = 0; round < 3; round++) {  // interleaved: the boxes' clocks drift; round 0 warms up
         for (auto& v : vs) {
-            HIP_OK(hipMemset(p.out, 0, (size_t)grid * 512 * 4));
-            hipLaunchKernelGGL(v.fn, dim3(grid), dim3(v.threads), LDS_BYTES, 0, p);  // warm-up
-            HIP_OK(hipDeviceSynchronize());
-            HIP_OK(hipEventRecord(e0));
-            for (int r = 0; r < reps; r++) hipLaunchKernelGGL(v.fn, dim3(grid), dim3(v.threads), LDS_BYTES, 0, p);
-            HIP_OK(hipEventRecord(e1));
-            HIP_OK(hipEventSynchronize(e1));
-            float ms = 0;
-            HIP_OK(hipEventElapsedTime(&ms, e0, e1));
-            ms /= reps;
-            std::vector<uint32_t> ho((size_t)grid * v.threads);
-            HIP_OK(hipMemcpy(ho.data(), p.out, ho.size() * 4, hipMemcpyDeviceToHost));
-            uint32_t got = 0;
-            for (uint32_t x : ho) got += x;
-            printf("%-52s %8.3f ms  %6.3f POP/s  %5.2f TB/s  checksum %s\n", v.name, ms, 2.0 * nq * (double)n * dim / (ms * 1e-3) / 1e15,
-                   (double)n * dim / (ms * 1e-3) / 1e12, got == want ? "ok" : "WRONG");
+            int threads; const char* name;
+            if (!variant_fn(v, &threads, &name)) continue;
+            const float ms = probe_k2_run(n, dim, nq, round ? reps : 1, v.c_str());
+            if (round == 0) continue;
+            printf("%-66s %8.3f ms  %6.3f POP/s  %5.2f TB/s  checksum %s\n", name, ms, 2.0 * nq * (double)n * dim / (ms * 1e-3) / 1e15,
+                   (double)n * dim / (ms * 1e-3) / 1e12, ms > 0 ? "ok" : "WRONG");
             fflush(stdout);
         }
     }
     return 0;
 }
+#endif
