@@ -60,7 +60,8 @@ constexpr int waitcnt_imm(int vm, int lgkm) { return (vm & 0xF) | ((vm >> 4) << 
 // fragment) instead of in front of the group, where hipcc's lgkmcnt(0) -- the only LDS wait it emits while an LDS-DMA is
 // pending -- covered the read just issued.
 // PRIO: waves 4..7 (the second-dispatched partner on every SIMD) run at s_setprio 1.
-template <int NW, bool PIPE, bool FA = false, bool PRIO = false>
+// U2 (PIPE only): the k-loop unrolled by two, the two B-fragment sets swapping roles -- no register copies at a k-tile's end.
+template <int NW, bool PIPE, bool FA = false, bool PRIO = false, bool U2 = false>
 __global__ void __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) kloop_kernel(P p) {
     constexpr int WN = NW == 8 ? 4 : 2;              // waves along the rows; 2 along the queries
     constexpr int WQ = 128, WR = BR / WN;            // wave tile
@@ -202,52 +203,63 @@ __global__ void __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) kloop_kernel(P p) {
         // one barrier per k-tile, in the MIDDLE: [groups 0..3 of k-tile g on the fragments read during k-tile g-1]
         // wait(k-tile g+1 landed) barrier [groups 4..7, reading k-tile g+1's B fragments and first A fragment underneath;
         // DMA of k-tile g+3 into the stage k-tile g-1 used: every wave is past its reads of that stage at this barrier]
-        u32x4 fbc[NJ], fa[2];
+        u32x4 fbc[NJ], fbd[NJ], fa[2];
 #pragma unroll
         for (int j = 0; j < NJ; j++) fbc[j] = read_b(smem, j);
         fa[0] = read_a(smem, 0);
-        {
-            for (uint32_t g = 0; g < G; g++) {
-                const unsigned char* st = smem + cs * STAGE_B;
-                const uint32_t ns = cs + 1 == NSTAGE ? 0 : cs + 1;
-                const unsigned char* stn = smem + ns * STAGE_B;
-                u32x4 fbn[NJ];
+        // one k-tile: multiplies with the B fragments in `cur`, leaves the next k-tile's in `nxt`; the A fragments alternate
+        // fa[0] / fa[1] and NI is even, so every k-tile starts on fa[0]
+        auto ktile_p = [&](u32x4 (&cur)[NJ], u32x4 (&nxt)[NJ]) __attribute__((always_inline)) {
+            const unsigned char* st = smem + cs * STAGE_B;
+            const uint32_t ns = cs + 1 == NSTAGE ? 0 : cs + 1;
+            const unsigned char* stn = smem + ns * STAGE_B;
 #pragma unroll
-                for (int i = 0; i < NI; i++) {
-                    if (i == NI / 2) {
-                        __builtin_amdgcn_s_waitcnt(waitcnt_imm(PIECES, 15));  // k-tile g+1's pieces have landed; only k-tile g+2's may still be in flight
-                        asm volatile("" ::: "memory");
-                        __builtin_amdgcn_s_barrier();
-                        asm volatile("" ::: "memory");
-                    }
-                    auto reads = [&]() __attribute__((always_inline)) {
-                        if (i + 1 < NI) fa[(i + 1) & 1] = read_a(st, i + 1);
-                        else fa[(i + 1) & 1] = read_a(stn, 0);  // the next k-tile's first A fragment
-                        if (i >= NI / 2) {  // the next k-tile's B fragments, NJ / (NI / 2) per group
-#pragma unroll
-                            for (int j = 0; j < NJ / (NI / 2); j++) fbn[(i - NI / 2) * (NJ / (NI / 2)) + j] = read_b(stn, (i - NI / 2) * (NJ / (NI / 2)) + j);
-                        }
-                    };
-                    if (!FA) reads();
-#pragma unroll
-                    for (int j = 0; j < NJ; j++) {
-                        mfma1(acc[i][j], fa[i & 1], fbc[j]);
-                        if (FA && j == 0) {
-                            __builtin_amdgcn_sched_barrier(0);
-                            reads();
-                        }
-                    }
-                    if (i >= NI / 2) {  // all of the k-tile's DMA pieces behind the barrier, PIECES / (NI / 2) per group
-#pragma unroll
-                        for (int q = 0; q < PIECES / (NI / 2); q++) dma_piece(ds, (PIECES / (NI / 2)) * (i - NI / 2) + q);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
+            for (int i = 0; i < NI; i++) {
+                if (i == NI / 2) {
+                    __builtin_amdgcn_s_waitcnt(waitcnt_imm(PIECES, 15));  // k-tile g+1's pieces have landed; only k-tile g+2's may still be in flight
+                    asm volatile("" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                    asm volatile("" ::: "memory");
                 }
+                auto reads = [&]() __attribute__((always_inline)) {
+                    if (i + 1 < NI) fa[(i + 1) & 1] = read_a(st, i + 1);
+                    else fa[(i + 1) & 1] = read_a(stn, 0);  // the next k-tile's first A fragment
+                    if (i >= NI / 2) {  // the next k-tile's B fragments, NJ / (NI / 2) per group
 #pragma unroll
-                for (int j = 0; j < NJ; j++) fbc[j] = fbn[j];
-                dma_advance();
-                cs = ns;
-                ds = ds + 1 == NSTAGE ? 0 : ds + 1;
+                        for (int j = 0; j < NJ / (NI / 2); j++) nxt[(i - NI / 2) * (NJ / (NI / 2)) + j] = read_b(stn, (i - NI / 2) * (NJ / (NI / 2)) + j);
+                    }
+                };
+                if (!FA) reads();
+#pragma unroll
+                for (int j = 0; j < NJ; j++) {
+                    mfma1(acc[i][j], fa[i & 1], cur[j]);
+                    if (FA && j == 0) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        reads();
+                    }
+                }
+                if (i >= NI / 2) {  // all of the k-tile's DMA pieces behind the barrier, PIECES / (NI / 2) per group
+#pragma unroll
+                    for (int q = 0; q < PIECES / (NI / 2); q++) dma_piece(ds, (PIECES / (NI / 2)) * (i - NI / 2) + q);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            dma_advance();
+            cs = ns;
+            ds = ds + 1 == NSTAGE ? 0 : ds + 1;
+        };
+        if constexpr (U2) {
+            uint32_t g = 0;
+            for (; g + 2 <= G; g += 2) {
+                ktile_p(fbc, fbd);
+                ktile_p(fbd, fbc);
+            }
+            if (g < G) ktile_p(fbc, fbd);
+        } else {
+            for (uint32_t g = 0; g < G; g++) {
+                ktile_p(fbc, fbd);
+#pragma unroll
+                for (int j = 0; j < NJ; j++) fbc[j] = fbd[j];
             }
         }
     }
@@ -302,6 +314,7 @@ static void (*variant_fn(const std::string& t, int* threads, const char** name))
     if (t == "8n") { *name = "W8N (W8, next A fragment requested behind the group's first MFMA)"; return &kloop_kernel<8, false, true>; }
     if (t == "8p") { *name = "W8P (W8, mid-tile barrier, next k-tile's fragments read under the second half)"; return &kloop_kernel<8, true>; }
     if (t == "8np") { *name = "W8NP (W8P + fragment requests behind the group's first MFMA)"; return &kloop_kernel<8, true, true>; }
+    if (t == "8np2") { *name = "W8NP2 (W8NP, k-loop unrolled by two: the fragment sets swap roles)"; return &kloop_kernel<8, true, true, false, true>; }
     if (t == "8ns") { *name = "W8NS (W8N + waves 4..7 at s_setprio 1)"; return &kloop_kernel<8, false, true, true>; }
     *threads = 256;
     if (t == "4") { *name = "W4  (4 waves, 128x128, one per SIMD)"; return &kloop_kernel<4, false>; }
