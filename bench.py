@@ -326,9 +326,10 @@ def cfg5_sharded_leg(args, rank, local_rank, world, backend, dist, torch, G, Sha
         if world > 1:
             dist.barrier()
         threads = oracle.set_threads(max(1, min(16, oracle.cpus_granted()["granted"] // world)))
-        if rows <= 12_500_000 and (world == 1 or threads >= 8):
+        # (the 100M-row corpus on ONE GPU -- the strong leg's N = 1 point -- is checked with two queries: ~80 s on 16 threads)
+        if (rows <= 12_500_000 and (world == 1 or threads >= 8)) or (world == 1 and threads >= 8):
             t1 = time.perf_counter()
-            sel = [0, nq // 3, 2 * nq // 3, nq - 1]
+            sel = [0, nq // 3, 2 * nq // 3, nq - 1] if rows <= 12_500_000 else [nq // 3, nq - 1]
             mine = oracle_topk_rows(oracle, lo, rows, dim, dtype, metric, dq.cpu().numpy()[sel], k)
             parts = [mine]
             if world > 1:
