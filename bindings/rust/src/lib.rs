@@ -124,6 +124,7 @@ fn elem_size(dt: DataType) -> Result<usize> {
 pub struct GpuCorpus {
     handle: *mut MvfGpuCorpus,
     dimension: u32,
+    rows: u64,
     float32: bool,
 }
 
@@ -145,7 +146,7 @@ impl GpuCorpus {
         if rc != 0 {
             return Err(status_to_error(rc));
         }
-        Ok(Self { handle, dimension: space.dimension(), float32: space.data_type().0 == DataType::Float32.0 })
+        Ok(Self { handle, dimension: space.dimension(), rows: total, float32: space.data_type().0 == DataType::Float32.0 })
     }
 
     /// k best rows for one f32 query, best first: (index, score).
@@ -175,7 +176,8 @@ impl GpuCorpus {
         let d = self.dimension as usize;
         let mut scores = vec![0f32; k];
         let mut indices = vec![0u64; k];
-        let mut rows = vec![0f32; k * d];
+        // one query: the library writes the first min(k, rows) payload rows only (include/mvf_gpu.h)
+        let mut rows = vec![0f32; k.min(self.rows as usize) * d];
         let rc = unsafe {
             mvfgpu_search_fetch(self.handle, metric.0, query.as_ptr() as *const c_void, DataType::Float32.0,
                                 query.len() as u32, 1, k as u32, scores.as_mut_ptr(), indices.as_mut_ptr(),

@@ -26,6 +26,7 @@
 // the space declares, not the example's hard-wired Euclidean distance.
 #pragma once
 
+#include <algorithm>
 #include <cstdint>
 #include <cstring>
 #include <stdexcept>
@@ -297,7 +298,11 @@ public:
         std::vector<float> scores(k);
         std::vector<uint64_t> idx(k);
         const size_t es = dt_ == DataType::Float32 ? 4 : 2;
-        std::vector<uint8_t> rows(with_vectors ? k * dim_ * es : 0);
+        // one query: the library writes the first min(k, rows) payload rows only (include/mvf_gpu.h) -- any k, as the reference takes
+        mvfgpu_corpus_info info{};
+        info.struct_size = sizeof info;
+        detail::check_gpu(mvfgpu_corpus_get_info(c_, &info));
+        std::vector<uint8_t> rows(with_vectors ? std::min<uint64_t>(k, info.rows) * dim_ * es : 0);
         if (with_vectors)  // the k best and their rows in one call
             detail::check_gpu(mvfgpu_search_fetch(c_, (uint8_t)metric_, query.data(), MVF_DTYPE_FLOAT32, (uint32_t)query.size(), 1, (uint32_t)k,
                                                   scores.data(), idx.data(), nullptr, rows.data()));

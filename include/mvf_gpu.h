@@ -253,9 +253,12 @@ int mvfgpu_search(const mvfgpu_corpus* corpus, uint8_t metric,
                   uint64_t* out_indices, int32_t* out_raw);
 
 /*
- * The same search, returning the payload as well: out_vectors = host [nq][k][dimension] in the space's stored type
- * (zero rows behind a short result list) -- what the reference's ScoredVector.vector holds
- * (examples/similarity_search.rs:18, :159-163).  The rows are gathered on the device behind the search, from the result
+ * The same search, returning the payload as well: out_vectors = host [nq][k][dimension] in the space's stored type -- what
+ * the reference's ScoredVector.vector holds (examples/similarity_search.rs:18, :159-163).  Only the first min(k, rows of the
+ * corpus) rows of each query's k are WRITTEN (a padding result among them -- deleted rows -- gives a zero row); the rows behind
+ * them, whose results are always padding, are left untouched: k far beyond the corpus (the reference takes any k and returns
+ * min(k, n) items) costs min(k, n) rows per query on the device and in the copies, and with nq = 1 a buffer of min(k, rows)
+ * rows is enough.  The rows are gathered on the device behind the search, from the result
  * indices where the selection kernel left them: one submission and one wait instead of mvfgpu_search +
  * mvfgpu_corpus_gather_rows.  Small results (rows and results <= 256 KiB, positions not ids) need no gather kernel at all:
  * the final select copies its query's k rows behind the results and the call waits on the flag it stores last (10k x 128 f32,
@@ -439,7 +442,8 @@ int mvfgpu_set_scan_path(mvfgpu_corpus* corpus, int path);
  * The tuning switches of the environment (MVF_K1_G, MVF_K1_RANK_MERGE, MVF_K2_*, MVF_I8_SHADOW, MVF_F16_SHADOW, MVF_QS_REFINE,
  * MVF_STREAM_*, MVF_REPAIR_WINDOW, MVF_UPLOAD_THREADS, MVF_HOST_ZC_*, MVF_HOST_FLAG_WAIT, MVF_LARGE_K, MVF_DEBUG_REPAIR; INTEGRATION.md lists them) are read ONCE per
  * handle, when it is created: a search never calls getenv.  An A/B script that changes the environment of a live handle
- * calls this to have it read again.
+ * calls this to have it read again.  A development aid: it waits for the handle's host-buffer searches, but
+ * mvfgpu_search_device reads the switches unlocked -- do not call it beside device-pointer searches of the same handle.
  */
 int mvfgpu_corpus_reload_tuning(mvfgpu_corpus* corpus);
 

@@ -125,11 +125,13 @@ def gpu() -> C.CDLL:
     lib.mvfgpu_corpus_reload_tuning.argtypes = [vp]
     lib.mvfgpu_selftest_feedback.argtypes = [vp, u32, vp]
     lib.mvfgpu_selftest_route.argtypes = [u64, u32, u8, u8, u32, u32, vp]
-    lib.mvfgpu_abi_version.restype = u32
-    lib.mvfgpu_abi_version.argtypes = []
-    if lib.mvfgpu_abi_version() != ABI_VERSION:
-        raise ImportError(f"{GPU_LIB_PATH} speaks ABI version {lib.mvfgpu_abi_version()}, this binding was written against "
-                          f"{ABI_VERSION} (include/mvf_gpu.h MVFGPU_ABI_VERSION): rebuild the library")
+    abi = getattr(lib, "mvfgpu_abi_version", None)  # a library from before round 4 has no such symbol: the same advice, not an AttributeError
+    if abi is not None:
+        abi.restype = u32
+        abi.argtypes = []
+    if abi is None or abi() != ABI_VERSION:
+        raise ImportError(f"{GPU_LIB_PATH} speaks ABI version {abi() if abi else '< 3 (no mvfgpu_abi_version)'}, this binding was written "
+                          f"against {ABI_VERSION} (include/mvf_gpu.h MVFGPU_ABI_VERSION): rebuild the library")
     for name in ("mvfgpu_device_count", "mvfgpu_corpus_create", "mvfgpu_corpus_create_ex", "mvfgpu_corpus_create_synthetic",
                  "mvfgpu_corpus_set_tombstones", "mvfgpu_corpus_set_vector_ids", "mvfgpu_shardset_create",
                  "mvfgpu_shardset_get_info", "mvfgpu_shardset_search", "mvfgpu_shardset_last_timing",

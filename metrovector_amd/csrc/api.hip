@@ -139,6 +139,19 @@ Tuning read_tuning() {
 }
 }  // namespace mvf
 
+// search_host's request to the search it is about to enqueue: "store `seq` to `flag` behind your results if your last kernel
+// can" (the streaming path's final select); `armed` comes back true if it will.  Handed to search_device (below) explicitly and
+// kept in the handle (flag_req) while that call holds the handle's lock.
+struct HostFlagReq {
+    uint32_t* flag;
+    uint32_t* ticket;
+    uint32_t seq;
+    bool armed;
+    uint64_t gen;  // the handle's work_gen of this search
+    unsigned char* gather_out;  // mvfgpu_search_fetch: the final select copies the payload rows here too (pinned host memory); NULL = none
+    bool gathered;              // ... and did, for every query
+};
+
 struct mvfgpu_corpus {
     int device = 0;
     uint64_t n = 0, index_base = 0;
@@ -197,6 +210,7 @@ struct mvfgpu_corpus {
     mutable PinBuf pin_flag;
     mutable DevBuf done_ticket;
     mutable uint32_t flag_seq = 0;
+    mutable HostFlagReq* flag_req = nullptr;  // the host-buffer call's request to the search being enqueued (set and read under mu)
     mutable uint64_t work_gen = 0, confirmed_gen = ~0ull;  // searches enqueued on the handle / the newest one seen complete through the flag
     mutable PinBuf pin_q, pin_out, pin_vec;  // ... and its pinned host mirrors (small queries / results / payload rows: no copy engine at all)
     mutable DevBuf h_v;                   // payload rows of mvfgpu_search_fetch too large for that
@@ -334,7 +348,9 @@ int scan_occupancy(const mvfgpu_corpus* c, const void* kfn, size_t lds, int* occ
             *occ_out = e.second;
             return MVF_OK;
         }
-    if (lds > 48 * 1024) HIP_TRY(hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    // the attribute is only ever RAISED: to the part's ceiling, once per kernel and handle (set to this miss's size, a later hit at a
+    // larger size the cache already knew would launch above it -- a runtime that enforces the attribute would refuse the launch)
+    if (lds > 48 * 1024) HIP_TRY(hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     int occ = 0;
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kfn, 256, lds));
     if (occ < 1) occ = 1;
@@ -343,18 +359,6 @@ int scan_occupancy(const mvfgpu_corpus* c, const void* kfn, size_t lds, int* occ
     return MVF_OK;
 }
 
-// search_host's request to the search it is about to make ON THIS THREAD: "store `seq` to `flag` behind your results if your
-// last kernel can" (the streaming path's final select); `armed` comes back true if it will.
-struct HostFlagReq {
-    uint32_t* flag;
-    uint32_t* ticket;
-    uint32_t seq;
-    bool armed;
-    uint64_t gen;  // the handle's work_gen of this search
-    unsigned char* gather_out;  // mvfgpu_search_fetch: the final select copies the payload rows here too (pinned host memory); NULL = none
-    bool gathered;              // ... and did, for every query
-};
-thread_local HostFlagReq* t_flag_req = nullptr;
 
 int search_stream_path(const mvfgpu_corpus* c, uint8_t metric, const void* d_queries, uint32_t nq, uint32_t k,
                        float* d_scores, uint64_t* d_indices, int32_t* d_raw, hipStream_t s, bool profile = true,
@@ -505,14 +509,13 @@ int search_stream_path(const mvfgpu_corpus* c, uint8_t metric, const void* d_que
             fp.out_scores = d_scores;
             fp.out_indices = d_indices;
             fp.out_raw = d_raw;
-            for (uint32_t q = 0; q < nq_here; q++) {
-                uint64_t* sorted = rank->a + (size_t)q * c->n;
-                if (c->n > 0) {
-                    size_t tb = rank->tmp_bytes;
-                    HIP_TRY(sort_composites(rank->tmp, &tb, rank->a + (size_t)q * c->n, rank->b + (size_t)q * c->n, (size_t)c->n, &sorted, s));
-                }
-                HIP_TRY(launch_write_sorted(fp, sorted, (uint32_t)c->n, (size_t)(q0 + q) * rank->k_out, s));
+            uint64_t* sorted = rank->a;
+            if (c->n > 0) {  // the pass's queries in one set of launches
+                size_t tb = rank->tmp_bytes;
+                HIP_TRY(sort_composites(rank->tmp, &tb, rank->a, rank->b, (size_t)c->n, (size_t)rank->k_out, &sorted, s, nq_here, (size_t)c->n));
             }
+            for (uint32_t q = 0; q < nq_here; q++)
+                HIP_TRY(launch_write_sorted(fp, sorted + (size_t)q * c->n, (uint32_t)c->n, (size_t)(q0 + q) * rank->k_out, s));
         } else {
             SelectParams fp{};
             fp.lists = static_cast<const uint64_t*>(c->cand.p);
@@ -543,18 +546,18 @@ int search_stream_path(const mvfgpu_corpus* c, uint8_t metric, const void* d_que
                 fp.out_stride = out_stride;
                 fp.out_offset = out_offset;
                 fp.out_floor1 = out_floor1 ? out_floor1 + q0 : nullptr;
-                if (t_flag_req && !out_floor1 && t_flag_req->gather_out && !c->ids.p) {  // payload rows behind the results, by the same block
+                if (c->flag_req && !out_floor1 && c->flag_req->gather_out && !c->ids.p) {  // payload rows behind the results, by the same block
                     fp.gather_rows = c->d_rows;
-                    fp.gather_out = t_flag_req->gather_out + (size_t)q0 * ostride * (c->dim * elem_size(c->dtype));
+                    fp.gather_out = c->flag_req->gather_out + (size_t)q0 * ostride * (c->dim * elem_size(c->dtype));
                     fp.gather_pitch = c->pitch;
                     fp.gather_row_bytes = c->dim * elem_size(c->dtype);
-                    if (q0 + nq_here == nq) t_flag_req->gathered = true;
+                    if (q0 + nq_here == nq) c->flag_req->gathered = true;
                 }
-                if (t_flag_req && !out_floor1 && q0 + nq_here == nq) {  // the search's last kernel
-                    fp.done_flag = t_flag_req->flag;
-                    fp.done_ticket = t_flag_req->ticket;
-                    fp.done_seq = t_flag_req->seq;
-                    t_flag_req->armed = true;
+                if (c->flag_req && !out_floor1 && q0 + nq_here == nq) {  // the search's last kernel
+                    fp.done_flag = c->flag_req->flag;
+                    fp.done_ticket = c->flag_req->ticket;
+                    fp.done_seq = c->flag_req->seq;
+                    c->flag_req->armed = true;
                 }
             }
             HIP_TRY(launch_select_final(fp, nq_here, s));
@@ -1646,7 +1649,7 @@ int search_sorted_k(const mvfgpu_corpus* c, uint8_t metric, const void* d_querie
                     uint64_t* d_indices, int32_t* d_raw, hipStream_t s, bool* no_room) {
     *no_room = false;
     size_t tmp_bytes = 0;
-    if (c->n > 0) HIP_TRY(sort_composites(nullptr, &tmp_bytes, nullptr, nullptr, (size_t)c->n, nullptr, s));
+    if (c->n > 0) HIP_TRY(sort_composites(nullptr, &tmp_bytes, nullptr, nullptr, (size_t)c->n, (size_t)k, nullptr, s, 4, (size_t)c->n));
     tmp_bytes = std::max<size_t>(tmp_bytes, 256);
     RankAll ra{};
     ra.k_out = k;
@@ -1695,21 +1698,24 @@ int search_sorted_k(const mvfgpu_corpus* c, uint8_t metric, const void* d_querie
                               0, &ra);
 }
 
-// Passes or the sort?  Measured in one process on every benchmark shape (profiles/r04_any_k.txt): the sort wins from the
-// second pass on nearly everywhere (10M x 768 f32, k = 16384: 72.6 -> 5.5 ms; four queries: 269 -> 8.0) -- a pass reads the
-// rows again and its 1024-entry lists are heavy (doubly so four queries at a time), the sort moves 8-byte keys only.  Passes
-// keep the one case a model of the two costs gives them: two passes of a batch over a small corpus (10k rows, four queries,
-// k = 2048: 0.14 against 0.17 ms).  The model errs towards the sort: where it is wrong that way the sort loses 4-27 % (two passes
-// of ONE query over 50M 16-byte rows: 2.0 against 2.6 ms), the other way round passes lost 2-4x.
+// Passes or the select + sort?  Measured in one process on every benchmark shape (profiles/r05_any_k.txt; round 4's library
+// sort: profiles/r04_any_k.txt): the sort route wins from the second pass on nearly everywhere (10M x 768 f32, k = 16384:
+// 72.5 -> 4.9 ms; four queries: 272 -> 5.9) -- a pass reads the rows again and its 1024-entry lists are heavy (doubly so four
+// queries at a time), the select moves 8-byte entries only.  Passes keep what a model of the two costs gives them: one or two
+// passes over a SMALL corpus (10k rows, k = 2048: 0.11 against 0.17 ms; four queries: 0.12 against 0.19), where the sort
+// route's chain of a dozen short launches is the larger cost.  The model: a pass = the scan + what its lists cost (~75 us a
+// full 1024-entry pass on corpora that fill the chip, a tenth of it the last, shorter one); the sort route = one dumping scan
+// + ~100 us of launches (+10 per further query of the pass) + 40 bytes of traffic per row and query.
 // MVF_LARGE_K forces one of them (A/B, tests).
 bool large_k_by_sort(const mvfgpu_corpus* c, uint32_t nq, uint32_t k) {
     if (k > MVFGPU_K_BY_PASSES) return true;
     if (c->tune.large_k) return c->tune.large_k == 2;
-    const double npass = (double)((k + MVFGPU_K_PER_PASS - 1) / MVFGPU_K_PER_PASS), scans = nq >= 2 ? (double)((nq + 3) / 4) : 1.0;
-    const double row_bytes = std::max(128.0, (double)c->dim * elem_size(c->dtype));             // short rows scan no faster than 128-byte ones
-    const double pass_us = std::max(40.0, (double)c->n * row_bytes / 5.0e6);                   // 5 TB/s = 5e6 bytes per us
-    const double sort_us = scans * pass_us + (double)nq * (35.0 + (double)c->n / 100.0e3);  // the sort: 0.1-0.9 ms per 10M rows, by how many key bits vary
-    const double passes_us = npass * scans * pass_us * (nq >= 2 ? 2.0 : 1.0);
+    const double full = (double)(k / MVFGPU_K_PER_PASS), partial = (k % MVFGPU_K_PER_PASS) ? 1.0 : 0.0, scans = nq >= 2 ? (double)((nq + 3) / 4) : 1.0;
+    const double row_bytes = std::max(128.0, (double)c->dim * elem_size(c->dtype));  // short rows scan no faster than 128-byte ones
+    const double pass_us = std::max(40.0, (double)c->n * row_bytes / 5.0e6);         // 5 TB/s = 5e6 bytes per us
+    const double lists_us = 75.0 * std::min(1.0, (double)c->n / 500.0e3);
+    const double passes_us = scans * (nq >= 2 ? 2.0 : 1.0) * (full * (pass_us + lists_us) + partial * (pass_us + 0.15 * lists_us));
+    const double sort_us = scans * (pass_us + 100.0 + 10.0 * (double)(std::min(nq, 4u) - 1)) + (double)nq * (double)c->n / 150.0e3;
     return sort_us < passes_us;
 }
 
@@ -2064,9 +2070,21 @@ int mvfgpu_corpus_set_vector_ids(mvfgpu_corpus* c, const void* ids_le, uint64_t 
     return MVF_OK;
 }
 
+namespace {
+int search_device(const mvfgpu_corpus* c, uint8_t metric, const void* d_queries, uint8_t query_dtype, uint32_t query_dim, uint32_t nq,
+                  uint32_t k, float* d_scores, uint64_t* d_indices, int32_t* d_raw, void* hip_stream, HostFlagReq* req);
+}
+
 int mvfgpu_search_device(const mvfgpu_corpus* c, uint8_t metric, const void* d_queries, uint8_t query_dtype,
                          uint32_t query_dim, uint32_t nq, uint32_t k, float* d_scores, uint64_t* d_indices,
                          int32_t* d_raw, void* hip_stream) {
+    return search_device(c, metric, d_queries, query_dtype, query_dim, nq, k, d_scores, d_indices, d_raw, hip_stream, nullptr);
+}
+
+namespace {
+// mvfgpu_search_device, and -- with `req` -- the enqueue step of the host-buffer calls (search_host)
+int search_device(const mvfgpu_corpus* c, uint8_t metric, const void* d_queries, uint8_t query_dtype, uint32_t query_dim, uint32_t nq,
+                  uint32_t k, float* d_scores, uint64_t* d_indices, int32_t* d_raw, void* hip_stream, HostFlagReq* req) {
     int rc = check_query_args(c, metric, d_queries, query_dtype, query_dim, nq, k, d_scores, d_indices);
     if (rc != MVF_OK) return rc;
     DeviceGuard guard(c->device);
@@ -2074,7 +2092,12 @@ int mvfgpu_search_device(const mvfgpu_corpus* c, uint8_t metric, const void* d_q
     hipStream_t s = static_cast<hipStream_t>(hip_stream);
     std::lock_guard<std::mutex> lk(c->mu);
     c->work_gen++;
-    if (t_flag_req) t_flag_req->gen = c->work_gen;
+    struct ReqGuard {  // the request belongs to this call only
+        const mvfgpu_corpus* c;
+        ~ReqGuard() { c->flag_req = nullptr; }
+    } req_guard{c};
+    c->flag_req = req;
+    if (req) req->gen = c->work_gen;
     // the scratch buffers are stream-ordered: a call on another stream waits for the previous one
     if (c->has_done && c->last_stream != s) HIP_TRY(hipStreamWaitEvent(s, c->ev_done, 0));
     mvfgpu_corpus::ProfSlot* wps = nullptr;  // whole-search events: every kernel of this call on the stream
@@ -2148,6 +2171,7 @@ int mvfgpu_search_device(const mvfgpu_corpus* c, uint8_t metric, const void* d_q
     }
     return MVF_OK;  // ev_done: DoneGuard
 }
+}  // namespace
 
 namespace {
 // mvfgpu_search / mvfgpu_search_fetch.  out_vectors (nullable): [nq][k] rows of the corpus in their stored type.
@@ -2165,13 +2189,22 @@ int search_host(const mvfgpu_corpus* c, uint8_t metric, const void* queries, uin
     // 65 -> 30 us per call (profiles/r04_host_api_latency.txt); three staged hipMemcpyAsync of pageable memory cost more
     // than the search.  Larger transfers keep the device mirrors (a kernel reading megabytes over PCIe stalls its blocks).
     const size_t out_bytes = nres * 16;
+    // (queries in place only where the search is short: on a large corpus every block of a pass -- a thousand and more -- would
+    // stage its query over PCIe and the re-scoring waves re-read it uncached; there the pinned copy is mirrored into HBM first,
+    // ~10 us in front of a search of milliseconds)
     const bool zc_q = qbytes <= c->tune.host_zc_query, zc_out = out_bytes <= c->tune.host_zc_results;
+    const bool mirror_q = zc_q && c->n * (uint64_t)c->pitch > (256ull << 20);
     // The payload rows are gathered on the device BEHIND the search, on its stream, from the result indices where the
     // selection kernel left them: one submission and one wait for "the k best and their vectors" (the reference's
     // ScoredVector carries the vector, examples/similarity_search.rs:18).  A corpus that reports vector ids translates
     // them back on the host (mvfgpu_corpus_gather_rows' table), after the search: two steps, as before.
+    // Only the first kv = min(k, rows) results of a query can name a row (the rest is padding): the payload staging holds
+    // [nq][kv] rows -- k = 10^6 on a 10k-row corpus is 10k rows per query, not a million zero rows on the device and the host --
+    // and only those rows of out_vectors ([nq][k] rows) are written.
     const uint32_t row_bytes = c->dim * elem_size(c->dtype);
-    const size_t vec_bytes = nres * row_bytes;
+    const uint32_t kv = (uint32_t)std::min<uint64_t>(k, c->n);
+    const size_t nvec = (size_t)nq * kv;
+    const size_t vec_bytes = nvec * row_bytes;
     const bool zc_vec = vec_bytes <= c->tune.host_zc_results;
     void *dq, *ds, *di, *dr, *dv = nullptr;
     std::lock_guard<std::mutex> host_lk(c->host_mu);
@@ -2186,6 +2219,11 @@ int search_host(const mvfgpu_corpus* c, uint8_t metric, const void* queries, uin
             HIP_TRY(c->pin_q.reserve(qbytes));
             memcpy(c->pin_q.p, queries, qbytes);
             dq = c->pin_q.p;
+            if (mirror_q) {
+                HIP_TRY(c->h_q.reserve(qbytes));
+                dq = c->h_q.p;
+                HIP_TRY(hipMemcpyAsync(dq, c->pin_q.p, qbytes, hipMemcpyHostToDevice, c->own_stream));
+            }
         } else {
             HIP_TRY(c->h_q.reserve(qbytes));
             dq = c->h_q.p;
@@ -2215,7 +2253,8 @@ int search_host(const mvfgpu_corpus* c, uint8_t metric, const void* queries, uin
         }
     }
     HostFlagReq req{};
-    if (zc_out && c->tune.host_flag_wait && (!out_vectors || (fused_fetch && zc_vec))) {
+    bool want_flag = false;
+    if (zc_out && c->tune.host_flag_wait && (!out_vectors || (fused_fetch && zc_vec && kv == k))) {
         std::lock_guard<std::mutex> lk(c->mu);
         if (!c->pin_flag.p) {
             HIP_TRY(c->pin_flag.reserve(64));
@@ -2227,12 +2266,11 @@ int search_host(const mvfgpu_corpus* c, uint8_t metric, const void* queries, uin
         req.ticket = static_cast<uint32_t*>(c->done_ticket.p);
         req.seq = ++c->flag_seq;
         if (req.seq == 0) req.seq = ++c->flag_seq;
-        req.gather_out = out_vectors ? static_cast<unsigned char*>(dv) : nullptr;  // the select copies the payload rows as well
-        t_flag_req = &req;
+        req.gather_out = out_vectors && kv == k ? static_cast<unsigned char*>(dv) : nullptr;  // the select copies the payload rows as well
+        want_flag = true;
     }
-    rc = mvfgpu_search_device(c, metric, dq, query_dtype, query_dim, nq, k, static_cast<float*>(ds),
-                              static_cast<uint64_t*>(di), static_cast<int32_t*>(dr), c->own_stream);
-    t_flag_req = nullptr;
+    rc = search_device(c, metric, dq, query_dtype, query_dim, nq, k, static_cast<float*>(ds), static_cast<uint64_t*>(di),
+                       static_cast<int32_t*>(dr), c->own_stream, want_flag ? &req : nullptr);
     if (rc != MVF_OK) return rc;
     if (req.armed && (!out_vectors || req.gathered)) {
         // the final select writes req.seq behind its results (and the payload rows it copied): spin on it (bounded: a long search falls back to the stream)
@@ -2257,23 +2295,36 @@ int search_host(const mvfgpu_corpus* c, uint8_t metric, const void* queries, uin
         if (out_vectors) memcpy(out_vectors, dv, vec_bytes);
         return MVF_OK;
     }
-    if (fused_fetch)  // padding entries (index UINT64_MAX) give zero rows
-        HIP_TRY(launch_gather_rows(c->d_rows, c->n, c->pitch, row_bytes, c->index_base, static_cast<const uint64_t*>(di), (uint32_t)nres,
-                                   static_cast<unsigned char*>(dv), c->own_stream));
+    if (fused_fetch)  // padding entries (index UINT64_MAX) among a query's first kv results give zero rows
+        HIP_TRY(launch_gather_rows(c->d_rows, c->n, c->pitch, row_bytes, c->index_base, static_cast<const uint64_t*>(di), (uint32_t)nvec,
+                                   static_cast<unsigned char*>(dv), c->own_stream, k, kv));
     if (!zc_out) {
         HIP_TRY(hipMemcpyAsync(out_scores, ds, nres * 4, hipMemcpyDeviceToHost, c->own_stream));
         HIP_TRY(hipMemcpyAsync(out_indices, di, nres * 8, hipMemcpyDeviceToHost, c->own_stream));
         if (out_raw) HIP_TRY(hipMemcpyAsync(out_raw, dr, nres * 4, hipMemcpyDeviceToHost, c->own_stream));
     }
-    if (fused_fetch && !zc_vec) HIP_TRY(hipMemcpyAsync(out_vectors, dv, vec_bytes, hipMemcpyDeviceToHost, c->own_stream));
+    if (fused_fetch && !zc_vec) {
+        if (kv == k) HIP_TRY(hipMemcpyAsync(out_vectors, dv, vec_bytes, hipMemcpyDeviceToHost, c->own_stream));
+        else HIP_TRY(hipMemcpy2DAsync(out_vectors, (size_t)k * row_bytes, dv, (size_t)kv * row_bytes, (size_t)kv * row_bytes, nq,
+                                      hipMemcpyDeviceToHost, c->own_stream));
+    }
     HIP_TRY(hipStreamSynchronize(c->own_stream));
     if (zc_out) {
         memcpy(out_scores, ds, nres * 4);
         memcpy(out_indices, di, nres * 8);
         if (out_raw) memcpy(out_raw, dr, nres * 4);
     }
-    if (fused_fetch && zc_vec) memcpy(out_vectors, dv, vec_bytes);
-    if (out_vectors && !fused_fetch) return gather_rows_host_locked(c, out_indices, nres, out_vectors);
+    if (fused_fetch && zc_vec)
+        for (uint32_t q = 0; q < nq; q++)
+            memcpy(static_cast<unsigned char*>(out_vectors) + (size_t)q * k * row_bytes, static_cast<unsigned char*>(dv) + (size_t)q * kv * row_bytes,
+                   (size_t)kv * row_bytes);
+    if (out_vectors && !fused_fetch) {  // vector ids: mapped back on the host, query by query (the first kv results each)
+        if (kv == k) return gather_rows_host_locked(c, out_indices, nres, out_vectors);
+        for (uint32_t q = 0; q < nq; q++) {
+            rc = gather_rows_host_locked(c, out_indices + (size_t)q * k, kv, static_cast<unsigned char*>(out_vectors) + (size_t)q * k * row_bytes);
+            if (rc != MVF_OK) return rc;
+        }
+    }
     return MVF_OK;
 }
 }  // namespace
@@ -2373,7 +2424,7 @@ int merge_topk_device_impl(const float* d_scores, const uint64_t* d_indices, con
     }
     // the sort's buffers live for this call only, in stream order (this entry point has no handle to keep them in)
     size_t tmp_bytes = 0;
-    HIP_TRY(sort_composites(nullptr, &tmp_bytes, nullptr, nullptr, (size_t)total, nullptr, s));
+    HIP_TRY(sort_composites(nullptr, &tmp_bytes, nullptr, nullptr, (size_t)total, (size_t)p.k, nullptr, s));
     tmp_bytes = std::max<size_t>(tmp_bytes, 256);
     const size_t cb = ((size_t)total * 8 + 255) & ~(size_t)255;
     void* scratch = nullptr;
@@ -2385,7 +2436,7 @@ int merge_topk_device_impl(const float* d_scores, const uint64_t* d_indices, con
         uint64_t* sorted = a;
         size_t tb = tmp_bytes;
         e = launch_merge_build(p, q, a, s);
-        if (e == hipSuccess) e = sort_composites(tmp, &tb, a, b, (size_t)total, &sorted, s);
+        if (e == hipSuccess) e = sort_composites(tmp, &tb, a, b, (size_t)total, (size_t)p.k, &sorted, s);
         if (e == hipSuccess) e = launch_merge_write(p, q, sorted, s);
     }
     const hipError_t ef = hipFreeAsync(scratch, s);
@@ -2494,6 +2545,9 @@ int mvfgpu_set_scan_path(mvfgpu_corpus* c, int path) {
 
 int mvfgpu_corpus_reload_tuning(mvfgpu_corpus* c) {
     if (!c) return fail(MVF_ERR_INVALID_ARGUMENT, "corpus is NULL");
+    // host_mu first (search_host's order): the host-buffer searches read c->tune under it, without c->mu.  Device-pointer
+    // searches (mvfgpu_search_device) read the switches unlocked: do not call this beside them (include/mvf_gpu.h).
+    std::lock_guard<std::mutex> host_lk(c->host_mu);
     std::lock_guard<std::mutex> lk(c->mu);
     c->tune = mvf::read_tuning();
     choose_group(c->V, 1, &c->G, &c->J, c->tune.k1_g);

@@ -83,16 +83,20 @@ hipError_t launch_merge_write(const ShardMergeParams& p, uint32_t q, const uint6
 // result row of a query from the ascending composites of ALL its rows (sort_topk.hip); reads metric, dtype, index_base, ids,
 // out_*, k of `p`; the row starts at element out_base of the output arrays
 hipError_t launch_write_sorted(const SelectParams& p, const uint64_t* sorted, uint32_t n, size_t out_base, hipStream_t s);
-// device-wide sort of n rank entries (mvf_common.h: position << 32 | key) that arrive in ascending position: a stable rocPRIM radix
-// sort of the key half = the order of the composites (key << 32 | position); stream-ordered, no host wait.
-// tmp == NULL: only *tmp_bytes is written.  The sorted keys end up in `a` or `b` (the other is scratch): *sorted says which.
-hipError_t sort_composites(void* tmp, size_t* tmp_bytes, uint64_t* a, uint64_t* b, size_t n, uint64_t** sorted, hipStream_t s);
+// The first min(k, n) of n rank entries (mvf_common.h: position << 32 | key) that arrive in ascending position, in the order of
+// their composites (key << 32 | position): radix select of the k-th key + position-ordered compaction, then a sort of the
+// survivors -- one block's LDS up to 16384, a stable LSD radix sort of the key half beyond (sort_topk.hip; hand-written, no
+// library).  Stream-ordered, no host wait.  tmp == NULL: only *tmp_bytes is written.  The result ends up in `a` or `b` (the
+// other is scratch): *sorted says which.
+hipError_t sort_composites(void* tmp, size_t* tmp_bytes, uint64_t* a, uint64_t* b, size_t n, size_t k, uint64_t** sorted, hipStream_t s,
+                           uint32_t nb = 1, size_t stride = 0);  // nb lists of the same n and k, list l at a + l stride / b + l stride
 hipError_t launch_synth_rows(unsigned char* rows, uint64_t n, uint32_t dim, uint32_t pitch, uint8_t dtype,
                              uint64_t seed, uint64_t row0, hipStream_t s);
 hipError_t launch_repack_rows(const unsigned char* src, unsigned char* dst, uint64_t n, uint32_t row_bytes,
                               uint64_t src_stride, uint32_t pitch, hipStream_t s);
 hipError_t launch_gather_rows(const unsigned char* rows, uint64_t n, uint32_t pitch, uint32_t row_bytes, uint64_t index_base,
-                              const uint64_t* d_idx, uint32_t count, unsigned char* d_out, hipStream_t s);
+                              const uint64_t* d_idx, uint32_t count, unsigned char* d_out, hipStream_t s,
+                              uint32_t idx_stride = 0, uint32_t per_list = 0);  // per_list != 0: out row i = d_idx[(i / per_list) * idx_stride + i % per_list]
 hipError_t launch_synth_packed(void* out, uint64_t nelem, uint8_t dtype, uint64_t seed, hipStream_t s);
 
 }  // namespace mvf

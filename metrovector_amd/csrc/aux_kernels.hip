@@ -398,12 +398,12 @@ __global__ void repack_rows_kernel(const unsigned char* src, unsigned char* dst,
 template <typename T>  // the copy unit: 16 bytes when the row size allows it (stored rows start on 16-byte pitches), else 4 or 1
 __global__ void __launch_bounds__(256) gather_rows_kernel(const unsigned char* rows, uint64_t n, uint32_t pitch,
                                                            uint32_t row_bytes, uint64_t index_base, const uint64_t* idx,
-                                                           uint32_t count, unsigned char* out) {
+                                                           uint32_t count, unsigned char* out, uint32_t idx_stride, uint32_t per_list) {
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = (blockIdx.x * 256u + threadIdx.x) >> 6, nwaves = (gridDim.x * 256u) >> 6;
     const uint32_t units = row_bytes / (uint32_t)sizeof(T);
     for (uint32_t i = wave; i < count; i += nwaves) {
-        const uint64_t g = idx[i];
+        const uint64_t g = idx[(size_t)(i / per_list) * idx_stride + i % per_list];  // out row i = entry i % per_list of list i / per_list
         const bool ok = g >= index_base && g - index_base < n;
         const T* src = reinterpret_cast<const T*>(rows + (ok ? (g - index_base) : 0) * pitch);
         T* dst = reinterpret_cast<T*>(out + (size_t)i * row_bytes);
@@ -487,13 +487,14 @@ hipError_t launch_repack_rows(const unsigned char* src, unsigned char* dst, uint
 }
 
 hipError_t launch_gather_rows(const unsigned char* rows, uint64_t n, uint32_t pitch, uint32_t row_bytes, uint64_t index_base,
-                              const uint64_t* d_idx, uint32_t count, unsigned char* d_out, hipStream_t s) {
+                              const uint64_t* d_idx, uint32_t count, unsigned char* d_out, hipStream_t s, uint32_t idx_stride, uint32_t per_list) {
     if (count == 0) return hipSuccess;
+    if (per_list == 0) idx_stride = per_list = count;  // one list
     const uint32_t blocks = std::min<uint32_t>((count + 3) / 4, 2048u);
     const uint64_t al = row_bytes | reinterpret_cast<uintptr_t>(d_out);
-    if (al % 16 == 0) hipLaunchKernelGGL(gather_rows_kernel<uint4>, dim3(blocks), dim3(256), 0, s, rows, n, pitch, row_bytes, index_base, d_idx, count, d_out);
-    else if (al % 4 == 0) hipLaunchKernelGGL(gather_rows_kernel<uint32_t>, dim3(blocks), dim3(256), 0, s, rows, n, pitch, row_bytes, index_base, d_idx, count, d_out);
-    else hipLaunchKernelGGL(gather_rows_kernel<unsigned char>, dim3(blocks), dim3(256), 0, s, rows, n, pitch, row_bytes, index_base, d_idx, count, d_out);
+    if (al % 16 == 0) hipLaunchKernelGGL(gather_rows_kernel<uint4>, dim3(blocks), dim3(256), 0, s, rows, n, pitch, row_bytes, index_base, d_idx, count, d_out, idx_stride, per_list);
+    else if (al % 4 == 0) hipLaunchKernelGGL(gather_rows_kernel<uint32_t>, dim3(blocks), dim3(256), 0, s, rows, n, pitch, row_bytes, index_base, d_idx, count, d_out, idx_stride, per_list);
+    else hipLaunchKernelGGL(gather_rows_kernel<unsigned char>, dim3(blocks), dim3(256), 0, s, rows, n, pitch, row_bytes, index_base, d_idx, count, d_out, idx_stride, per_list);
     return hipGetLastError();
 }
 

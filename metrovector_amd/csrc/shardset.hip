@@ -135,7 +135,7 @@ struct mvfgpu_shardset {
         *p = nullptr;
         *have = 0;
         need = (need + 4095) & ~(size_t)4095;
-        hipError_t e = hipHostMalloc(p, need, hipHostMallocPortable);
+        hipError_t e = hipHostMalloc(p, need, hipHostMallocPortable | hipHostMallocMapped | hipHostMallocCoherent);  // coherent like api.hip's PinBuf: kernels on every device read / write it in place
         if (e == hipSuccess) *have = need;
         return e;
     }

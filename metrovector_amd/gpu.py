@@ -195,7 +195,7 @@ class GpuCorpus:
         sc = np.empty((nq, k), np.float32)
         idx = np.empty((nq, k), np.uint64)
         raw = np.empty((nq, k), np.int32)
-        vec = np.empty((nq, k, dim), _NP_OF[dt])
+        vec = np.zeros((nq, k, dim), _NP_OF[dt])  # zeros, not empty: the library writes min(k, rows) rows per query; untouched pages stay unmapped
         _lib.gpu_check(_lib.gpu().mvfgpu_search_fetch(self._h, metric, q.ctypes.data_as(C.c_void_p), qcode, qdim, nq, k,
                                                       sc.ctypes.data_as(C.c_void_p), idx.ctypes.data_as(C.c_void_p),
                                                       raw.ctypes.data_as(C.c_void_p), vec.ctypes.data_as(C.c_void_p)))

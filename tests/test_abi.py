@@ -209,11 +209,14 @@ def test_the_route_of_a_search_is_a_function_of_its_shape():
     assert [_route(300_000, 768, U8, L2, nq, 10) for nq in (4, 8, 9)] == [K1, K1, K2]                    # 230 MB
     assert [_route(1_000_000, 128, I8, IP, nq, 10) for nq in (4, 8)] == [K1, K2]                         # 128 MB of 128-byte rows
     assert [_route(50_000_000, 768, I8, IP, nq, 100) for nq in (1, 2)] == [K1, K2]                       # 38 GB: from two queries on
-    # k beyond one pass: the sort from the second pass on nearly everywhere, passes for a two-pass batch on a small corpus,
-    # the sort alone beyond 16384
+    # k beyond one pass: the select + sort from the second pass on nearly everywhere, passes for one or two passes over a small
+    # corpus (profiles/r05_any_k.txt: 10k x 128, k = 2048: 0.11 against 0.17 ms; four queries 0.12 against 0.19), the sort
+    # route alone beyond 16384
     assert _route(10_000_000, 768, F32, COS, 1, 1025) == SORT and _route(10_000_000, 768, F32, COS, 4, 16384) == SORT
     assert _route(10_000, 128, F32, L2, 4, 2048) == PASSES and _route(10_000, 128, F32, L2, 4, 4096) == SORT
-    assert _route(10_000, 128, F32, L2, 1, 1025) == SORT
+    assert _route(10_000, 128, F32, L2, 1, 1025) == PASSES and _route(10_000, 128, F32, L2, 1, 2048) == PASSES
+    assert _route(10_000, 128, F32, L2, 1, 4096) == SORT
+    assert _route(1_000_000, 128, F32, L2, 1, 2048) == SORT and _route(20_000_000, 64, I8, IP, 1, 1025) == SORT
     assert _route(10_000, 128, F32, L2, 1, 16385) == SORT and _route(60, 4, F32, L2, 300, 1 << 20) == SORT
     # refused shapes
     out = C.c_uint32(0)

@@ -44,3 +44,38 @@ def test_cfg5_100m_x_1024_f16_l2_eight_shards_vs_one_handle_vs_the_oracle_over_a
     all_sc = oracle_scores_all_rows(oracle, SEED, 0, n, dim, 1, 0, q[sel], chunk=500_000)
     for j, qi in enumerate(sel):
         assert_float_topk(0, one.scores[qi], one.indices[qi], all_sc[j], None, q[qi], k)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Part 2 -- mvfgpu_search_fetch with k far beyond the corpus: the reference takes any k and returns min(k, n)
+# items (examples/similarity_search.rs:143, :159-168); the payload staging is min(k, rows) rows per query, not k.
+# ---------------------------------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("with_ids", [False, True])
+def test_search_fetch_with_k_far_beyond_the_corpus(oracle, with_ids):
+    n, dim, k, nq = 300, 64, 200_000, 3
+    rows = oracle.synth_rows(SEED + 3, 0, n, dim, 0)
+    q = oracle.synth_queries(SEED + 4, nq, dim, 0)
+    dead = np.zeros(n, bool)
+    dead[::7] = True
+    with G.GpuCorpus.from_array(rows) as c:
+        before = c.info().device_bytes
+        if with_ids:
+            c.set_vector_ids(np.arange(n, dtype=np.uint64) * 3 + 11)
+        c.set_tombstones(np.packbits(dead, bitorder="little"))
+        res, vec = c.search_fetch(q, k, G.L2)
+        grown = c.info().device_bytes - before
+    live = np.nonzero(~dead)[0]
+    sc, idx, _ = oracle.search(rows[live], 0, 0, q, len(live))
+    want = live[idx.astype(np.int64)]
+    assert vec.shape == (nq, k, dim) and res.indices.shape == (nq, k)
+    for qi in range(nq):
+        got = res.indices[qi][:len(live)].astype(np.int64)
+        pos = (got - 11) // 3 if with_ids else got
+        assert (pos == want[qi]).all()
+        assert np.allclose(res.scores[qi][:len(live)], sc[qi], rtol=1e-5)
+        assert (res.indices[qi][len(live):] == np.uint64(0xFFFFFFFFFFFFFFFF)).all()
+        assert (vec[qi][:len(live)] == rows[pos]).all()
+        assert not vec[qi][len(live):].any()  # padding results: rows left as the caller allocated them (zeros here)
+    # 3 queries x 200k results x 256 B = 154 MB of zero rows if the staging were sized by k; min(k, rows) rows are 230 KB
+    assert grown < 64 << 20, f"{grown} bytes of scratch for a 300-row corpus"
