@@ -374,6 +374,13 @@ def cfg5_sharded_leg(args, rank, local_rank, world, backend, dist, torch, G, Sha
             leg["f16_selection_at_every_n"] = forced
         if tm.samples and tm.scan_ms_avg > 0 and tm.scan_kernel >= 2:
             leg["roofline"] = mfma_roofline(tm, dtype)
+            tp = os.path.join(ROOT, "profiles", "r05_cfg5_hbm_traffic.json")  # a 12.5M-row shard through the int8 shadow: HBM bytes of a whole search
+            if rows == 12_500_000 and int(tm.scan_kernel) == 6 and os.path.exists(tp) and "whole_search" in leg["roofline"]:
+                prof = json.load(open(tp))
+                leg["roofline"]["whole_search"]["traffic"] = prof.get("search_traffic_bytes")
+                leg["roofline"]["whole_search"]["algorithmic_bytes"] = prof.get("algorithmic_bytes_per_search")
+                leg["roofline"]["whole_search"]["traffic_source"] = ("profiles/r05_cfg5_hbm_traffic.json (separate --pmc passes, FETCH_SIZE x2 + WRITE_SIZE over the "
+                                                                     "search's kernels: the shadow rows once, the re-scored f16 rows, the candidate records)")
         if recall:
             leg.update(recall)
     corpus.close()
@@ -530,7 +537,7 @@ def cfg4_leg(args, torch, G, _lib, oracle, local_rank):
                              "hbm_frac": tm.scan_bytes / (tm.scan_ms_avg * 1e-3) / 1e9 / HBM_PEAK_GBS,
                              "mfma_frac": tm.scan_flops / (tm.scan_ms_avg * 1e-3) / 1e12 / MFMA_I8_PEAK_TOPS,
                              "scan_launches_per_search": tm.scan_launches}
-    tp = os.path.join(ROOT, "profiles", "r04_cfg4_hbm_traffic.json")
+    tp = os.path.join(ROOT, "profiles", "r05_cfg4_hbm_traffic.json")
     if not os.path.exists(tp):
         tp = os.path.join(ROOT, "profiles", "r03_cfg4_hbm_traffic.json")
     if os.path.exists(tp):
@@ -889,7 +896,7 @@ def main():
         # wide streaming reads on gfx950 + WRITE_SIZE, MI355X_MICROARCH.md §HBM), so the figure is the committed
         # summary of those passes for this exact workload, not a live measurement.
         if "roofline" in result:
-            for name in ("r04_bench_n1_hbm_traffic.json", "r03_bench_n1_hbm_traffic.json", "r02_bench_n1_hbm_traffic.json"):
+            for name in ("r05_bench_n1_hbm_traffic.json", "r04_bench_n1_hbm_traffic.json", "r03_bench_n1_hbm_traffic.json"):
                 tp = os.path.join(ROOT, "profiles", name)
                 if not os.path.exists(tp) or result["roofline"].get("traffic"):
                     continue
@@ -1066,11 +1073,11 @@ def main():
                 if tmb.samples and tmb.scan_ms_avg > 0 and tmb.scan_kernel >= 2:
                     leg["roofline"] = mfma_roofline(tmb, args.dtype)
                     # HBM bytes per launch from the committed PMC passes of this exact workload and kernel
-                    tp = os.path.join(ROOT, "profiles", {2: "r04_bench_n1_q1024_hbm_traffic.json",
-                                                         4: "r04_bench_n1_q1024_shadow_hbm_traffic.json",
-                                                         6: "r04_bench_n1_q1024_i8_shadow_hbm_traffic.json"}.get(tmb.scan_kernel, "-"))
+                    tp = os.path.join(ROOT, "profiles", {2: "r05_bench_n1_q1024_hbm_traffic.json",
+                                                         4: "r05_bench_n1_q1024_shadow_hbm_traffic.json",
+                                                         6: "r05_bench_n1_q1024_i8_shadow_hbm_traffic.json"}.get(tmb.scan_kernel, "-"))
                     if not os.path.exists(tp):
-                        tp = tp.replace("r04_", "r03_")
+                        tp = tp.replace("r05_", "r04_")
                     if os.path.exists(tp):
                         leg["roofline"]["traffic"] = json.load(open(tp))["roofline_traffic_bytes_per_launch"]
                         leg["roofline"]["traffic_source"] = "profiles/" + os.path.basename(tp)
