@@ -383,8 +383,49 @@ def cfg5_sharded_leg(args, rank, local_rank, world, backend, dist, torch, G, Sha
                                                                      "search's kernels: the shadow rows once, the re-scored f16 rows, the candidate records)")
         if recall:
             leg.update(recall)
+    ref_idx = out[1].cpu().numpy().view(np.uint64) if (strong and world == 1 and rank == 0 and not args.no_shardset) else None
     corpus.close()
+    if ref_idx is not None:
+        try:
+            leg["as_eight_handles_in_one_shard_set"] = strong_as_shard_set(args, torch, G, dq, total_rows, dim, dtype, metric, nq, k, local_rank, ref_idx)
+        except Exception as e:  # the extra must not cost the leg
+            leg["as_eight_handles_in_one_shard_set"] = {"error": f"{type(e).__name__}: {e}"[:300]}
     return leg
+
+
+def strong_as_shard_set(args, torch, G, dq, total_rows, dim, dtype, metric, nq, k, device, ref_idx):
+    """The strong leg's N = 1 corpus once more, as the 8-way split north_star names held by ONE GPU: eight row-range handles
+    in one mvfgpu_shardset (lists by device copies).  A 204.8-GB handle has no room for its int8 selection shadow; eight
+    25.6-GB handles build theirs one after the other until HBM runs out -- the shards that got one select at the int8 MFMA
+    rate, the rest on their stored f16 rows, and the merged result must be the single handle's, bit for bit."""
+    n_sh = 8
+    rows = total_rows // n_sh
+    if rows * n_sh != total_rows:
+        return {"skipped": "the corpus does not split into eight equal shards"}
+    hq = dq.cpu().numpy()
+    shards = []
+    try:
+        for i in range(n_sh):
+            c = G.GpuCorpus.synthetic(rows, dim, dtype, SEED, row0=i * rows, device=device)
+            shards.append(c)
+            c.search(hq[:8], k, metric)  # a batched search: norms, and the int8 shadow if it still fits (one shard at a time: no race for the last GB)
+        with_shadow = [bool(c.info().shadows & 1) for c in shards]
+        steps, warmup = 3, 1
+        with G.ShardSet(shards) as ss:
+            for _ in range(warmup):
+                res = ss.search(hq, k, metric)
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                res = ss.search(hq, k, metric)
+            elapsed = time.perf_counter() - t0
+            tm = ss.last_timing()
+        return {"what": "mvfgpu_shardset_search over eight 12.5M-row handles on ONE device (host queries in, merged host results out; lists by device copies)",
+                "ms_per_step": elapsed / steps * 1e3, "value": float(nq) * total_rows * steps / elapsed, "unit": "distance-ops/s",
+                "shards_with_int8_shadow": int(sum(with_shadow)), "shard_search_ms": [float(tm.shard_search_ms[i]) for i in range(n_sh)],
+                "indices_identical_to_the_single_handle": bool((res.indices == ref_idx).all())}
+    finally:
+        for c in shards:
+            c.close()
 
 
 def free_port():
