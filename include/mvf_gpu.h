@@ -81,7 +81,8 @@ typedef struct mvfgpu_corpus_info {
     uint32_t pitch_bytes; /* device row pitch: dimension*elem_size rounded up to 16 */
     uint8_t data_type;    /* enum mvf_data_type */
     uint8_t has_vector_ids; /* 1 when vector ids are attached (searches then report ids, not positions) */
-    uint8_t shadows;      /* bit 0: the int8 selection shadow is resident, bit 1: the scaled-f16 one */
+    uint8_t shadows;      /* bit 0: the int8 selection shadow is resident (all rows), bit 1: the scaled-f16 one, bit 2: an int8
+                             shadow of a PREFIX of the rows (all rows did not fit: batched searches run as two row ranges) */
     uint8_t selection_state; /* bit 0: the repair feedback has switched the int8-shadow selection off for this corpus,
                                 bit 1: it has switched the folded pre-filter of the int8 kernels off */
     uint32_t reserved2;

@@ -122,6 +122,8 @@ Tuning read_tuning() {
     t.k2_tile = tile == 0 ? 0 : tile == 64 ? 64 : tile == 128 ? 128 : 256;
     t.f16_shadow = flag("MVF_F16_SHADOW", true);
     t.i8_shadow = flag("MVF_I8_SHADOW", true);
+    t.i8_shadow_partial = flag("MVF_I8_SHADOW_PARTIAL", true);
+    t.i8_shadow_rows = (uint64_t)std::max(0l, num("MVF_I8_SHADOW_ROWS", 0));
     t.qs_refine = flag("MVF_QS_REFINE", true);
     t.debug_repair = getenv("MVF_DEBUG_REPAIR") != nullptr;
     t.repair_window = (uint32_t)std::max(0l, num("MVF_REPAIR_WINDOW", 0));
@@ -180,7 +182,9 @@ struct mvfgpu_corpus {
     mutable std::vector<std::pair<uint64_t, uint32_t>> id_index;  // ... and, built by the first gather, (id, row) sorted by id
     mutable int shadow_state = 0;         // 0 not built yet, 1 ready, -1 unavailable (no memory)
     mutable DevBuf shadow8, xscale8, qs_stats;  // Float32 / Float16 corpora: int8 shadow rows, s_r per row, the 4 bound maxima
-    mutable int shadow8_state = 0;
+    mutable int shadow8_state = 0;             // 0 not tried, 1 all rows, 2 a PREFIX of the rows (shadow8_rows; batched path only), -1 no room for all rows, -2 none for a useful prefix either
+    mutable uint64_t shadow8_rows = 0;         // rows the int8 shadow covers
+    mutable DevBuf split_out;                  // partial shadow: the two row ranges' result lists before their merge
     // feedback for the automatic choice: after a search that selected on the int8 shadow the number of queries the
     // repair launches had to redo is copied to pinned host memory (no wait); a later search that finds it large
     // (the data defeats the int8 bound: near-duplicates everywhere, heavy-tailed rows) switches this corpus back to the
@@ -655,15 +659,27 @@ constexpr uint32_t kBatchCapQS = 8192;  // candidate slots per query with int8 s
 constexpr uint32_t kQsMaxK = kBatchCapQS / 2 / 10;        // batched: 4096 kept candidates per query
 constexpr uint32_t kQsStreamMaxK = kBatchCap / 2 / 10;    // streamed (select_final's margin mode): 2048
 
-bool qs_wanted(const mvfgpu_corpus* c, uint32_t k = 0) {
+// everything but the shadow's own state
+bool qs_possible(const mvfgpu_corpus* c, uint32_t k) {
     if (is_int_dtype(c->dtype) || c->n == 0) return false;
     if (k > kQsMaxK) return false;
     if (!k2_dma_enabled(c)) return false;  // the register-staged A/B kernel (MVF_K2_DMA=0) has no int8-shadow flavour
     if ((size_t)((c->dim + 7u) & ~7u) * 4 + kBatchCapQS * 4 > 64 * 1024) return false;  // re-scoring: query + candidates in LDS
     if (c->scan_path == 5 || c->scan_path == 6) return true;
     if (c->scan_path != 0 && c->scan_path != 4) return false;
-    if (c->qs_disabled || c->shadow8_state < 0) return false;
-    return c->tune.i8_shadow;
+    return !c->qs_disabled && c->tune.i8_shadow;
+}
+
+bool qs_wanted(const mvfgpu_corpus* c, uint32_t k = 0) {
+    if (!qs_possible(c, k)) return false;
+    return c->scan_path == 5 || c->scan_path == 6 || c->shadow8_state >= 0;
+}
+
+// The batched path alone can live with a shadow of a PREFIX of the rows (search_batched_path): where all rows did not fit
+// (state -1) it still asks, once, for what does.
+bool qs_wanted_batched(const mvfgpu_corpus* c, uint32_t k) {
+    if (!qs_possible(c, k)) return false;
+    return c->scan_path == 5 || c->scan_path == 6 || c->shadow8_state >= 0 || (c->shadow8_state == -1 && c->tune.i8_shadow_partial);
 }
 
 // The decision itself, a pure function of the sequence of samples (mvfgpu_selftest_feedback runs it without a GPU).
@@ -728,30 +744,50 @@ int qs_feedback_post(const mvfgpu_corpus* c, uint32_t nq, hipStream_t s, bool us
     return MVF_OK;
 }
 
-hipError_t ensure_shadow8(const mvfgpu_corpus* c, hipStream_t s, bool insist) {
+// allow_partial (the batched path): where all rows do not fit beside the corpus, shadow the longest PREFIX of rows that does
+// (a 204.8-GB Float16 corpus has no room for its 102.4-GB shadow, but for 90+ % of it on this part): the search then runs
+// as two row ranges -- int8 selection over the prefix, the f16 kernels over the rest -- whose lists are merged like two
+// shards' (search_batched_path).  At least a quarter of the rows and a million, 4 GiB left free for the scratch buffers.
+hipError_t ensure_shadow8(const mvfgpu_corpus* c, hipStream_t s, bool insist, bool allow_partial = false) {
     if (c->shadow8_state == -1 && insist) c->shadow8_state = 0;
-    if (c->shadow8_state != 0) return hipSuccess;
-    const size_t need = (size_t)std::max<uint64_t>(c->n, 1) * shadow8_pitch(c->dim);
-    if (!insist) {
+    if (c->shadow8_state > 0 || c->shadow8_state == -2 || (c->shadow8_state == -1 && !allow_partial)) return hipSuccess;
+    const size_t pitch8 = shadow8_pitch(c->dim);
+    uint64_t rows = std::max<uint64_t>(c->n, 1);
+    const uint64_t forced = c->tune.i8_shadow_rows && c->tune.i8_shadow_rows < c->n ? c->tune.i8_shadow_rows : 0;  // tests
+    if (c->shadow8_state == 0 && !insist) {
         size_t free_b = 0, total_b = 0;
-        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < need + ((size_t)2 << 30)) {
-            c->shadow8_state = -1;
+        if (forced || hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < rows * pitch8 + ((size_t)2 << 30)) c->shadow8_state = -1;
+    }
+    if (c->shadow8_state == -1) {
+        if (!allow_partial || !c->tune.i8_shadow_partial) return hipSuccess;
+        size_t free_b = 0, total_b = 0;
+        uint64_t fit = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > ((size_t)4 << 30)) fit = ((free_b - ((size_t)4 << 30)) / (pitch8 + 4)) & ~(uint64_t)65535;
+        if (fit >= c->n) fit = c->n;  // (memory was freed meanwhile)
+        if (forced) fit = std::min(fit, forced);
+        else if (fit < c->n / 4 || fit < (1u << 20)) fit = 0;
+        if (fit == 0) {
+            c->shadow8_state = -2;
             return hipSuccess;
         }
+        rows = fit;
     }
-    if (c->shadow8.reserve(need) != hipSuccess || c->xscale8.reserve(((size_t)std::max<uint64_t>(c->n, 1) + 256) * 4) != hipSuccess ||
+    if (c->shadow8.reserve(rows * pitch8) != hipSuccess || c->xscale8.reserve(((size_t)rows + 256) * 4) != hipSuccess ||
         c->qs_stats.reserve(16) != hipSuccess) {
         (void)hipGetLastError();
         c->shadow8.release();
         c->xscale8.release();
-        c->shadow8_state = -1;
+        c->shadow8_state = c->shadow8_state == -1 ? -2 : -1;
         return hipSuccess;
     }
     hipError_t e = hipMemsetAsync(c->qs_stats.p, 0, 16, s);
     if (e == hipSuccess)
-        e = launch_shadow_i8(c->d_rows, c->dtype, (uint32_t)c->n, c->pitch, c->dim, static_cast<unsigned char*>(c->shadow8.p),
-                             shadow8_pitch(c->dim), static_cast<float*>(c->xscale8.p), static_cast<float*>(c->qs_stats.p), s);
-    if (e == hipSuccess) c->shadow8_state = 1;
+        e = launch_shadow_i8(c->d_rows, c->dtype, (uint32_t)rows, c->pitch, c->dim, static_cast<unsigned char*>(c->shadow8.p),
+                             (uint32_t)pitch8, static_cast<float*>(c->xscale8.p), static_cast<float*>(c->qs_stats.p), s);
+    if (e == hipSuccess) {
+        c->shadow8_rows = rows;
+        c->shadow8_state = rows == std::max<uint64_t>(c->n, 1) ? 1 : 2;
+    }
     return e;
 }
 
@@ -906,19 +942,27 @@ int repair_flagged_queries(const mvfgpu_corpus* c, uint8_t metric, const void* d
 // compaction between them (scan_mfma.hip for Float32 rows, scan_mfma16.hip for
 // Float16 / Int8 rows).  Asynchronous: queries whose candidate budget overflowed are
 // redone exactly by K1 in repair launches that decide on the device whether to run.
-int search_batched_path(const mvfgpu_corpus* c, uint8_t metric, const void* d_queries, uint32_t nq, uint32_t k,
-                        float* d_scores, uint64_t* d_indices, int32_t* d_raw, hipStream_t s) {
+// One ROW RANGE [lo, hi) of the corpus (the whole of it, or one of the two ranges of a corpus whose int8 shadow covers a prefix
+// of the rows: search_batched_path below).  allow_qs: the range may select on the int8 shadow (it lies inside it).  defer: the
+// caller merges this range's lists with the other's first and runs the repair of flagged queries / the feedback itself --
+// what it needs for that comes back in *dr.  profile: this range's last phase is the one the handle's timing reports.
+struct BatchedDeferred {
+    uint32_t* overflow = nullptr;
+    uint32_t nq_pad = 0;
+    bool used_bias = false, used_qs = false;
+};
+int search_batched_range(const mvfgpu_corpus* c, uint8_t metric, const void* d_queries, uint32_t nq, uint32_t k,
+                         float* d_scores, uint64_t* d_indices, int32_t* d_raw, hipStream_t s, uint64_t lo, uint64_t hi, bool allow_qs,
+                         bool defer, bool profile, BatchedDeferred* dr) {
     // Float32 rows: either the exact f32 MFMA kernel on the rows themselves, or -- 4x faster -- the f16 kernel on a
     // scaled-f16 SHADOW copy that only selects candidates (error bound below); the kept rows are re-scored from the
     // f32 rows and the f32 query either way, so results do not depend on which one ran.
     bool use_shadow = false, use_qs = false;
     const bool rescore_fits = (size_t)((c->dim + 7u) & ~7u) * 4 + kBatchCap * 4 <= 64 * 1024;  // query + candidates in LDS
-    qs_feedback_poll(c);
-    if (qs_wanted(c, k)) {  // int8 shadow: selection at the int8 MFMA rate (Float32 and Float16 corpora)
+    if (allow_qs && qs_wanted(c, k)) {  // int8 shadow: selection at the int8 MFMA rate (Float32 and Float16 corpora)
         int rc = ensure_norms(c, s);
         if (rc != MVF_OK) return rc;
-        HIP_TRY(ensure_shadow8(c, s, c->scan_path == 5 || c->scan_path == 6));
-        use_qs = c->shadow8_state == 1;
+        use_qs = c->shadow8_state == 1 || (c->shadow8_state == 2 && hi <= c->shadow8_rows);  // built by the caller
     }
     if (!use_qs && c->dtype == MVF_DTYPE_FLOAT32 && c->scan_path != 2 && (c->scan_path == 3 || shadow_enabled(c)) && rescore_fits) {
         HIP_TRY(ensure_shadow(c, s, c->scan_path == 3));
@@ -939,7 +983,8 @@ int search_batched_path(const mvfgpu_corpus* c, uint8_t metric, const void* d_qu
     const uint32_t KPB = KT * ktb;                         // prepared query row, bytes
     const uint32_t planes = 1u;
     const uint32_t cap = use_qs ? kBatchCapQS : kBatchCap;
-    const uint32_t n = (uint32_t)c->n;
+    const uint32_t n = (uint32_t)c->n;          // the corpus: layout of the norm arrays
+    const uint64_t nr = hi - lo;                // the range: what the phases cover
 
     HIP_TRY(c->bq.reserve((size_t)planes * nq_pad * KPB + (size_t)nq_pad * 12 + 64));
     unsigned char* qprep = static_cast<unsigned char*>(c->bq.p);
@@ -1072,14 +1117,14 @@ int search_batched_path(const mvfgpu_corpus* c, uint8_t metric, const void* d_qu
     mvfgpu_timing tm{};
     tm.scan_kernel = wide ? 2u : use_qs ? 6u : use_shadow ? 4u : 3u;
     mvfgpu_corpus::ProfSlot* ps = nullptr;
-    if (c->profiling) {
+    if (c->profiling && profile) {
         ps = &c->prof[c->prof_next % mvfgpu_corpus::kProfSlots];
         for (auto& e : ps->e)
             if (!e) HIP_TRY(hipEventCreate(&e));
         ps->scanned = false;
     }
 
-    // Phase p scans rows [R_p, R_{p+1}); phase 0 passes everything (no threshold yet: R_1 <= cap rows, stored by row
+    // Phase p scans rows [R_p, R_{p+1}) of the range; phase 0 passes everything (no threshold yet: R_1 <= cap rows, stored by row
     // offset), later phases grow by g: expected survivors per query k (g - 1) + k carried <= cap / 2.  The boundaries are
     // laid out BACKWARDS from the corpus' end -- R_j = n / g^(P - j), P the fewest steps that bring R_1 under cap -- so every
     // phase, the last one included, scans (g - 1) times what its threshold has seen, and the last phase is always the
@@ -1089,25 +1134,25 @@ int search_batched_path(const mvfgpu_corpus* c, uint8_t metric, const void* d_qu
     std::vector<uint64_t> bounds;  // R_1 .. R_{P+1} = n
     {
         uint32_t P = 0;
-        for (uint64_t f = n; f > cap; f = (f + g - 1) / g) P++;
+        for (uint64_t f = nr; f > cap; f = (f + g - 1) / g) P++;
         for (uint32_t j = 0; j <= P; j++) {
             uint64_t div = 1;
             for (uint32_t i = j; i < P; i++) div *= g;
-            uint64_t e = (n + div - 1) / div;
-            e = std::min<uint64_t>(n, (e + 255) / 256 * 256);
+            uint64_t e = (nr + div - 1) / div;
+            e = std::min<uint64_t>(nr, (e + 255) / 256 * 256);
             if (j == 0) e = std::min<uint64_t>(e, cap);  // the direct phase's slots are row offsets
             if (bounds.empty() || e > bounds.back()) bounds.push_back(e);
         }
-        if (bounds.empty() || bounds.back() < n) bounds.push_back(n);
+        if (bounds.empty() || bounds.back() < nr) bounds.push_back(nr);
     }
     size_t bi = 0;
     uint64_t begin = 0, end = bounds[0];
     bool regions_armed = false, used_bias = false;
     for (;;) {
-        const bool last = end >= n;
+        const bool last = end >= nr;
         if (end > begin) {
-            bp.row_begin = hp.row_begin = (uint32_t)begin;
-            bp.row_end = hp.row_end = (uint32_t)end;
+            bp.row_begin = hp.row_begin = (uint32_t)(lo + begin);
+            bp.row_end = hp.row_end = (uint32_t)(lo + end);
             bp.ntiles = hp.ntiles = (uint32_t)((end - begin + tile_rows - 1) / tile_rows);
             bp.direct = hp.direct = (begin == 0 && end - begin <= cap) ? 1u : 0u;
             const bool regions = hp.blk_cand && !hp.direct;
@@ -1154,7 +1199,7 @@ int search_batched_path(const mvfgpu_corpus* c, uint8_t metric, const void* d_qu
         if (approx) HIP_TRY(launch_compact_margin(cp, nq, s));
         else HIP_TRY(launch_compact(cp, nq, last, s));
         if (last) break;
-        if (refine && bounds[bi + 1] >= n && n - end >= kRefineMinRows) {  // worth its ~0.1 ms in front of the last (largest) phase
+        if (refine && bounds[bi + 1] >= nr && nr - end >= kRefineMinRows) {  // worth its ~0.1 ms in front of the last (largest) phase
             RescoreParams rp{};
             rp.cand = bp.cand;
             rp.cnt = cnt;
@@ -1172,7 +1217,7 @@ int search_batched_path(const mvfgpu_corpus* c, uint8_t metric, const void* d_qu
         end = bounds[++bi];
     }
     if (approx) {  // exact scores of the kept candidates from the caller's f32 queries, final top-k
-        if (refine && n >= kRefineMinRows) {  // once more on the final lists: the re-scoring skips what falls outside
+        if (refine && nr >= kRefineMinRows) {  // once more on the final lists: the re-scoring skips what falls outside
             RescoreParams fp{};
             fp.cand = bp.cand;
             fp.cnt = cnt;
@@ -1210,9 +1255,54 @@ int search_batched_path(const mvfgpu_corpus* c, uint8_t metric, const void* d_qu
         c->prof_next++;
     }
 
+    if (dr) {
+        dr->overflow = overflow;
+        dr->nq_pad = std::max(dr->nq_pad, nq_pad);
+        dr->used_bias |= used_bias;
+        dr->used_qs |= use_qs && c->scan_path != 5 && c->scan_path != 6;
+    }
+    if (defer) return MVF_OK;
     int rc = repair_flagged_queries(c, metric, d_queries, nq, nq_pad, k, overflow, d_scores, d_indices, d_raw, s);
     if (rc == MVF_OK && ((use_qs && c->scan_path != 5 && c->scan_path != 6) || used_bias))
         rc = qs_feedback_post(c, nq, s, used_bias, use_qs && c->scan_path != 5 && c->scan_path != 6);
+    return rc;
+}
+
+int merge_topk_device_impl(const float* d_scores, const uint64_t* d_indices, const int32_t* d_raw, size_t ls_scores, size_t ls_indices,
+                           size_t ls_raw, uint32_t nlists, uint32_t nq, uint32_t k, uint8_t metric, uint8_t data_type, float* d_out_scores,
+                           uint64_t* d_out_indices, int32_t* d_out_raw, int device, void* hip_stream);
+
+// The batched search of a corpus.  Usually ONE range, all rows.  A Float32 / Float16 corpus whose int8 selection shadow does
+// not fit beside it as a whole (the 100M x 1024 Float16 corpus of BASELINE configs[4] on one GPU: 204.8 GB of rows, 102.4 GB of
+// shadow) gets a shadow of the longest prefix of rows that does (ensure_shadow8) and is searched as TWO row ranges -- the
+// prefix by the int8 selection, the rest by the f16 kernels on the stored rows -- whose exact top-k lists are merged like two
+// shards' (the same device merge: ties by ascending position); the repair of flagged queries runs once, behind the merge, over
+// the whole corpus.  100M x 1024 f16, 1024 queries: 181-184 ms -> 95.5 (profiles/r05_partial_shadow.json).
+int search_batched_path(const mvfgpu_corpus* c, uint8_t metric, const void* d_queries, uint32_t nq, uint32_t k,
+                        float* d_scores, uint64_t* d_indices, int32_t* d_raw, hipStream_t s) {
+    qs_feedback_poll(c);
+    if (qs_wanted_batched(c, k)) {
+        int rc = ensure_norms(c, s);
+        if (rc != MVF_OK) return rc;
+        HIP_TRY(ensure_shadow8(c, s, c->scan_path == 5 || c->scan_path == 6, /*allow_partial=*/true));
+    }
+    if (!(c->shadow8_state == 2 && qs_wanted(c, k) && c->shadow8_rows < c->n))
+        return search_batched_range(c, metric, d_queries, nq, k, d_scores, d_indices, d_raw, s, 0, c->n, true, false, true, nullptr);
+    const size_t ls = (size_t)nq * k;
+    HIP_TRY(c->split_out.reserve(2 * ls * 16));
+    unsigned char* t = static_cast<unsigned char*>(c->split_out.p);
+    uint64_t* ti = reinterpret_cast<uint64_t*>(t);                 // [2][nq k]
+    float* ts = reinterpret_cast<float*>(t + 2 * ls * 8);          // [2][nq k]
+    int32_t* tr = reinterpret_cast<int32_t*>(t + 2 * ls * 12);     // [2][nq k]
+    BatchedDeferred dr{};
+    int rc = search_batched_range(c, metric, d_queries, nq, k, ts, ti, tr, s, 0, c->shadow8_rows, true, true, true, &dr);
+    if (rc != MVF_OK) return rc;
+    rc = search_batched_range(c, metric, d_queries, nq, k, ts + ls, ti + ls, tr + ls, s, c->shadow8_rows, c->n, false, true, false, &dr);
+    if (rc != MVF_OK) return rc;
+    rc = merge_topk_device_impl(ts, ti, tr, ls, ls, ls, 2, nq, k, metric, c->dtype, d_scores, d_indices, d_raw, c->device, s);
+    if (rc != MVF_OK) return rc;
+    rc = repair_flagged_queries(c, metric, d_queries, nq, dr.nq_pad, k, dr.overflow, d_scores, d_indices, d_raw, s);
+    if (rc == MVF_OK && (dr.used_qs || dr.used_bias)) rc = qs_feedback_post(c, nq, s, dr.used_bias, dr.used_qs);
     return rc;
 }
 
@@ -1876,6 +1966,7 @@ void mvfgpu_corpus_destroy(mvfgpu_corpus* c) {
         c->xscale.release();
         c->tomb.release();
         c->ids.release();
+        c->split_out.release();
         c->shadow8.release();
         c->xscale8.release();
         c->qs_stats.release();
@@ -1915,10 +2006,10 @@ int mvfgpu_corpus_get_info(const mvfgpu_corpus* c, mvfgpu_corpus_info* out) {
     {
         std::lock_guard<std::mutex> lk(c->mu);
         inf.has_vector_ids = c->ids.p ? 1 : 0;
-        inf.shadows = (uint8_t)((c->shadow8_state == 1 ? 1 : 0) | (c->shadow_state == 1 ? 2 : 0));
+        inf.shadows = (uint8_t)((c->shadow8_state == 1 ? 1 : 0) | (c->shadow_state == 1 ? 2 : 0) | (c->shadow8_state == 2 ? 4 : 0));
         inf.selection_state = (uint8_t)((c->qs_disabled ? 1 : 0) | (c->bias_disabled ? 2 : 0));
         inf.device_bytes = c->tomb.bytes + c->ids.bytes + c->rows_bytes + c->cand.bytes + c->bq.bytes + c->bstate.bytes + c->bcand.bytes +
-                           c->xnorm.bytes + c->repair.bytes + c->floor1.bytes + c->rank_a.bytes + c->rank_b.bytes + c->rank_tmp.bytes + c->blk.bytes + c->shadow8.bytes + c->xscale8.bytes + c->qs_stats.bytes +
+                           c->xnorm.bytes + c->repair.bytes + c->floor1.bytes + c->rank_a.bytes + c->rank_b.bytes + c->rank_tmp.bytes + c->blk.bytes + c->shadow8.bytes + c->xscale8.bytes + c->qs_stats.bytes + c->split_out.bytes +
                            c->shadow.bytes + c->xscale.bytes + c->h_q.bytes + c->h_s.bytes + c->h_i.bytes + c->h_r.bytes + c->h_v.bytes;
     }
     return copy_out_struct(out, inf);

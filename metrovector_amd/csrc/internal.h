@@ -39,6 +39,8 @@ struct Tuning {
     int k2_tile = 0;            // MVF_K2_TILE=64|128|256: force a query-tile shape
     bool f16_shadow = true;     // MVF_F16_SHADOW=0
     bool i8_shadow = true;      // MVF_I8_SHADOW=0
+    bool i8_shadow_partial = true;  // MVF_I8_SHADOW_PARTIAL=0: no int8 shadow of a prefix of the rows where all rows do not fit
+    uint64_t i8_shadow_rows = 0;    // MVF_I8_SHADOW_ROWS=n (tests): as if only the first n rows' shadow fitted
     bool qs_refine = true;      // MVF_QS_REFINE=0
     bool debug_repair = false;  // MVF_DEBUG_REPAIR: report repaired queries on stderr (synchronises inside a search)
     uint32_t repair_window = 0; // MVF_REPAIR_WINDOW: queries per repair launch pair (tests: several windows)

@@ -35,6 +35,14 @@ def test_cfg5_100m_x_1024_f16_l2_eight_shards_vs_one_handle_vs_the_oracle_over_a
     with G.GpuCorpus.synthetic(n, dim, 1, SEED) as c:
         assert c.info().rows == n
         one = c.search(q, k, G.L2)
+        assert not c.info().shadows & 5
+    # the same handle with the default environment (round 5): no room for the int8 shadow of all 100M rows, so a PREFIX of
+    # them is shadowed and the search runs as two row ranges whose lists are merged -- same rows, same score bits
+    monkeypatch.delenv("MVF_I8_SHADOW")
+    with G.GpuCorpus.synthetic(n, dim, 1, SEED) as c:
+        part = c.search(q, k, G.L2)
+        assert c.info().shadows & 4, "expected an int8 shadow of a prefix of the rows beside 204.8 GB of Float16 rows"
+    assert (part.indices == one.indices).all() and (part.scores.view(np.uint32) == one.scores.view(np.uint32)).all()
     assert (merged.indices == one.indices).all(), "merge(top-k per shard) != top-k(one handle)"
     assert (merged.scores.view(np.uint32) == one.scores.view(np.uint32)).all()
     assert merged.indices.max() < n and (np.sort(merged.indices, axis=1)[:, 1:] != np.sort(merged.indices, axis=1)[:, :-1]).all()
@@ -79,3 +87,70 @@ def test_search_fetch_with_k_far_beyond_the_corpus(oracle, with_ids):
         assert not vec[qi][len(live):].any()  # padding results: rows left as the caller allocated them (zeros here)
     # 3 queries x 200k results x 256 B = 154 MB of zero rows if the staging were sized by k; min(k, rows) rows are 230 KB
     assert grown < 64 << 20, f"{grown} bytes of scratch for a 300-row corpus"
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Part 3 -- an int8 selection shadow of a PREFIX of the rows (round 5): a corpus whose shadow does not fit beside it as a
+# whole is searched as two row ranges (int8 selection over the prefix, the f16 / f32 kernels over the rest) whose lists are
+# merged.  MVF_I8_SHADOW_ROWS forces the split on corpora of test size: the answers must be those of the unsplit search, bit
+# for bit, and the oracle's.
+# ---------------------------------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("dt,metric,nq,k", [(1, 0, 300, 10), (1, 2, 70, 100), (0, 1, 257, 25), (0, 2, 1024, 100)])
+def test_int8_shadow_of_a_prefix_of_the_rows_two_ranges_merged(oracle, monkeypatch, dt, metric, nq, k):
+    n, dim = 400_000, 96
+    rows = oracle.synth_rows(SEED + 11, 0, n, dim, dt)
+    q = oracle.synth_queries(SEED + 12, nq, dim, dt)
+    dead = np.zeros(n, bool)
+    dead[5::11] = True
+    ids = (np.arange(n, dtype=np.uint64) * 7 + 3) if metric == 2 else None
+
+    def run(env):
+        for key, val in env.items():
+            monkeypatch.setenv(key, val)
+        with G.GpuCorpus.from_array(rows) as c:
+            c.set_tombstones(np.packbits(dead, bitorder="little"))
+            if ids is not None:
+                c.set_vector_ids(ids)
+            res = c.search(q, k, metric)
+            sh = c.info().shadows
+        for key in env:
+            monkeypatch.delenv(key)
+        return res, sh
+
+    whole, sh_whole = run({})
+    split, sh_split = run({"MVF_I8_SHADOW_ROWS": "262144"})
+    assert sh_whole & 1 and not sh_whole & 4, "the unsplit handle selects on an int8 shadow of all rows"
+    assert sh_split & 4 and not sh_split & 1, "MVF_I8_SHADOW_ROWS shadows a prefix only"
+    assert (split.indices == whole.indices).all()
+    assert (split.scores.view(np.uint32) == whole.scores.view(np.uint32)).all()
+    live = np.nonzero(~dead)[0]
+    sel = [0, nq // 2, nq - 1]
+    rows32 = rows[live].astype(np.float32)
+    for qi in sel:
+        all_sc = oracle.scores(rows[live], dt, metric, q[qi])[0]
+        got = split.indices[qi].astype(np.int64)
+        pos = (got - 3) // 7 if ids is not None else got
+        assert not dead[pos].any()
+        local = np.searchsorted(live, pos)
+        assert_float_topk(metric, split.scores[qi], local.astype(np.uint64), all_sc, rows32, q[qi].astype(np.float32), k)
+
+
+def test_prefix_shadow_with_overflowing_candidate_regions_is_repaired_once_behind_the_merge(oracle, monkeypatch):
+    """Tiny candidate regions overflow in both ranges: the flagged queries are redone exactly over the WHOLE corpus, after
+    the merge (a repair inside a range would return rows of the other range twice)."""
+    n, dim, nq, k = 300_000, 64, 300, 20
+    rows = oracle.synth_rows(SEED + 13, 0, n, dim, 1)
+    q = oracle.synth_queries(SEED + 14, nq, dim, 1)
+    monkeypatch.setenv("MVF_I8_SHADOW_ROWS", "196608")
+    monkeypatch.setenv("MVF_K2_REGION_RECORDS", "4096")
+    with G.GpuCorpus.from_array(rows) as c:
+        res = c.search(q, k, G.COSINE)
+        assert c.info().shadows & 4
+        repaired = c.last_timing().repaired_queries if hasattr(c.last_timing(), "repaired_queries") else None
+    sc, idx, _ = oracle.search(rows, 1, 2, q, k)
+    rec = np.mean([len(set(a.tolist()) & set(b.tolist())) / k for a, b in zip(res.indices, idx)])
+    assert rec >= 0.999, rec
+    assert np.allclose(res.scores, sc, rtol=0, atol=1e-5)
+    for r in res.indices:
+        assert len(set(r.tolist())) == k, "a row returned twice"
