@@ -307,6 +307,7 @@ def cfg5_sharded_leg(args, rank, local_rank, world, backend, dist, torch, G, Sha
         return elapsed, out, tm, per_rank
 
     elapsed, out, tm, per_rank = timed(0)
+    shadow_bits = int(corpus.info().shadows)
     forced = None
     if strong:
         e3, out3, tm3, pr3 = timed(3)
@@ -364,8 +365,11 @@ def cfg5_sharded_leg(args, rank, local_rank, world, backend, dist, torch, G, Sha
                "total_rows": total_rows,
                "rccl_ranks": (dist.get_world_size() if world > 1 and backend == "nccl" else 0),
                "process_group_backend": (dist.get_backend() if world > 1 else None),
-               "selection_path": {3: "f16 MFMA kernel on the stored rows (no room or no use for an int8 shadow)",
-                                  6: "int8 MFMA kernel on the int8 shadow + exact re-scoring"}.get(int(tm.scan_kernel), int(tm.scan_kernel)),
+               "selection_path": ("int8 MFMA kernel on the int8 shadow of a PREFIX of the rows (all rows' shadow does not fit beside them) + the f16 MFMA "
+                                  "kernel on the stored rows of the rest, the two row ranges' exact lists merged; exact re-scoring" if shadow_bits & 4 else
+                                  {3: "f16 MFMA kernel on the stored rows (no room or no use for an int8 shadow)",
+                                   6: "int8 MFMA kernel on the int8 shadow + exact re-scoring"}.get(int(tm.scan_kernel), int(tm.scan_kernel))),
+               "rank0_shadow_bits": shadow_bits,
                "per_rank": [{"rank": r, "rows": p[5], "local_search_ms": p[0], "exchange_merge_ms": p[1], "last_phase_scan_ms": p[2],
                              "search_device_ms": p[3], "scan_kernel": p[4]} for r, p in enumerate(per_rank)],
                "result_check": {"indices_in_range": bool(idx.max() < total_rows), "unique_per_query": bool(
