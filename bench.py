@@ -25,10 +25,11 @@ handles on N devices, the same cfg5 shard shape per device, per-shard searches +
 inside the library; run by rank 0 in a child process after the ranks have released their GPUs.
 
 Fourth leg at EVERY N, `cfg5_strong`: STRONG scaling of the same config -- ONE fixed 100M x 1024 Float16 corpus (204.8 GB:
-it fits one MI355X without a selection shadow) split by row range over the N ranks, value = 1024 * 100M / t at every N, so
-value(N) / value(1) is north_star's ">= 6x at 8 GPUs vs 1".  A 204.8 GB shard has no room for the int8 shadow the smaller
-shards select on, so the leg also runs with the f16 selection forced on every rank (`f16_selection_at_every_n`): that
-pair of numbers compares like with like.
+it fits one MI355X) split by row range over the N ranks, value = 1024 * 100M / t at every N, so value(N) / value(1) is
+north_star's ">= 6x at 8 GPUs vs 1".  A 204.8 GB shard has no room for the int8 shadow of ALL its rows -- since round 5 it
+shadows the ~95M-row prefix that fits and searches the corpus as two row ranges (int8 selection / f16 kernels) whose lists
+are merged -- so the leg also runs with the f16 selection forced on every rank (`f16_selection_at_every_n`): that pair of
+numbers compares like with like.  At N = 1 the same corpus is also searched as eight handles in one shard set.
 
 N = 1 also: `mvf_file_e2e` (a real 4.6 GB two-space .mvf: write, open, upload off the mmap cold and warm, checksum,
 search), `cfg4_int8` (BASELINE.json configs[3]: 50M x 768 Int8 dot, 256 batched queries, top-100; both the HBM and the
@@ -263,8 +264,8 @@ def cfg5_sharded_leg(args, rank, local_rank, world, backend, dist, torch, G, Sha
     reference's serial loop over one corpus (examples/similarity_search.rs:147) sharded by row range; value =
     nq * total_rows / t at every N, so value(N) / value(1) is the speed-up north_star's ">= 6x at 8 GPUs" asks for.
     The selection path a shard takes depends on what fits beside it in HBM (the int8 shadow is +50 % of Float16 rows: a
-    204.8 GB shard cannot hold one and selects on the stored f16 rows), so the strong leg ALSO runs with the f16
-    selection forced (scan path 3) at every N: that pair of numbers compares like with like.
+    204.8 GB shard holds the shadow of a ~95M-row prefix and runs its rest on the stored f16 rows), so the strong leg ALSO
+    runs with the f16 selection forced (scan path 3) at every N: that pair of numbers compares like with like.
     Returns the leg's dict on rank 0 (None elsewhere)."""
     from metrovector_amd.sharded import shard_range
     dim, dtype, metric, nq, k = 1024, 1, 0, 1024, args.k
@@ -399,9 +400,9 @@ def cfg5_sharded_leg(args, rank, local_rank, world, backend, dist, torch, G, Sha
 
 def strong_as_shard_set(args, torch, G, dq, total_rows, dim, dtype, metric, nq, k, device, ref_idx):
     """The strong leg's N = 1 corpus once more, as the 8-way split north_star names held by ONE GPU: eight row-range handles
-    in one mvfgpu_shardset (lists by device copies).  A 204.8-GB handle has no room for its int8 selection shadow; eight
-    25.6-GB handles build theirs one after the other until HBM runs out -- the shards that got one select at the int8 MFMA
-    rate, the rest on their stored f16 rows, and the merged result must be the single handle's, bit for bit."""
+    in one mvfgpu_shardset (lists by device copies).  Eight 25.6-GB handles build their int8 selection shadows one after
+    the other until HBM runs out -- the shards that got one select at the int8 MFMA rate, the rest on their stored f16
+    rows -- and the merged result must be the single handle's, bit for bit."""
     n_sh = 8
     rows = total_rows // n_sh
     if rows * n_sh != total_rows:
