@@ -1775,6 +1775,14 @@ int search_sorted_k(const mvfgpu_corpus* c, uint8_t metric, const void* d_querie
             c->rank_tmp.release();
         }
         if (nqv == 1) {
+            if (c->shadow8_state == 2) {  // a shadow of what fitted took the room: the search the caller asked for comes first
+                HIP_TRY(hipStreamSynchronize(s));  // nothing may still read it
+                c->shadow8.release();
+                c->xscale8.release();
+                c->shadow8_state = -2;
+                c->shadow8_rows = 0;
+                continue;  // once more, one query per pass
+            }
             *no_room = true;
             return fail(MVF_ERR_DEVICE, "no device memory for the whole-shard sort of a large-k search (16 bytes per row)");
         }
