@@ -1288,6 +1288,11 @@ int search_batched_path(const mvfgpu_corpus* c, uint8_t metric, const void* d_qu
     }
     if (!(c->shadow8_state == 2 && qs_wanted(c, k) && c->shadow8_rows < c->n))
         return search_batched_range(c, metric, d_queries, nq, k, d_scores, d_indices, d_raw, s, 0, c->n, true, false, true, nullptr);
+    {   // the per-query state (thresholds, counts, overflow flags) must not be re-allocated between the two ranges -- the second
+        // would lose the first's overflow flags: sized here for the widest query tile either range may take
+        const int brc = ensure_bstate(c, (nq + 255u) & ~255u, s);
+        if (brc != MVF_OK) return brc;
+    }
     const size_t ls = (size_t)nq * k;
     HIP_TRY(c->split_out.reserve(2 * ls * 16));
     unsigned char* t = static_cast<unsigned char*>(c->split_out.p);
