@@ -12,7 +12,7 @@ import pytest
 
 from metrovector_amd import gpu as G
 
-from _util import assert_float_topk, oracle_scores_all_rows
+from _util import assert_exact, assert_float_topk, oracle_scores_all_rows
 
 pytestmark = pytest.mark.gpu
 SEED = 0x4D564631
@@ -154,3 +154,24 @@ def test_prefix_shadow_with_overflowing_candidate_regions_is_repaired_once_behin
     assert np.allclose(res.scores, sc, rtol=0, atol=1e-5)
     for r in res.indices:
         assert len(set(r.tolist())) == k, "a row returned twice"
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Part 4 -- the hand-written select + sorts behind k > 1024 (csrc/sort_topk.hip): the long-list forms that the older tests
+# do not reach -- a select whose survivors exceed 131072 entries (8-bit digit passes with the scan launch) and the sort of a
+# whole shard of that length -- on rows with few distinct scores (ties by position everywhere), bit-exact against the oracle.
+# ---------------------------------------------------------------------------------------------------------------------
+
+def test_select_and_sort_of_long_lists_with_ties(oracle):
+    rng = np.random.default_rng(5)
+    n, dim = 300_000, 16
+    rows = rng.integers(-2, 3, (n, dim)).astype(np.int8)
+    q = rng.integers(-2, 3, (5, dim)).astype(np.int8)
+    with G.GpuCorpus.from_array(rows) as c:
+        c.set_profiling(True)
+        for k in (140_000, 200_000, n):      # select (k < n / 2) / full sort / full ranking
+            got = c.search(q, k, G.INNER_PRODUCT)
+            assert c.last_timing().scan_kernel == 8
+            assert_exact(got, *oracle.search(rows, 2, 1, q, k))
+        one = c.search(q[0], 131_073, G.L2)  # one query per pass, survivors one past the 11-bit form's limit
+        assert_exact(one, *oracle.search(rows, 2, 0, q[:1], 131_073))
