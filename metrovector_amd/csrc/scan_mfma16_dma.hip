@@ -142,10 +142,13 @@ __global__ void __launch_bounds__(512, 2) scan_mfma16_dma_kernel(Batch16Params p
 #ifdef MVF_K2_ENDBARRIER  // A/B builds only
     constexpr bool MIDB = false;
 #else
-    constexpr bool MIDB = BMQ_ == 256 && DT == MVF_DTYPE_INT8;
+    constexpr bool MIDB = BMQ_ == 256 && DT != MVF_DTYPE_FLOAT16;
 #endif
-    // ... and on the int8 shadow with the 256-query tile the query half of the bound does not change from tile to tile
-    constexpr bool INVB = BIAS && DT == MVF_DTYPE_INT8 && XS && Cf::INV_LDS;
+    // ... and at the 256-query tile the query half of the bound does not change from tile to tile (scan_mfma16_bias.inc): -B per
+    // query in LDS, R per row from the block's transform pass -- the int8 shadow and, since the second half of round 5, the
+    // exact-integer flavours
+    constexpr bool INVB = BIAS && Cf::INV_LDS;
+    constexpr bool INV_PROD = INVB && (QSF || METRIC == MVF_METRIC_COSINE);  // the bound has a product term: a reference point, the halves' extremes
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -412,9 +415,10 @@ __global__ void __launch_bounds__(512, 2) scan_mfma16_dma_kernel(Batch16Params p
             const uint32_t* rc = rc_of(m);
             const int row = tid & (Cf::BR - 1), half = tid >> 8;
             float u, v;
-            inv_row_uv<METRIC>(NEED0 ? rc[row] : 0u, rc[Cf::BR + row], u, v);
+            int32_t ri;
+            inv_row_uv<DT, METRIC, XS>(NEED0 ? rc[row] : 0u, NEED1 ? rc[Cf::BR + row] : 0u, p.dim, u, v, ri);
             rb_s[((m & (Cf::NRB - 1)) * 2 + half) * Cf::BR + row] =
-                inv_row_bound<METRIC>(u, v, ref_val(0), ref_val(1), ext_s + 4 * half, p.row_begin + nt * Cf::BR + (uint32_t)row < p.row_end);
+                inv_row_bound<DT, METRIC, XS>(u, v, ri, ref_val(0), ref_val(1), ext_s + 4 * half, p.row_begin + nt * Cf::BR + (uint32_t)row < p.row_end);
         }
     };
     auto inv_rows = [&](uint32_t n) __attribute__((always_inline)) {
@@ -436,36 +440,42 @@ __global__ void __launch_bounds__(512, 2) scan_mfma16_dma_kernel(Batch16Params p
                     u_s[tid] = w;
                 }
             }
-            if (first && tid < Cf::BR) {
+            if (INV_PROD && first && tid < Cf::BR) {
                 uint32_t nt, mt;
                 slot_tile(0, nt, mt);
                 const uint32_t* rc = rc_of(0);
                 float u, v;
-                inv_row_uv<METRIC>(NEED0 ? rc[tid] : 0u, rc[Cf::BR + tid], u, v);
+                int32_t ri;
+                inv_row_uv<DT, METRIC, XS>(NEED0 ? rc[tid] : 0u, NEED1 ? rc[Cf::BR + tid] : 0u, p.dim, u, v, ri);
                 if (p.row_begin + nt * Cf::BR + (uint32_t)tid < p.row_end) {
                     if (u >= 0.0f && u < inf) atomicMin(&ref_s[0], __float_as_uint(u));
-                    if (METRIC == MVF_METRIC_L2 && v >= 0.0f && v < inf) atomicMin(&ref_s[1], __float_as_uint(v));
+                    if (L2Q && v >= 0.0f && v < inf) atomicMin(&ref_s[1], __float_as_uint(v));
                 }
             }
             __syncthreads();
             const float* parr = L2Q ? thu_s : thr_s;
-            float pmin = inf, pmax = -inf, wmin = inf, wmax = 0.0f;
+            if constexpr (INV_PROD) {
+                float pmin = inf, pmax = -inf, wmin = inf, wmax = 0.0f;
 #pragma unroll
-            for (int h = 0; h < WQ / 64; h++) {
-                const int ql = wm * WQ + h * 64 + lane;
-                const float P = parr[ql], W = L2Q ? u_s[ql] : 0.0f;
-                if (fabsf(P) < 3.0e38f && (!L2Q || (W >= 0.0f && W < 3.0e38f))) {
-                    pmin = fminf(pmin, P), pmax = fmaxf(pmax, P);
-                    wmin = fminf(wmin, W), wmax = fmaxf(wmax, W);
+                for (int h = 0; h < WQ / 64; h++) {
+                    const int ql = wm * WQ + h * 64 + lane;
+                    const float P = parr[ql], W = L2Q ? u_s[ql] : 0.0f;
+                    if (fabsf(P) < 3.0e38f && (!L2Q || (W >= 0.0f && W < 3.0e38f))) {
+                        pmin = fminf(pmin, P), pmax = fmaxf(pmax, P);
+                        wmin = fminf(wmin, W), wmax = fmaxf(wmax, W);
+                    }
                 }
+                for (int off = 32; off > 0; off >>= 1) {
+                    pmin = fminf(pmin, __shfl_xor(pmin, off, 64)), pmax = fmaxf(pmax, __shfl_xor(pmax, off, 64));
+                    wmin = fminf(wmin, __shfl_xor(wmin, off, 64)), wmax = fmaxf(wmax, __shfl_xor(wmax, off, 64));
+                }
+                if (!(pmin <= pmax)) pmin = pmax = wmin = wmax = 0.0f;  // no query of the half has finite constants: B decides alone
+                if (wn == 0 && lane == 0) ext_s[4 * wm + 0] = pmin, ext_s[4 * wm + 1] = pmax, ext_s[4 * wm + 2] = wmin, ext_s[4 * wm + 3] = wmax;
             }
-            for (int off = 32; off > 0; off >>= 1) {
-                pmin = fminf(pmin, __shfl_xor(pmin, off, 64)), pmax = fmaxf(pmax, __shfl_xor(pmax, off, 64));
-                wmin = fminf(wmin, __shfl_xor(wmin, off, 64)), wmax = fmaxf(wmax, __shfl_xor(wmax, off, 64));
+            if (tid < BMQ) {
+                const uint32_t scb = L2Q ? __float_as_uint(u_s[tid]) : (U8 && METRIC == MVF_METRIC_COSINE) ? __float_as_uint(qb_s[tid]) : 0u;  // W / c_q
+                nbq_s[tid] = inv_bias_query<DT, METRIC, XS>(__float_as_uint(parr[tid]), scb, ref_val(0), ref_val(1));
             }
-            if (!(pmin <= pmax)) pmin = pmax = wmin = wmax = 0.0f;  // no query of the half has finite constants: B decides alone
-            if (wn == 0 && lane == 0) ext_s[4 * wm + 0] = pmin, ext_s[4 * wm + 1] = pmax, ext_s[4 * wm + 2] = wmin, ext_s[4 * wm + 3] = wmax;
-            if (tid < BMQ) nbq_s[tid] = inv_bias_query<METRIC>(parr[tid], L2Q ? u_s[tid] : 0.0f, ref_val(0), ref_val(1));
             __syncthreads();  // the extremes and -B are published
         }
     };

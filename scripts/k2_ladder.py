@@ -26,7 +26,10 @@ CFGS = {"cfg3": (10_000_000, 768, 1, 2, 1024),   # f16 rows, cosine: the int8-sh
         "cfg5": (12_500_000, 1024, 1, 0, 1024),  # f16 rows, L2: <2, 0, false, true, 256, true>
         "cfg3ip": (10_000_000, 768, 1, 1, 1024),
         "cfg4": (50_000_000, 768, 2, 1, 256),    # int8 rows, dot: <2, 1, false, false, 256, true> (no probe: other row count per byte)
-        "u8cos": (20_000_000, 768, 3, 2, 256)}   # uint8 rows, cosine: <3, 2, false, false, 256, true>
+        "u8cos": (20_000_000, 768, 3, 2, 256),   # uint8 rows, cosine: <3, 2, false, false, 256, true>
+        "u8l2": (20_000_000, 768, 3, 0, 1024),   # uint8 rows, L2, four query tiles
+        "i8l2": (20_000_000, 512, 2, 0, 1024),   # int8 rows, L2
+        "i8cos": (20_000_000, 512, 2, 2, 512)}   # int8 rows, cosine
 
 
 def load(tag):
