@@ -132,13 +132,13 @@ __global__ void __launch_bounds__(512, 2) scan_mfma16_dma_kernel(Batch16Params p
 
     // i32 accumulators behind a threshold: the pre-filter is folded into the accumulators (scan_mfma16_bias.inc)
     constexpr bool BIAS = !DIRECT && DT != MVF_DTYPE_FLOAT16 && Cf::RC_LDS && REG;
-    // The k-tile's barrier in the MIDDLE of its MFMAs (256-query tile, Int8 rows / the int8 shadow): the next k-tile's B
+    // The k-tile's barrier in the MIDDLE of its MFMAs (256-query tile; Int8 / UInt8 rows and the int8 shadow): the next k-tile's B
     // fragments and first A fragment are read under the second half of this one's MFMAs, so no wave starts a k-tile with an LDS
     // round trip in the open and the eight waves' fragment bursts no longer collide behind the barrier.  Round 5, one process,
     // 12 rotated rounds (profiles/r05_k2_shadow_ladder.txt): cfg3's last phase 5.65 -> 5.46 ms, the cfg5 shard's 9.16 -> 8.75,
     // cfg4's 7.60 -> 7.53; the bare k-loop (scripts/probe_k2_w1.hip, W8N -> W8NP) 4.97 -> 4.75 / 8.25 -> 7.88.  14 registers more
-    // (the fragments in hand): UInt8 rows under cosine spill with them and lose 3 %, so they -- and Float16 rows, whose long
-    // phases take the ping-pong kernel -- keep the barrier at the k-tile's end.
+    // (the fragments in hand): UInt8 rows under cosine spilled with them until their bounds left the registers (INVB below);
+    // Float16 rows, whose long phases take the ping-pong kernel, keep the barrier at the k-tile's end.
 #ifdef MVF_K2_ENDBARRIER  // A/B builds only
     constexpr bool MIDB = false;
 #else
