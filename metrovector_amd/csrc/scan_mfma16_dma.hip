@@ -80,13 +80,15 @@ template <int BMQ_> struct CfT {
     // (s_waitcnt vmcnt(0)): that was 20 % of the int8-selection scan.  The 64-query shape has no LDS left
     // for them (4 x 36 KB of ring) and keeps the loads.
     static constexpr bool RC_LDS = BMQ != 64;
-    static constexpr int NRC = 8;                               // >= NSTAGE + 1 (one k-tile per tile) with room for waves that lag inside the epilogue
-    // The int8 shadow's tile-invariant bounds (scan_mfma16_bias.inc, round 5; 256-query tile): R per row and query half, NRB
-    // buffers by tile ordinal, + the halves' threshold extremes and the block's reference point
-    static constexpr bool INV_LDS = BMQ == 256;
-    static constexpr int NRB = 4;
+    static constexpr int NRC = BMQ == 128 ? 4 : 8;              // >= NSTAGE + 1 (one k-tile per tile: the DMA cursor runs NSTAGE - 1 tiles ahead and the next
+                                                                //  iteration's requests go out while this tile's buffer is still read); a power of two
+    // The tile-invariant bounds of the i32-accumulator flavours (scan_mfma16_bias.inc, round 5): R per row and query half
+    // (HALVES = 2 at the 256-query tile, 1 at the 128-query one), NRB buffers by tile ordinal, + the halves' threshold extremes,
+    // the block's reference point and -B per query
+    static constexpr bool INV_LDS = RC_LDS;
+    static constexpr int NRB = 4, HALVES = BMQ / WQ;
     static constexpr size_t LDS = (size_t)NSTAGE * STAGE_B + 4 * BMQ * 4 + (RC_LDS ? NRC * 2 * BR * 4 + 2 * BMQ * 4 : 0) + 16 +  // ring + qaux0 + tau + qaux1 + prefilter [+ row constants + the L2 bounds' per-query pair] + candidate counter
-                                  (INV_LDS ? NRB * 2 * BR * 4 + 64 + BMQ * 4 : 0);  // ... and -B per query
+                                  (INV_LDS ? NRB * HALVES * BR * 4 + 64 + BMQ * 4 : 0);  // ... and -B per query
 };
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -118,8 +120,8 @@ __global__ void __launch_bounds__(512, 2) scan_mfma16_dma_kernel(Batch16Params p
     uint32_t* bc_s = rc_s + (Cf::RC_LDS ? Cf::NRC * 2 * Cf::BR : 0);  // records in the block's candidate region
     float* thu_s = reinterpret_cast<float*>(bc_s + 4);                // [BMQ] int8 shadow, L2: (th - |th| 1e-6) / (2 s_q) ...
     float* u_s = thu_s + BMQ;                                         // [BMQ] ... and 1 / (2 s_q) (scan_mfma16_bias.inc)
-    int32_t* rb_s = reinterpret_cast<int32_t*>(u_s + BMQ);            // [NRB][2][BR] tile-invariant bounds: R(row) per query half
-    float* ext_s = reinterpret_cast<float*>(rb_s + (Cf::INV_LDS ? Cf::NRB * 2 * Cf::BR : 0));  // [2][4] {Pmin, Pmax, Wmin, Wmax} per half
+    int32_t* rb_s = reinterpret_cast<int32_t*>(u_s + BMQ);            // [NRB][HALVES][BR] tile-invariant bounds: R(row) per query half
+    float* ext_s = reinterpret_cast<float*>(rb_s + (Cf::INV_LDS ? Cf::NRB * Cf::HALVES * Cf::BR : 0));  // [2][4] {Pmin, Pmax, Wmin, Wmax} per half
     uint32_t* ref_s = reinterpret_cast<uint32_t*>(ext_s + 8);         // u_ref, v_ref (bit patterns; +inf = not set)
     int32_t* nbq_s = reinterpret_cast<int32_t*>(ref_s + 8);           // [BMQ] -B per query (the block's reference point: the same for every lane)
     // per-row constants the epilogue needs (scan_mfma16_common.inc): array 0 = norms, array 1 = shadow scale / UInt8 bias
@@ -144,10 +146,11 @@ __global__ void __launch_bounds__(512, 2) scan_mfma16_dma_kernel(Batch16Params p
 #else
     constexpr bool MIDB = BMQ_ == 256 && DT != MVF_DTYPE_FLOAT16;
 #endif
-    // ... and at the 256-query tile the query half of the bound does not change from tile to tile (scan_mfma16_bias.inc): -B per
-    // query in LDS, R per row from the block's transform pass -- the int8 shadow and, since the second half of round 5, the
-    // exact-integer flavours
-    constexpr bool INVB = BIAS && Cf::INV_LDS;
+    // ... and the query half of the bound does not change from tile to tile (scan_mfma16_bias.inc, round 5): -B per query in LDS,
+    // R per row from the block's transform pass -- every flavour with the folded pre-filter (INVB is BIAS: kept as the name of
+    // the scheme where the code speaks of it)
+    constexpr bool INVB = BIAS;
+    static_assert(!BIAS || Cf::INV_LDS, "the bounds' LDS");
     constexpr bool INV_PROD = INVB && (QSF || METRIC == MVF_METRIC_COSINE);  // the bound has a product term: a reference point, the halves' extremes
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -281,12 +284,7 @@ __global__ void __launch_bounds__(512, 2) scan_mfma16_dma_kernel(Batch16Params p
     };
 
     // ---- pre-filter folded into the accumulators (scan_mfma16_bias.inc): per-lane state ------------------------------
-    [[maybe_unused]] AccT negb[INVB ? 1 : NI];  // -B of the tile being multiplied, one 4-query vector per group (INVB: in LDS, nbq_s)
-    [[maybe_unused]] int32_t br_cur[NJ];   // R(row) of that tile
-    // the lane's smallest threshold (float thresholds; L2 on the int8 shadow: the smallest (th - |th| 1e-6) / (2 s_q)) and,
-    // L2 on the shadow, its smallest 1 / (2 s_q)
-    [[maybe_unused]] float umin = 0.f, thumin = 0.f;
-    [[maybe_unused]] bool thr_ok = false;  // wave-uniform: every threshold of the wave's queries allows the short form of the bounds
+    [[maybe_unused]] int32_t br_cur[NJ];   // R(row) of the tile being multiplied (-B sits in LDS: nbq_s)
     // the wave's own slice of the block's candidate region and its running record count (wave-uniform)
     [[maybe_unused]] const uint32_t wcap = p.blk_cap / (uint32_t)NW;
     [[maybe_unused]] uint4* const wbase = p.blk_cand + ((size_t)blockIdx.x * NW + (uint32_t)wave) * wcap;
@@ -294,109 +292,9 @@ __global__ void __launch_bounds__(512, 2) scan_mfma16_dma_kernel(Batch16Params p
     [[maybe_unused]] uint32_t flagged = 0;  // wave-uniform: bit i = query group i of the tile being finished holds a maximum >= 0
     constexpr bool L2Q = QSF && METRIC == MVF_METRIC_L2;
     auto rc_of = [&](uint32_t n) __attribute__((always_inline)) { return rc_s + (n & (Cf::NRC - 1)) * 2 * Cf::BR; };
-    // int8 shadow: the rows' factors 1 / m_j replace the shadow scales in tile n's LDS copy, once per row (scan_mfma16_bias.inc:
-    // lane_rows16's PRE form).  Called for a tile whose constants have landed and that no wave reads yet (see the call sites).
-    constexpr bool RC_PRE = BIAS && QSF && !INVB;
-    auto rc_transform = [&](uint32_t n) __attribute__((always_inline)) {
-        if constexpr (RC_PRE) {
-            if (n < my_tiles) {
-                uint32_t* rc = rc_of(n);
-                for (int r = tid; r < Cf::BR; r += NW * 64) rc[Cf::BR + r] = row_factor_inv16<METRIC>(rc[r], rc[Cf::BR + r]);
-            }
-        }
-    };
-    auto read_thr = [&](int i, u32x4& th4, u32x4& sc4, bool transformed) __attribute__((always_inline)) {
-        const int ql = wm * WQ + 4 * (lane / SH) + i * SH;
-        th4 = *reinterpret_cast<const u32x4*>((L2Q && transformed ? thu_s : thr_s) + ql);
-        sc4 = u32x4{0, 0, 0, 0};
-        if (L2Q) sc4 = *reinterpret_cast<const u32x4*>((transformed ? u_s : qa_s) + ql);  // u / s_q
-        if (U8 && METRIC == MVF_METRIC_COSINE) sc4 = *reinterpret_cast<const u32x4*>(qb_s + ql);  // c_q
-    };
-    // once per query tile: can the lane's thresholds take the short form?  (the caller has published thr_s / qa_s)
-    auto query_prep = [&]() {
-        if constexpr (!QSF && METRIC != MVF_METRIC_COSINE) {  // integer thresholds: the padding queries' 2^30 -> 2^29 (still out of reach here)
-            if (tid < BMQ && c_mt * BMQ + (uint32_t)tid >= p.nq) thr_s[tid] = __int_as_float(kBiasBig);
-            __syncthreads();
-        }
-        if constexpr (L2Q) {
-            if (tid < BMQ) {
-                const float th = thr_s[tid], u = 0.5f * __builtin_amdgcn_rcpf(qa_s[tid]);
-                thu_s[tid] = (th - fabsf(th) * 1e-6f) * u;
-                u_s[tid] = u;
-            }
-            __syncthreads();
-        }
-        bool ok = true;
-        umin = __builtin_inff();
-        thumin = __builtin_inff();
-#pragma unroll
-        for (int i = 0; i < NI; i++) {
-            u32x4 th4, sc4;
-            read_thr(i, th4, sc4, true);
-#pragma unroll
-            for (int e = 0; e < 4; e++) {
-                if constexpr (L2Q) {
-                    const float a = __uint_as_float(th4[e]), u = __uint_as_float(sc4[e]);
-                    ok &= (fabsf(a) < 3.0e38f) && (u >= 0.0f) && (u < 3.0e38f);
-                    thumin = fminf(thumin, a);
-                    umin = fminf(umin, u);
-                } else if constexpr (QSF || METRIC == MVF_METRIC_COSINE) {
-                    const float th = __uint_as_float(th4[e]);
-                    ok &= th >= 0.0f;  // +inf (padding queries) is fine: their B saturates at 2^29
-                    thumin = fminf(thumin, th);
-                } else {
-                    const int32_t th = (int32_t)th4[e];
-                    ok &= th >= -kBiasBig && th <= kBiasBig;
-                }
-            }
-        }
-        if (!ok) thumin = 0.f;  // a negative (or NaN) threshold in the lane: no multiplicative row term
-        thr_ok = __builtin_amdgcn_ballot_w64(!ok) == 0;
-    };
-    // -B of every query group and R of every row of block tile n: at the start of the tile, in the open
-    auto bias_all = [&](uint32_t n) {
-        uint32_t nt, mt;
-        slot_tile(n, nt, mt);
-        const uint32_t* rc = rc_of(n);
-        LaneRows L;
-        lane_rows16<DT, METRIC, XS, SH, WR, Cf::BR, true, true, RC_PRE>(p, nt, wn, lane, rc, rc + Cf::BR, umin, thumin, L, br_cur);
-        bool ok = thr_ok;
-        float kmul = 0.f, xlo_adj = 0.f;
-        if constexpr (QSF || METRIC == MVF_METRIC_COSINE) {
-            ok = ok && L.inv_hi >= 0.0f && L.inv_hi < 3.0e38f;
-            kmul = -L.inv_hi * (1.0f - 2e-6f);
-        }
-        if constexpr (L2Q) {
-            xlo_adj = L.xlo - L.xhi * 1e-6f;
-            ok = ok && xlo_adj >= 0.0f && thumin + xlo_adj * umin >= 0.0f;  // every (th' + xlo') u of the lane is >= 0
-        }
-        if (__builtin_amdgcn_ballot_w64(!ok) == 0) {
-#pragma unroll
-            for (int i = 0; i < NI; i++) {
-                u32x4 th4, sc4;
-                read_thr(i, th4, sc4, true);
-                negb[i] = __builtin_bit_cast(AccT, bias_group16_fast<DT, METRIC, XS>(L, kmul, xlo_adj, th4, sc4));
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < NI; i++) {
-                u32x4 th4, sc4;
-                read_thr(i, th4, sc4, false);
-                negb[i] = __builtin_bit_cast(AccT, bias_group16<DT, METRIC, XS>(L, th4, sc4));
-            }
-        }
-    };
-#ifdef MVF_DIAG_NOBIAS  // diagnostic build only (with MVF_DIAG_NOEPI): the tile's bounds are not computed, the sums start from zero
-#define MVF_BIAS_ALL(n)                                         \
-    do {                                                        \
-        for (int i_ = 0; i_ < (INVB ? 1 : NI); i_++) negb[i_] = AccT{0, 0, 0, 0}; \
-    } while (0)
-#else
-#define MVF_BIAS_ALL(n) bias_all(n)
-#endif
     // ---- tile-invariant bounds (INVB; scan_mfma16_bias.inc): -B per lane and query once per query tile, R per row and
     // query half once per tile by the block, one tile ahead ----------------------------------------------------------------
-    static_assert(!INVB || (Cf::BR == 256 && NW * 64 == 2 * Cf::BR && WQ == 128), "one thread per (row, query half)");
+    static_assert(!INVB || (NW * 64 == Cf::HALVES * Cf::BR && WQ == 128), "one thread per (row, query half)");
     auto tile_mt = [&](uint32_t n) __attribute__((always_inline)) -> uint32_t {
         uint32_t nt, mt;
         slot_tile(n, nt, mt);
@@ -413,17 +311,17 @@ __global__ void __launch_bounds__(512, 2) scan_mfma16_dma_kernel(Batch16Params p
             uint32_t nt, mt;
             slot_tile(m, nt, mt);
             const uint32_t* rc = rc_of(m);
-            const int row = tid & (Cf::BR - 1), half = tid >> 8;
+            const int row = tid & (Cf::BR - 1), half = tid / Cf::BR;
             float u, v;
             int32_t ri;
             inv_row_uv<DT, METRIC, XS>(NEED0 ? rc[row] : 0u, NEED1 ? rc[Cf::BR + row] : 0u, p.dim, u, v, ri);
-            rb_s[((m & (Cf::NRB - 1)) * 2 + half) * Cf::BR + row] =
+            rb_s[((m & (Cf::NRB - 1)) * Cf::HALVES + half) * Cf::BR + row] =
                 inv_row_bound<DT, METRIC, XS>(u, v, ri, ref_val(0), ref_val(1), ext_s + 4 * half, p.row_begin + nt * Cf::BR + (uint32_t)row < p.row_end);
         }
     };
     auto inv_rows = [&](uint32_t n) __attribute__((always_inline)) {
         if constexpr (INVB) {
-            const int32_t* rb = rb_s + ((n & (Cf::NRB - 1)) * 2 + wm) * Cf::BR + wn * WR + (lane & (SH - 1));
+            const int32_t* rb = rb_s + ((n & (Cf::NRB - 1)) * Cf::HALVES + wm) * Cf::BR + wn * WR + (lane & (SH - 1));
 #pragma unroll
             for (int j = 0; j < NJ; j++) br_cur[j] = rb[j * SH];
         }
@@ -480,28 +378,16 @@ __global__ void __launch_bounds__(512, 2) scan_mfma16_dma_kernel(Batch16Params p
         }
     };
     if constexpr (BIAS) {
-#ifdef MVF_DIAG_NOBIAS
-        MVF_BIAS_ALL(0);
-        if constexpr (INVB) {
-            if (tid < BMQ) nbq_s[tid] = 0;
-            __syncthreads();
-        }
+#ifdef MVF_DIAG_NOBIAS  // diagnostic build only (with MVF_DIAG_NOEPI): the tile's bounds are not computed, the sums start from zero
+        if (tid < BMQ) nbq_s[tid] = 0;
+        __syncthreads();
 #else
-        if constexpr (INVB) {  // tile 0 (and 1, see below): their constants were requested in front of k-tile 0, which has landed
-            inv_query_prep(true);
-            inv_transform(0);
-            if (p.KT == 1 && 1 < my_tiles && tile_mt(1) == c_mt) inv_transform(1);
-            __syncthreads();
-            inv_rows(0);
-        } else {
-            if constexpr (RC_PRE) {  // tile 0 (and 1, see below): their constants were requested in front of k-tile 0, which has landed
-                rc_transform(0);
-                if (p.KT == 1) rc_transform(1);
-                __syncthreads();
-            }
-            query_prep();
-            MVF_BIAS_ALL(0);
-        }
+        // tile 0 (and 1, see below): their constants were requested in front of k-tile 0, which has landed
+        inv_query_prep(true);
+        inv_transform(0);
+        if (p.KT == 1 && 1 < my_tiles && tile_mt(1) == c_mt) inv_transform(1);
+        __syncthreads();
+        inv_rows(0);
 #endif
     }
 
@@ -520,10 +406,7 @@ __global__ void __launch_bounds__(512, 2) scan_mfma16_dma_kernel(Batch16Params p
 #pragma unroll
             for (int i = 0; i < NI; i++) {
                 if (!(flags & (1u << i))) continue;
-                auto nb_of = [&](int e) __attribute__((always_inline)) -> int32_t {
-                    if constexpr (INVB) return nbq_s[wm * WQ + 4 * (lane / SH) + i * SH + e];
-                    else return negb[i][e];
-                };
+                auto nb_of = [&](int e) __attribute__((always_inline)) -> int32_t { return nbq_s[wm * WQ + 4 * (lane / SH) + i * SH + e]; };
                 epilogue_group16<SH, NJ>(p, acc[i], nb_of, br_cur, mt * BMQ + (uint32_t)(wm * WQ + 4 * (lane / SH) + i * SH),
                                          p.row_begin + nt * Cf::BR + (uint32_t)(wn * WR + (lane & (SH - 1))), wbase, wcap, wcnt);
             }
@@ -559,7 +442,7 @@ __global__ void __launch_bounds__(512, 2) scan_mfma16_dma_kernel(Batch16Params p
 #pragma unroll
             for (int j = 0; j < NJ; j++) fb[j] = read_b(st, j);
             fa[0] = read_a(st, 0);
-            if constexpr (INVB && FIRST) nbv[0] = read_nb(0);
+            if constexpr (BIAS && FIRST) nbv[0] = read_nb(0);
 #pragma unroll
             for (int i = 0; i < NI; i++) {
 #ifdef MVF_K2_OLD_FRAG_ORDER  // A/B builds only: rounds 2-4 requested the next fragment in front of the group
@@ -567,10 +450,7 @@ __global__ void __launch_bounds__(512, 2) scan_mfma16_dma_kernel(Batch16Params p
 #endif
 #pragma unroll
                 for (int j = 0; j < NJ; j++) {
-                    if constexpr (BIAS && FIRST) {  // the MFMA's C operand: no copy is emitted
-                        if constexpr (INVB) acc[i][j] = nbv[i & 1];
-                        else acc[i][j] = negb[i];
-                    }
+                    if constexpr (BIAS && FIRST) acc[i][j] = nbv[i & 1];  // the MFMA's C operand: no copy is emitted
                     mfma1(acc[i][j], fa[i & 1], fb[j]);
 #ifndef MVF_K2_OLD_FRAG_ORDER
                     // The next group's A fragment is requested BEHIND this group's first MFMA, that is behind the wait for this
@@ -581,7 +461,7 @@ __global__ void __launch_bounds__(512, 2) scan_mfma16_dma_kernel(Batch16Params p
                         __builtin_amdgcn_sched_barrier(0);
                         if (i + 1 < NI) {
                             fa[(i + 1) & 1] = read_a(st, i + 1);
-                            if constexpr (INVB && FIRST) nbv[(i + 1) & 1] = read_nb(i + 1);
+                            if constexpr (BIAS && FIRST) nbv[(i + 1) & 1] = read_nb(i + 1);
                         }
                     }
 #endif
@@ -604,7 +484,7 @@ __global__ void __launch_bounds__(512, 2) scan_mfma16_dma_kernel(Batch16Params p
                 return *reinterpret_cast<const AccT*>(nbq_s + wm * WQ + 4 * (lane / SH) + i * SH);
             };
             fa[0] = fa_first;
-            if constexpr (INVB && FIRST) nbv[0] = read_nb(0);
+            if constexpr (BIAS && FIRST) nbv[0] = read_nb(0);
 #pragma unroll
             for (int i = 0; i < NI; i++) {
                 if (i == NI / 2) {
@@ -615,16 +495,13 @@ __global__ void __launch_bounds__(512, 2) scan_mfma16_dma_kernel(Batch16Params p
                 }
 #pragma unroll
                 for (int j = 0; j < NJ; j++) {
-                    if constexpr (BIAS && FIRST) {
-                        if constexpr (INVB) acc[i][j] = nbv[i & 1];
-                        else acc[i][j] = negb[i];
-                    }
+                    if constexpr (BIAS && FIRST) acc[i][j] = nbv[i & 1];
                     mfma1(acc[i][j], fa[i & 1], fbc[j]);
                     if (j == 0) {  // requests behind the group's first MFMA (see ktile)
                         __builtin_amdgcn_sched_barrier(0);
                         fa[(i + 1) & 1] = i + 1 < NI ? read_a(st, i + 1) : read_a(stn, 0);
                         if (i >= NI / 2) fbn[i - NI / 2] = read_b(stn, i - NI / 2);
-                        if constexpr (INVB && FIRST) {
+                        if constexpr (BIAS && FIRST) {
                             if (i + 1 < NI) nbv[(i + 1) & 1] = read_nb(i + 1);
                         }
                     }
@@ -642,16 +519,12 @@ __global__ void __launch_bounds__(512, 2) scan_mfma16_dma_kernel(Batch16Params p
             // tile has two k-tiles or more.  With ONE k-tile per tile the tile after the next is taken instead: the DMA cursor
             // runs NSTAGE - 1 tiles ahead then, its constants were requested behind the pieces of tile c_n + 1 at the latest,
             // and those are older than everything the last wait left in flight.
-            if constexpr (INVB) {
 #ifndef MVF_DIAG_NOBIAS
-                // R of the next tile (the one after it when a tile is ONE k-tile), if it is multiplied with the queries in place
-                // now; a change of the query tile computes its own (below)
-                const uint32_t m = c_n + (p.KT == 1 ? 2u : 1u);
-                if (m < my_tiles && tile_mt(m) == c_mt && (p.KT != 1 || tile_mt(c_n + 1) == c_mt)) inv_transform(m);
+            // R of the next tile (the one after it when a tile is ONE k-tile), if it is multiplied with the queries in place
+            // now; a change of the query tile computes its own (below)
+            const uint32_t m = c_n + (p.KT == 1 ? 2u : 1u);
+            if (m < my_tiles && tile_mt(m) == c_mt && (p.KT != 1 || tile_mt(c_n + 1) == c_mt)) inv_transform(m);
 #endif
-            } else {
-                rc_transform(c_n + (p.KT == 1 ? 2u : 1u));
-            }
             if constexpr (MIDB) ktile_mid(std::true_type{});
             else ktile(std::true_type{});
         } else {
@@ -690,24 +563,15 @@ __global__ void __launch_bounds__(512, 2) scan_mfma16_dma_kernel(Batch16Params p
                         c_mt = nmt;
                         __syncthreads();
 #ifndef MVF_DIAG_NOBIAS
-                        if constexpr (INVB) {
-                            inv_query_prep(false);
-                            inv_transform(c_n);
-                            if (p.KT == 1 && c_n + 1 < my_tiles && tile_mt(c_n + 1) == c_mt) inv_transform(c_n + 1);
-                            __syncthreads();
-                        } else
+                        inv_query_prep(false);
+                        inv_transform(c_n);
+                        if (p.KT == 1 && c_n + 1 < my_tiles && tile_mt(c_n + 1) == c_mt) inv_transform(c_n + 1);
+                        __syncthreads();
 #endif
-                        {
-                            query_prep();
-                        }
                     }
 #ifndef MVF_DIAG_NOBIAS
-                    if constexpr (INVB) inv_rows(c_n);
-                    else
+                    inv_rows(c_n);
 #endif
-                    {
-                        MVF_BIAS_ALL(c_n);
-                    }
                 }
             } else {
 #ifdef MVF_DIAG_NOEPI  // diagnostic build only: the k-loop alone (the sums are kept alive, nothing is selected)
@@ -752,8 +616,6 @@ __global__ void __launch_bounds__(512, 2) scan_mfma16_dma_kernel(Batch16Params p
         if (tid == 0 && p.blk_cnt) p.blk_cnt[blockIdx.x] = min(*bc_s, p.blk_cap);  // behind the loop's last barrier: every epilogue is done
     }
 }
-
-#undef MVF_BIAS_ALL
 
 template <int DT, int METRIC, int BMQ>
 hipError_t launch_dtm(const Batch16Params& p, dim3 grid, hipStream_t s) {

@@ -29,7 +29,10 @@ CFGS = {"cfg3": (10_000_000, 768, 1, 2, 1024),   # f16 rows, cosine: the int8-sh
         "u8cos": (20_000_000, 768, 3, 2, 256),   # uint8 rows, cosine: <3, 2, false, false, 256, true>
         "u8l2": (20_000_000, 768, 3, 0, 1024),   # uint8 rows, L2, four query tiles
         "i8l2": (20_000_000, 512, 2, 0, 1024),   # int8 rows, L2
-        "i8cos": (20_000_000, 512, 2, 2, 512)}   # int8 rows, cosine
+        "i8cos": (20_000_000, 512, 2, 2, 512),   # int8 rows, cosine
+        "q100": (10_000_000, 768, 1, 2, 100),    # the 128-query tile: f16 rows, cosine through the int8 shadow
+        "q128l2": (12_500_000, 1024, 1, 0, 128), # the 128-query tile, L2
+        "i8q128": (20_000_000, 512, 2, 2, 128)}  # the 128-query tile, int8 rows, cosine
 
 
 def load(tag):
@@ -117,6 +120,8 @@ def main():
         ops = 2.0 * nq * last_rows * dim
         for v in pvars:
             x = sorted(pres[v])
+            if not x:  # (the probe takes multiples of 256 queries)
+                continue
             print(f"== {name} probe{v:6s} k-loop alone       median {x[len(x) // 2]:7.3f} min {x[0]:7.3f} ms  {ops / x[len(x) // 2] / 1e12:6.3f} POP/s", flush=True)
         for t in tags:
             a = sorted(x[0] for x in res[t])
