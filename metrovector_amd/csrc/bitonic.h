@@ -42,6 +42,63 @@ __device__ __forceinline__ void bitonic_sort_u64(uint64_t* buf, uint32_t P, int 
     }
 }
 
+// The same network with the entries in REGISTERS (E per thread: entry i = tid + x * NT): a step whose partners sit in the same
+// wave (stride < 64) is a lane exchange -- no LDS round trip, no barrier -- and only the strides of 64 and more go through LDS
+// (store, barrier, read the partner, barrier).  A 512-entry list: 6 barrier steps instead of 45 (round 5: the per-phase
+// compaction of a 256-query search 29 -> ~9 us).  buf[0 .. P) filled (padding included) and a barrier passed on entry; P a
+// power of two, 2 <= P <= E * NT; sorted ascending in buf, barrier passed, on return.
+template <int NT, int E>
+__device__ __forceinline__ void bitonic_sort_u64_reg(uint64_t* buf, uint32_t P, int tid) {
+    uint64_t v[E];
+#pragma unroll
+    for (int x = 0; x < E; x++) {
+        const uint32_t i = (uint32_t)tid + (uint32_t)(x * NT);
+        v[x] = i < P ? buf[i] : ~0ull;
+    }
+    for (uint32_t size = 2; size <= P; size <<= 1) {
+        uint32_t stride = size >> 1;
+        for (; stride >= 64; stride >>= 1) {
+            __syncthreads();  // every read of the step before is done
+#pragma unroll
+            for (int x = 0; x < E; x++) {
+                const uint32_t i = (uint32_t)tid + (uint32_t)(x * NT);
+                if (i < P) buf[i] = v[x];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int x = 0; x < E; x++) {
+                const uint32_t i = (uint32_t)tid + (uint32_t)(x * NT);
+                if (i < P) {
+                    const uint64_t w = buf[i ^ stride];
+                    const bool keep_min = ((i & stride) == 0) == ((i & size) == 0);
+                    v[x] = (w < v[x]) == keep_min ? w : v[x];
+                }
+            }
+        }
+#pragma unroll
+        for (int s = 32; s >= 1; s >>= 1) {
+            if ((uint32_t)s <= stride) {  // (block-uniform)
+#pragma unroll
+                for (int x = 0; x < E; x++) {
+                    const uint32_t i = (uint32_t)tid + (uint32_t)(x * NT);
+                    if ((i & ~63u) < P) {  // (wave-uniform: whole waves behind the list sit the exchanges out)
+                        const uint64_t w = __shfl_xor((unsigned long long)v[x], s, 64);
+                        const bool keep_min = ((i & (uint32_t)s) == 0) == ((i & size) == 0);
+                        v[x] = (w < v[x]) == keep_min ? w : v[x];
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int x = 0; x < E; x++) {
+        const uint32_t i = (uint32_t)tid + (uint32_t)(x * NT);
+        if (i < P) buf[i] = v[x];
+    }
+    __syncthreads();
+}
+
 // Merge of a few new composites into a short sorted list, by counting instead of sorting: buf[0 .. kp) ascending (kp <= NT),
 // buf[kp .. kp + c) in any order (c <= NT), all composites distinct; afterwards buf[0 .. min(kp + c, k)) holds the smallest
 // of them ascending (whatever ranks at k or behind is dropped).  An element's place = the number of elements in front of it:

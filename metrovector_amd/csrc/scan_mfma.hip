@@ -520,11 +520,15 @@ __global__ void __launch_bounds__(1024) compact_kernel(CompactParams p) {
     const uint32_t raw_cnt = p.direct_cnt ? p.direct_cnt : p.cnt[q];  // direct phase: every row of it, no counter
     uint32_t m = raw_cnt < p.cap ? raw_cnt : p.cap;
     uint64_t* c = p.cand + (size_t)q * p.cap;
-    const uint32_t P2 = next_pow2(m < 2 ? 2 : m);
-    for (uint32_t i = tid; i < P2; i += 1024) buf[i] = i < m ? c[i] : kPadComposite;
-    __syncthreads();
-    bitonic_sort_u64<1024>(buf, P2, tid);
-    m = live_prefix(buf, m, tid, &live_s);
+    {
+        const uint32_t P2 = next_pow2(m < 2 ? 2 : m);
+        for (uint32_t i = tid; i < P2; i += 1024) buf[i] = i < m ? c[i] : kPadComposite;
+        __syncthreads();
+        // (the usual list between two phases holds a few hundred entries -- k carried + ~k (g - 1) new: one per thread, in registers)
+        if (P2 <= 1024) bitonic_sort_u64_reg<1024, 1>(buf, P2, tid);
+        else bitonic_sort_u64<1024>(buf, P2, tid);
+        m = live_prefix(buf, m, tid, &live_s);
+    }
     const uint32_t keep = m < p.k ? m : p.k;
     if (FINAL) {
         for (uint32_t i = tid; i < p.k; i += 1024) write_result_b(i < keep ? buf[i] : kPadComposite, q * p.k + i, p);
@@ -954,7 +958,8 @@ __global__ void __launch_bounds__(1024) rescore_select_kernel(RescoreParams p, i
     const uint32_t P2 = next_pow2(m < 2 ? 2 : m);
     for (uint32_t i = m + tid; i < P2; i += 1024) buf[i] = kPadComposite;
     __syncthreads();
-    bitonic_sort_u64<1024>(buf, P2, tid);
+    if (P2 <= 1024) bitonic_sort_u64_reg<1024, 1>(buf, P2, tid);
+    else bitonic_sort_u64<1024>(buf, P2, tid);
     for (uint32_t i = tid; i < p.k; i += 1024) {
         const uint32_t o = q * p.k + i;
         const uint64_t comp = i < m ? buf[i] : kPadComposite;

@@ -171,7 +171,10 @@ __global__ void __launch_bounds__(1024) sort_small_kernel(const uint64_t* in, ui
         buf[i] = i < m ? (ent << 32) | (ent >> 32) : ~0ull;  // rank entry -> (key' << 32 | position): distinct, their order is the result's
     }
     __syncthreads();
-    bitonic_sort_u64<1024>(buf, P, threadIdx.x);
+    if (P <= 1024) bitonic_sort_u64_reg<1024, 1>(buf, P, threadIdx.x);
+    else if (P <= 2048) bitonic_sort_u64_reg<1024, 2>(buf, P, threadIdx.x);
+    else if (P <= 4096) bitonic_sort_u64_reg<1024, 4>(buf, P, threadIdx.x);
+    else bitonic_sort_u64<1024>(buf, P, threadIdx.x);
     for (uint32_t i = threadIdx.x; i < m; i += 1024) out[i] = (buf[i] << 32) | (buf[i] >> 32);
 }
 

@@ -11,6 +11,7 @@ from metrovector_amd import _lib, gpu as G
 
 CFGS = {"cfg4": (50_000_000, 768, 2, 1, 256), "cfg5": (12_500_000, 1024, 1, 0, 1024), "cfg3": (10_000_000, 768, 0, 2, 1024),
         "cfg3l2": (10_000_000, 768, 0, 0, 1024), "cfg3ip": (10_000_000, 768, 0, 1, 1024), "u8": (20_000_000, 768, 3, 0, 256),
+        "cfg3q": (2_500_000, 768, 0, 2, 1024), "cfg3s": (625_000, 768, 0, 2, 1024),  # cfg3 minus its last phase / its last two
         "i8ip": (3_000_000, 768, 2, 1, 256), "i8l2": (3_000_000, 768, 2, 0, 256), "i8cos": (3_000_000, 768, 2, 2, 256)}
 lib = _lib.gpu()
 for name in (sys.argv[1] if len(sys.argv) > 1 else "cfg3,cfg5,cfg4").split(","):
