@@ -4,7 +4,8 @@
 #   scripts/bin/libmvf_gpu_<tag>.so   tag = noepi   -DMVF_DIAG_NOEPI                     (no drain at a tile's end)
 #                                           nobias  -DMVF_DIAG_NOEPI -DMVF_DIAG_NOBIAS    (... and no bounds at its start)
 #                                           oldfrag -DMVF_K2_OLD_FRAG_ORDER              (rounds 2-4's fragment request order)
-#                                           nowalk / nostore  the drain without the element walk / the walk without its stores
+#                                           nowalk  the drain without the element walk (NB: nothing is selected then, every group of the later phases is flagged)
+#                                           oldwalk -DMVF_K2_OLD_WALK  a compare + branch per element in the walk of a flagged group (until the middle of round 5)
 #                                           endb    -DMVF_K2_ENDBARRIER  the barrier at the end of the k-tile (rounds 2-4) instead of in the middle of its MFMAs
 #                                           r4      round 4's kernel sources (git show b12f680:...) against this tree's headers
 #   scripts/bin/libprobe_k2.so        scripts/probe_k2_w1.hip -DPROBE_K2_SHARED
@@ -26,8 +27,11 @@ for t in $TAGS; do
       nobias) defs="-DMVF_DIAG_NOEPI -DMVF_DIAG_NOBIAS" ;;
       oldfrag) defs="-DMVF_K2_OLD_FRAG_ORDER" ;;
       nowalk) defs="-DMVF_DIAG_NOWALK" ;;
-      nostore) defs="-DMVF_DIAG_NOSTORE" ;;
       endb) defs="-DMVF_K2_ENDBARRIER" ;;
+      oldwalk) defs="-DMVF_K2_OLD_WALK" ;;
+      head) d=$B/obj/src_$t; mkdir -p $d   # the last commit's kernel sources against the working tree: A/B of an uncommitted change
+          for f in scan_mfma16_dma.hip scan_mfma16_bias.inc scan_mfma16_common.inc; do git -C $ROOT show HEAD:metrovector_amd/csrc/$f > $d/$f; done
+          src=$d/scan_mfma16_dma.hip ;;
       r4*) d=$B/obj/src_$t; mkdir -p $d
           for f in scan_mfma16_dma.hip scan_mfma16_bias.inc scan_mfma16_common.inc; do git -C $ROOT show b12f680:metrovector_amd/csrc/$f > $d/$f; done
           src=$d/scan_mfma16_dma.hip

@@ -109,7 +109,7 @@ def main():
                 if rnd:
                     res[t].append((tm.scan_ms_avg, wall))
                 print(f"{name} round {rnd} {t:8s} last-phase {tm.scan_ms_avg:7.3f} ms  wall {wall:7.3f} ms  launches {tm.scan_launches} kernel {tm.scan_kernel} "
-                      f"same_as_first={same}", flush=True)
+                      f"repaired {tm.repaired_queries} same_as_first={same}", flush=True)
             if probe is not None and last_rows and nq % 256 == 0:
                 for v in pvars:
                     print(f"SEQ {name} probe{v}", flush=True)
