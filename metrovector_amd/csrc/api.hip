@@ -115,6 +115,7 @@ Tuning read_tuning() {
     t.k2_sb = flag("MVF_K2_SB", true);
     t.k2_pp = getenv("MVF_K2_PP") ? (int)flag("MVF_K2_PP", false) : -1;
     t.k2_growth = (uint32_t)std::max(2l, num("MVF_K2_GROWTH", 4));
+    t.k2_direct64 = (int)num("MVF_K2_DIRECT64", 1);
     t.k2_bias = flag("MVF_K2_BIAS", true);
     t.k2_persistent = getenv("MVF_K2_PERSISTENT") ? (int)flag("MVF_K2_PERSISTENT", false) : -1;
     t.k2_persistent16 = getenv("MVF_K2_PERSISTENT16") ? (int)flag("MVF_K2_PERSISTENT16", true) : -1;
@@ -1180,7 +1181,16 @@ int search_batched_range(const mvfgpu_corpus* c, uint8_t metric, const void* d_q
             if (wide) HIP_TRY(launch_scan_mfma_f32(bp, metric, c->num_cus, c->tune.k2_persistent, s));
             else if (use_pp) HIP_TRY(launch_scan_mfma16_pp(hp, kdtype, metric, c->num_cus, s));
             else if (use_sb) HIP_TRY(launch_scan_mfma16_sb(hp, kdtype, metric, c->num_cus, s));
-            else if (dma) HIP_TRY(launch_scan_mfma16_dma(hp, kdtype, metric, c->num_cus, qpb, persistent, s));
+            else if (dma && hp.direct && qpb == 256u && c->tune.k2_direct64) {
+                // The direct phase is a few thousand rows: 10 row tiles x 4 query tiles of 256 x 256 leave 216 CUs idle while 40 blocks
+                // multiply, key and store 65536 pairs each.  In 64-query tiles (64 x 512) the same pairs spread over twice the blocks
+                // at half the work each (the prepared queries and the slots by row offset do not depend on the tile shape).
+                Batch16Params dp = hp;
+                const uint32_t tr = scan_mfma16_dma_tile_rows(64u);
+                dp.mtiles = nq_pad / 64u;
+                dp.ntiles = (uint32_t)((end - begin + tr - 1) / tr);
+                HIP_TRY(launch_scan_mfma16_dma(dp, kdtype, metric, c->num_cus, 64u, persistent, s));
+            } else if (dma) HIP_TRY(launch_scan_mfma16_dma(hp, kdtype, metric, c->num_cus, qpb, persistent, s));
             else HIP_TRY(launch_scan_mfma16(hp, kdtype, metric, c->num_cus, c->tune.k2_persistent16, s));
             if (ps && last) {
                 HIP_TRY(hipEventRecord(ps->e[1], s));
