@@ -116,6 +116,7 @@ Tuning read_tuning() {
     t.k2_pp = getenv("MVF_K2_PP") ? (int)flag("MVF_K2_PP", false) : -1;
     t.k2_growth = (uint32_t)std::max(2l, num("MVF_K2_GROWTH", 4));
     t.k2_direct64 = (int)num("MVF_K2_DIRECT64", 1);
+    t.qs_refine_phases = (uint32_t)std::max(1l, num("MVF_QS_REFINE_PHASES", 2));
     t.k2_bias = flag("MVF_K2_BIAS", true);
     t.k2_persistent = getenv("MVF_K2_PERSISTENT") ? (int)flag("MVF_K2_PERSISTENT", false) : -1;
     t.k2_persistent16 = getenv("MVF_K2_PERSISTENT16") ? (int)flag("MVF_K2_PERSISTENT16", true) : -1;
@@ -1209,7 +1210,7 @@ int search_batched_range(const mvfgpu_corpus* c, uint8_t metric, const void* d_q
         if (approx) HIP_TRY(launch_compact_margin(cp, nq, s));
         else HIP_TRY(launch_compact(cp, nq, last, s));
         if (last) break;
-        if (refine && bounds[bi + 1] >= nr && nr - end >= kRefineMinRows) {  // worth its ~0.1 ms in front of the last (largest) phase
+        if (refine && bi + c->tune.qs_refine_phases >= bounds.size() - 1 && bounds[bi + 1] - end >= kRefineMinRows) {  // worth its ~0.07 ms in front of the last (largest) phases
             RescoreParams rp{};
             rp.cand = bp.cand;
             rp.cnt = cnt;

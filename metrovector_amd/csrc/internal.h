@@ -43,6 +43,7 @@ struct Tuning {
     bool i8_shadow_partial = true;  // MVF_I8_SHADOW_PARTIAL=0: no int8 shadow of a prefix of the rows where all rows do not fit
     uint64_t i8_shadow_rows = 0;    // MVF_I8_SHADOW_ROWS=n (tests): as if only the first n rows' shadow fitted
     bool qs_refine = true;      // MVF_QS_REFINE=0
+    uint32_t qs_refine_phases = 2;  // MVF_QS_REFINE_PHASES: the threshold is refined in front of this many of the last phases (round 5: 2; each costs ~70 us for 1024 queries and spares the phase behind it two thirds of its records)
     bool debug_repair = false;  // MVF_DEBUG_REPAIR: report repaired queries on stderr (synchronises inside a search)
     uint32_t repair_window = 0; // MVF_REPAIR_WINDOW: queries per repair launch pair (tests: several windows)
     uint64_t region_records = 0;  // MVF_K2_REGION_RECORDS: size of the candidate regions (tests: force overflows)
