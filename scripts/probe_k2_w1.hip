@@ -49,7 +49,7 @@ struct P {
 
 constexpr int DKB = 64, BMQ = 256, BR = 256, NSTAGE = 4, SH = 16;
 constexpr int A_B = BMQ * DKB, STAGE_B = A_B + BR * DKB;  // 32 KB
-constexpr size_t LDS_BYTES = (size_t)NSTAGE * STAGE_B;
+constexpr size_t LDS_BYTES = (size_t)NSTAGE * STAGE_B + 32768;  // (+ 32 KB: the deep-ring W8S variants; one block per CU either way)
 
 __device__ __forceinline__ uint32_t slot_swz(uint32_t x) { return (0x78u >> (2u * x)) & 3u; }
 
@@ -268,6 +268,156 @@ __global__ void __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) kloop_kernel(P p) {
     p.out[(size_t)blockIdx.x * (NW * 64) + tid] = check;
 }
 
+// W8S<NA, NB> (round 5, second half): W8NP with SPLIT rings and the DMA split BY WAVE -- waves 0..3 bring the A (query) pieces
+// into a ring of NA 16-KB stages, waves 4..7 the B (corpus row) pieces into a ring of NB.  vmcnt counts a wave's own loads in
+// order, so as long as every wave issues A and B pieces alike, A and B are prefetched equally far; a wave that only ever issues
+// one operand waits on that operand's depth alone.  The queries come out of L2 (every block reads the same ones), the rows out of
+// HBM: NA = 3, NB = 5 keeps the LDS of the 4 x 32 KB ring and holds two to three k-tiles of rows in flight instead of one to two.
+template <int NA, int NB>
+__global__ void __launch_bounds__(512, 2) kloop_split_kernel(P p) {
+    constexpr int NW = 8, WN = 4, WQ = 128, WR = BR / WN, NI = WQ / SH, NJ = WR / SH;
+    constexpr int PW = 4;                      // 1-KB pieces per wave and k-tile (A waves: of A; B waves: of B)
+    constexpr int B_B = BR * DKB, B_BASE = NA * A_B;
+    static_assert(BMQ / 16 == PW * NW / 2 && BR / 16 == PW * NW / 2 && NA >= 3 && NB >= 3, "shape");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const bool is_a = wave < NW / 2;           // wave-uniform
+    const int pw = wave & (NW / 2 - 1);
+
+    const uint32_t xcd = blockIdx.x & 7u, ls = blockIdx.x >> 3, nls = gridDim.x >> 3;
+    auto slot_tile = [&](uint32_t n, uint32_t& nt, uint32_t& mt) {
+        const uint32_t slot = ls + n * nls;
+        nt = (slot / p.mtiles) * 8u + xcd;
+        mt = slot % p.mtiles;
+    };
+    uint32_t my_tiles = 0;
+    {
+        const uint32_t max_slot_excl = ((p.ntiles + 7u - xcd) / 8u) * p.mtiles;
+        if (ls < max_slot_excl) my_tiles = (max_slot_excl - ls + nls - 1) / nls;
+    }
+    if (my_tiles == 0) return;
+    const uint32_t G = my_tiles * p.KT;
+
+    const uint32_t rl = (uint32_t)lane >> 2;
+    const uint32_t cl = ((uint32_t)lane & 3u) ^ slot_swz(((uint32_t)lane >> 4) & 3u);
+    uint32_t d_n = 0, d_kt = 0;                // this wave's DMA cursor (its own operand's)
+    const unsigned char* src[PW];
+    auto set_dma_tile = [&](uint32_t n) {
+        uint32_t nt, mt;
+        slot_tile(n, nt, mt);
+        const uint32_t r0 = nt * BR;
+#pragma unroll
+        for (int j = 0; j < PW; j++) {
+            if (is_a) {
+                src[j] = p.qprep + ((size_t)mt * BMQ + ((uint32_t)pw * PW + j) * 16u + rl) * p.KPB + cl * 16u;
+            } else {
+                const uint32_t r = r0 + ((uint32_t)pw * PW + j) * 16u + rl;
+                src[j] = p.rows + (size_t)(r < p.n ? r : r0) * p.pitch;
+            }
+        }
+    };
+    auto dma_piece = [&](uint32_t stage, int j) __attribute__((always_inline)) {
+        if (is_a) {
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)(src[j] + (size_t)d_kt * DKB), (lds_ptr_t)(smem + stage * A_B + (pw * PW + j) * (16 * DKB)), 16, 0, 0);
+        } else {
+            const uint32_t v = d_kt * 4u + cl;
+            const unsigned char* s = v < p.V ? src[j] + (size_t)v * 16u : p.zeros;
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)s, (lds_ptr_t)(smem + B_BASE + stage * B_B + (pw * PW + j) * (16 * DKB)), 16, 0, 0);
+        }
+    };
+    auto dma_advance = [&]() __attribute__((always_inline)) {
+        if (++d_kt == p.KT) {
+            d_kt = 0;
+            if (++d_n < my_tiles) set_dma_tile(d_n);
+        }
+    };
+
+    i32x4 acc[NI][NJ];
+#pragma unroll
+    for (int i = 0; i < NI; i++)
+#pragma unroll
+        for (int j = 0; j < NJ; j++) acc[i][j] = i32x4{0, 0, 0, 0};
+    uint32_t check = 0;
+
+    set_dma_tile(0);
+    const uint32_t my_stages = is_a ? NA : NB;
+    for (uint32_t st = 0; st + 1 < my_stages; st++) {
+#pragma unroll
+        for (int j = 0; j < PW; j++) dma_piece(st, j);
+        dma_advance();
+    }
+    if (is_a) __builtin_amdgcn_s_waitcnt(waitcnt_imm(PW * (NA - 2), 15));
+    else __builtin_amdgcn_s_waitcnt(waitcnt_imm(PW * (NB - 2), 15));
+    __syncthreads();
+
+    const uint32_t frow = (uint32_t)lane & (SH - 1), fchunk = (uint32_t)lane >> 4;
+    const uint32_t fslot = (fchunk ^ slot_swz((frow >> 2) & 3u)) & 3u;
+    const uint32_t a_off = ((uint32_t)wm * WQ + frow) * DKB + fslot * 16u;
+    const uint32_t b_off = B_BASE + ((uint32_t)wn * WR + frow) * DKB + fslot * 16u;
+    auto read_a = [&](uint32_t stage, int i) __attribute__((always_inline)) -> u32x4 {
+        return *reinterpret_cast<const u32x4*>(smem + stage * A_B + a_off + i * SH * DKB);
+    };
+    auto read_b = [&](uint32_t stage, int j) __attribute__((always_inline)) -> u32x4 {
+        return *reinterpret_cast<const u32x4*>(smem + stage * B_B + b_off + j * SH * DKB);
+    };
+    auto mfma1 = [&](i32x4& c, const u32x4& fa, const u32x4& fb) __attribute__((always_inline)) {
+        c = __builtin_amdgcn_mfma_i32_16x16x64_i8(__builtin_bit_cast(i32x4, fa), __builtin_bit_cast(i32x4, fb), c, 0, 0, 0);
+    };
+
+    uint32_t ca = 0, cb = 0, ds = my_stages - 1;  // compute stages of the two rings; this wave's DMA stage (in its own ring)
+    u32x4 fbc[NJ], fbd[NJ], fa[2];
+#pragma unroll
+    for (int j = 0; j < NJ; j++) fbc[j] = read_b(0, j);
+    fa[0] = read_a(0, 0);
+    for (uint32_t g = 0; g < G; g++) {
+        const uint32_t na = ca + 1 == NA ? 0 : ca + 1, nb = cb + 1 == NB ? 0 : cb + 1;
+#pragma unroll
+        for (int i = 0; i < NI; i++) {
+            if (i == NI / 2) {
+                // k-tile g+1 has landed: an A wave has nothing newer in flight (NA = 3), a B wave k-tiles g+2 .. g+NB-2
+                if (is_a) __builtin_amdgcn_s_waitcnt(waitcnt_imm(PW * (NA - 3), 15));
+                else __builtin_amdgcn_s_waitcnt(waitcnt_imm(PW * (NB - 3), 15));
+                asm volatile("" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+            }
+            auto reads = [&]() __attribute__((always_inline)) {
+                if (i + 1 < NI) fa[(i + 1) & 1] = read_a(ca, i + 1);
+                else fa[(i + 1) & 1] = read_a(na, 0);
+                if (i >= NI / 2) {
+#pragma unroll
+                    for (int j = 0; j < NJ / (NI / 2); j++) fbd[(i - NI / 2) * (NJ / (NI / 2)) + j] = read_b(nb, (i - NI / 2) * (NJ / (NI / 2)) + j);
+                }
+            };
+#pragma unroll
+            for (int j = 0; j < NJ; j++) {
+                mfma1(acc[i][j], fa[i & 1], fbc[j]);
+                if (j == 0) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    reads();
+                }
+            }
+            if (i >= NI / 2) dma_piece(ds, i - NI / 2);  // PW = NI / 2 pieces behind the barrier, one per group
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        dma_advance();
+        ca = na;
+        cb = nb;
+        ds = ds + 1 == my_stages ? 0 : ds + 1;
+#pragma unroll
+        for (int j = 0; j < NJ; j++) fbc[j] = fbd[j];
+    }
+#pragma unroll
+    for (int i = 0; i < NI; i++)
+#pragma unroll
+        for (int j = 0; j < NJ; j++) check += (uint32_t)(acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3]);
+    __builtin_amdgcn_s_waitcnt(waitcnt_imm(0, 0));
+    p.out[(size_t)blockIdx.x * (NW * 64) + tid] = check;
+}
+
 static uint64_t mix64(uint64_t z) {
     z += 0x9E3779B97F4A7C15ull;
     z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
@@ -315,6 +465,11 @@ static void (*variant_fn(const std::string& t, int* threads, const char** name))
     if (t == "8p") { *name = "W8P (W8, mid-tile barrier, next k-tile's fragments read under the second half)"; return &kloop_kernel<8, true>; }
     if (t == "8np") { *name = "W8NP (W8P + fragment requests behind the group's first MFMA)"; return &kloop_kernel<8, true, true>; }
     if (t == "8np2") { *name = "W8NP2 (W8NP, k-loop unrolled by two: the fragment sets swap roles)"; return &kloop_kernel<8, true, true, false, true>; }
+    if (t == "8s") { *name = "W8S<3,5> (W8NP, split rings: waves 0-3 bring A into 3 stages, waves 4-7 bring B into 5)"; return &kloop_split_kernel<3, 5>; }
+    if (t == "8s44") { *name = "W8S<4,4> (the split by wave alone: the rings as deep as W8NP's)"; return &kloop_split_kernel<4, 4>; }
+    if (t == "8s45") { *name = "W8S<4,5> (144 KB of LDS: the probe only)"; return &kloop_split_kernel<4, 5>; }
+    if (t == "8s46") { *name = "W8S<4,6> (160 KB of LDS: the probe only)"; return &kloop_split_kernel<4, 6>; }
+    if (t == "8s36") { *name = "W8S<3,6> (144 KB of LDS: the probe only)"; return &kloop_split_kernel<3, 6>; }
     if (t == "8ns") { *name = "W8NS (W8N + waves 4..7 at s_setprio 1)"; return &kloop_kernel<8, false, true, true>; }
     *threads = 256;
     if (t == "4") { *name = "W4  (4 waves, 128x128, one per SIMD)"; return &kloop_kernel<4, false>; }
