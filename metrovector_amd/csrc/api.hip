@@ -116,7 +116,7 @@ Tuning read_tuning() {
     t.k2_pp = getenv("MVF_K2_PP") ? (int)flag("MVF_K2_PP", false) : -1;
     t.k2_growth = (uint32_t)std::max(2l, num("MVF_K2_GROWTH", 4));
     t.k2_direct64 = (int)num("MVF_K2_DIRECT64", 1);
-    t.qs_refine_phases = (uint32_t)std::max(1l, num("MVF_QS_REFINE_PHASES", 2));
+    t.qs_refine_phases = (uint32_t)std::max(0l, num("MVF_QS_REFINE_PHASES", 2));
     t.k2_bias = flag("MVF_K2_BIAS", true);
     t.k2_persistent = getenv("MVF_K2_PERSISTENT") ? (int)flag("MVF_K2_PERSISTENT", false) : -1;
     t.k2_persistent16 = getenv("MVF_K2_PERSISTENT16") ? (int)flag("MVF_K2_PERSISTENT16", true) : -1;
@@ -797,6 +797,11 @@ hipError_t ensure_shadow8(const mvfgpu_corpus* c, hipStream_t s, bool insist, bo
 // the corpus -- when that is at least this many rows (in front of the second largest phase too it cost what it saved);
 // MVF_QS_REFINE=0 switches it off (A/B runs).
 constexpr uint64_t kRefineMinRows = 200000;
+// ... and in front of a phase only where the phase is worth it: a refinement is ~12-16 us of latency whatever the batch, what it
+// spares the phase behind it grows with queries x rows.  One process, the switch toggled between rounds (scripts/probe_tune_ab.py,
+// profiles/r05_k2_walk_and_phase_costs.txt 8c): 16 / 64 queries on 1M x 768 -4 % without, 32 on 3M -1.3 %, 16 on 10M -1 %;
+// 64 on 10M +1 % without, 128 and more: with.
+constexpr uint64_t kRefineMinPairs = 256ull << 20;
 bool qs_refine_enabled(const mvfgpu_corpus* c) { return c->tune.qs_refine; }
 
 // K2 per-query state (threshold key, candidate count, overflow flag; for the refinement the number of best candidates
@@ -1210,7 +1215,8 @@ int search_batched_range(const mvfgpu_corpus* c, uint8_t metric, const void* d_q
         if (approx) HIP_TRY(launch_compact_margin(cp, nq, s));
         else HIP_TRY(launch_compact(cp, nq, last, s));
         if (last) break;
-        if (refine && bi + c->tune.qs_refine_phases >= bounds.size() - 1 && bounds[bi + 1] - end >= kRefineMinRows) {  // worth its ~0.07 ms in front of the last (largest) phases
+        if (refine && c->tune.qs_refine_phases && bi + c->tune.qs_refine_phases >= bounds.size() - 1 && bounds[bi + 1] - end >= kRefineMinRows &&
+            (uint64_t)nq * (bounds[bi + 1] - end) >= kRefineMinPairs) {  // worth its ~0.07 ms in front of the last (largest) phases
             RescoreParams rp{};
             rp.cand = bp.cand;
             rp.cnt = cnt;

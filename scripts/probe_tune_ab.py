@@ -9,7 +9,9 @@ var, modes = sys.argv[1], sys.argv[2].split(",")
 names = (sys.argv[3] if len(sys.argv) > 3 else "cfg3,cfg5,cfg4").split(",")
 rounds = int(sys.argv[4]) if len(sys.argv) > 4 else 10
 CFGS = {"cfg3": (10_000_000, 768, 0, 2, 1024), "cfg5": (12_500_000, 1024, 1, 0, 1024), "cfg4": (50_000_000, 768, 2, 1, 256),
-        "cfg3f16": (10_000_000, 768, 1, 2, 1024), "q256": (10_000_000, 768, 0, 2, 256), "q4096": (4_000_000, 768, 0, 2, 4096)}
+        "cfg3f16": (10_000_000, 768, 1, 2, 1024), "q256": (10_000_000, 768, 0, 2, 256), "q4096": (4_000_000, 768, 0, 2, 4096),
+        "q16_1m": (1_000_000, 768, 0, 2, 16), "q64_1m": (1_000_000, 768, 0, 2, 64), "q16": (10_000_000, 768, 0, 2, 16), "q64": (10_000_000, 768, 0, 2, 64),
+        "q128": (10_000_000, 768, 0, 2, 128), "q32_3m": (3_000_000, 768, 0, 2, 32)}
 lib = _lib.gpu()
 k = 100
 for name in names:
