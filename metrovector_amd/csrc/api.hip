@@ -115,6 +115,7 @@ Tuning read_tuning() {
     t.k2_sb = flag("MVF_K2_SB", true);
     t.k2_pp = getenv("MVF_K2_PP") ? (int)flag("MVF_K2_PP", false) : -1;
     t.k2_growth = (uint32_t)std::max(2l, num("MVF_K2_GROWTH", 4));
+    t.k2_growth_small = (uint32_t)std::max(2l, num("MVF_K2_GROWTH_SMALL", getenv("MVF_K2_GROWTH") ? (long)t.k2_growth : 6));
     t.k2_direct64 = (int)num("MVF_K2_DIRECT64", 1);
     t.qs_refine_phases = (uint32_t)std::max(0l, num("MVF_QS_REFINE_PHASES", 2));
     t.k2_bias = flag("MVF_K2_BIAS", true);
@@ -602,7 +603,16 @@ bool k2_pp_wanted(const mvfgpu_corpus* c, uint8_t kdtype, uint32_t ntiles, uint3
 // several per 256 x 256 tile at g = 8, and every candidate sends its wave through the epilogue's second stage.  g = 4
 // costs one or two more (small) launches and measured 2-3 % faster on cfg3 / cfg5 / cfg4 (profiles/r02_k2_ab.txt); g = 16
 // and 32 were 4 % slower in round 1.
-uint32_t k2_growth_cap(const mvfgpu_corpus* c) { return c->tune.k2_growth; }
+// Batches of up to 64 queries (round 5, one process, the switch toggled between rounds -- profiles/r05_k2_walk_and_phase_costs.txt 8d): their
+// scans are HBM-bound and their small kernels pure latency, so a phase less is worth more than its records cost: g = 6 is 2-4 % faster than
+// 4 on 1M-3M rows, 0.6-1.5 % on 10M (g = 8 the same or a little more; 6 keeps a phase's records near half of the list capacity).
+// Only where a phase's records stay near half of the list capacity: with the int8 selection's margin a phase files about
+// 7 k (g - 1) records per query (measured: 1800 at k = 100, g = 4), so g <= 1 + cap / (14 k) -- k <= 117 for g = 6 on 8192 slots.
+uint32_t k2_growth_for(const mvfgpu_corpus* c, uint32_t nq, uint32_t k, uint32_t cap) {
+    uint32_t g = std::min(c->tune.k2_growth, std::max(2u, cap / (2u * k)));
+    if (nq <= 64u) g = std::max(g, std::min(c->tune.k2_growth_small, 1u + cap / (14u * k)));
+    return g;
+}
 
 // The folded pre-filter of the LDS-DMA kernel's i32-accumulator flavours (scan_mfma16_bias.inc); MVF_K2_BIAS=0 keeps
 // round 2's epilogue (A/B runs).
@@ -1137,7 +1147,7 @@ int search_batched_range(const mvfgpu_corpus* c, uint8_t metric, const void* d_q
     // phase, the last one included, scans (g - 1) times what its threshold has seen, and the last phase is always the
     // largest ((1 - 1/g) of the rows: the launch bench.py times and prices).  Round 1 grew forwards from cap rows, which
     // left a small odd phase at the end (and the one before it carrying most of the corpus).
-    const uint32_t g = std::min(k2_growth_cap(c), std::max(2u, cap / (2u * k)));
+    const uint32_t g = k2_growth_for(c, nq, k, cap);
     std::vector<uint64_t> bounds;  // R_1 .. R_{P+1} = n
     {
         uint32_t P = 0;
