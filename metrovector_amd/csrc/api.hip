@@ -603,14 +603,15 @@ bool k2_pp_wanted(const mvfgpu_corpus* c, uint8_t kdtype, uint32_t ntiles, uint3
 // several per 256 x 256 tile at g = 8, and every candidate sends its wave through the epilogue's second stage.  g = 4
 // costs one or two more (small) launches and measured 2-3 % faster on cfg3 / cfg5 / cfg4 (profiles/r02_k2_ab.txt); g = 16
 // and 32 were 4 % slower in round 1.
-// Batches of up to 64 queries (round 5, one process, the switch toggled between rounds -- profiles/r05_k2_walk_and_phase_costs.txt 8d): their
+// Batches of up to 128 queries (round 5, one process, the switch toggled between rounds -- profiles/r05_k2_walk_and_phase_costs.txt 8d): their
 // scans are HBM-bound and their small kernels pure latency, so a phase less is worth more than its records cost: g = 6 is 2-4 % faster than
-// 4 on 1M-3M rows, 0.6-1.5 % on 10M (g = 8 the same or a little more; 6 keeps a phase's records near half of the list capacity).
+// 4 on 1M-3M rows, 0.6-1.5 % on 10M (g = 8 the same or a little more; 6 keeps a phase's records near half of the list capacity); 128 queries
+// -4 % on 3M and 10M rows; 256 queries -2.4 % / -0.9 % / +1.4 % on three shapes, 384 and more: 4 wins.
 // Only where a phase's records stay near half of the list capacity: with the int8 selection's margin a phase files about
 // 7 k (g - 1) records per query (measured: 1800 at k = 100, g = 4), so g <= 1 + cap / (14 k) -- k <= 117 for g = 6 on 8192 slots.
 uint32_t k2_growth_for(const mvfgpu_corpus* c, uint32_t nq, uint32_t k, uint32_t cap) {
     uint32_t g = std::min(c->tune.k2_growth, std::max(2u, cap / (2u * k)));
-    if (nq <= 64u) g = std::max(g, std::min(c->tune.k2_growth_small, 1u + cap / (14u * k)));
+    if (nq <= 128u) g = std::max(g, std::min(c->tune.k2_growth_small, 1u + cap / (14u * k)));
     return g;
 }
 

@@ -33,7 +33,7 @@ struct Tuning {
     bool k2_sb = true;          // MVF_K2_SB=0: the 64-query tile shape instead of the streaming MFMA kernel
     int k2_pp = -1;             // MVF_K2_PP=0|1: force the lockstep / ping-pong schedule on 256-query tiles
     uint32_t k2_growth = 4;     // MVF_K2_GROWTH: largest phase-to-phase growth of the batched scan
-    uint32_t k2_growth_small = 6;  // MVF_K2_GROWTH_SMALL: ... of batches of up to 64 queries (the streaming MFMA kernel: HBM-bound, its records cost it little); follows MVF_K2_GROWTH where only that is set
+    uint32_t k2_growth_small = 6;  // MVF_K2_GROWTH_SMALL: ... of batches of up to 128 queries (HBM-bound scans: their records cost them little); follows MVF_K2_GROWTH where only that is set
     int k2_direct64 = 1;        // MVF_K2_DIRECT64: the direct phase of a 256-query-tile search runs in 64-query tiles (more, smaller blocks: it is all latency)
     bool k2_bias = true;        // MVF_K2_BIAS=0: round 2's epilogue instead of the folded pre-filter
     int k2_persistent = -1;     // MVF_K2_PERSISTENT: the f32 MFMA kernel's grid

@@ -11,7 +11,8 @@ rounds = int(sys.argv[4]) if len(sys.argv) > 4 else 10
 CFGS = {"cfg3": (10_000_000, 768, 0, 2, 1024), "cfg5": (12_500_000, 1024, 1, 0, 1024), "cfg4": (50_000_000, 768, 2, 1, 256),
         "cfg3f16": (10_000_000, 768, 1, 2, 1024), "q256": (10_000_000, 768, 0, 2, 256), "q4096": (4_000_000, 768, 0, 2, 4096),
         "q16_1m": (1_000_000, 768, 0, 2, 16), "q64_1m": (1_000_000, 768, 0, 2, 64), "q16": (10_000_000, 768, 0, 2, 16), "q64": (10_000_000, 768, 0, 2, 64),
-        "q128": (10_000_000, 768, 0, 2, 128), "q32_3m": (3_000_000, 768, 0, 2, 32)}
+        "q128": (10_000_000, 768, 0, 2, 128), "q512": (10_000_000, 768, 0, 2, 512), "q256_c5": (12_500_000, 1024, 1, 0, 256),
+        "q128_3m": (3_000_000, 768, 0, 1, 128), "q384": (10_000_000, 768, 0, 2, 384), "q256_d128": (20_000_000, 128, 0, 0, 256), "q32_3m": (3_000_000, 768, 0, 2, 32)}
 lib = _lib.gpu()
 k = 100
 for name in names:
