@@ -1198,7 +1198,7 @@ int search_batched_range(const mvfgpu_corpus* c, uint8_t metric, const void* d_q
             if (wide) HIP_TRY(launch_scan_mfma_f32(bp, metric, c->num_cus, c->tune.k2_persistent, s));
             else if (use_pp) HIP_TRY(launch_scan_mfma16_pp(hp, kdtype, metric, c->num_cus, s));
             else if (use_sb) HIP_TRY(launch_scan_mfma16_sb(hp, kdtype, metric, c->num_cus, s));
-            else if (dma && hp.direct && qpb == 256u && c->tune.k2_direct64) {
+            else if (dma && hp.direct && qpb >= 128u && c->tune.k2_direct64) {
                 // The direct phase is a few thousand rows: 10 row tiles x 4 query tiles of 256 x 256 leave 216 CUs idle while 40 blocks
                 // multiply, key and store 65536 pairs each.  In 64-query tiles (64 x 512) the same pairs spread over twice the blocks
                 // at half the work each (the prepared queries and the slots by row offset do not depend on the tile shape).
