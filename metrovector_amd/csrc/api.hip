@@ -1565,8 +1565,12 @@ bool use_batched_path(const mvfgpu_corpus* c, uint8_t metric, uint32_t nq) {
             if (nq <= 16 && bytes <= (32ull << 20) && row_bytes >= 512u) return false;
         }
     }
-    const uint32_t threshold = bytes < (8ull << 20)                           ? 33u  // (32 queries = 8 fused passes: 37-39 us against 73-85)
-                               : bytes < (16ull << 20)                        ? 32u
+    // (round 5, the same probe on the final tree: K1's passes over SHORT rows cost by the row, not by the byte -- 100k x 128 int8,
+    //  13 MB: 12 / 16 queries 111 / 145 us against 97 / 96 batched; 30k x 128 f16, 7.7 MB, whose rows K1 converts: 16 / 32 queries
+    //  79 / 153 us against 72 / 76)
+    const uint32_t small = c->n >= 65536u ? 12u : (c->n >= 24576u && c->dtype == MVF_DTYPE_FLOAT16) ? 16u : 0u;
+    const uint32_t threshold = bytes < (8ull << 20)                           ? (small ? small : 33u)  // (32 queries = 8 fused passes: 37-39 us against 73-85)
+                               : bytes < (16ull << 20)                        ? (small ? small : 32u)
                                : c->dtype == MVF_DTYPE_FLOAT32 && !shadowed ? (bytes < (1ull << 30) ? 32u : 9u)
                                : is_int_dtype(c->dtype)                     ? (bytes < ((c->pitch <= 256u ? 2ull : 4ull) << 29) ? 5u : 2u)
                                                                             : 2u;
