@@ -175,3 +175,30 @@ def test_select_and_sort_of_long_lists_with_ties(oracle):
             assert_exact(got, *oracle.search(rows, 2, 1, q, k))
         one = c.search(q[0], 131_073, G.L2)  # one query per pass, survivors one past the 11-bit form's limit
         assert_exact(one, *oracle.search(rows, 2, 0, q[:1], 131_073))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Part 5 -- the schedule switches of the round's second half change WHEN thresholds tighten and how the phases are cut,
+# never what is returned: the same handle under every value of each switch (mvfgpu_corpus_reload_tuning re-reads them)
+# returns the same rows and the same score bits, and they are the oracle's.
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dt,metric,nq,k", [(0, 2, 16, 100), (0, 0, 100, 10), (1, 2, 128, 100), (0, 2, 400, 100), (1, 0, 1030, 50)])
+def test_phase_schedule_switches_do_not_change_the_results(oracle, monkeypatch, dt, metric, nq, k):
+    n, dim = 1_200_000, 128
+    q = oracle.synth_queries(SEED + 1, nq, dim, dt)
+    with G.GpuCorpus.synthetic(n, dim, dt, SEED) as c:
+        base = c.search(q, k, metric)
+        sel = [0, nq // 2, nq - 1]
+        all_sc = oracle_scores_all_rows(oracle, SEED, 0, n, dim, dt, metric, q[sel], chunk=400_000)
+        for j, qi in enumerate(sel):
+            assert_float_topk(metric, base.scores[qi], base.indices[qi], all_sc[j], None, q[qi], k)
+        for var, values in (("MVF_K2_GROWTH_SMALL", ("4", "8")), ("MVF_K2_GROWTH", ("3", "6")), ("MVF_QS_REFINE_PHASES", ("0", "1", "3")),
+                            ("MVF_K2_DIRECT64", ("0",))):
+            for v in values:
+                monkeypatch.setenv(var, v)
+                c.reload_tuning()
+                r = c.search(q, k, metric)
+                assert (r.indices == base.indices).all(), f"{var}={v}: other rows"
+                assert (r.scores.view(np.uint32) == base.scores.view(np.uint32)).all(), f"{var}={v}: other score bits"
+            monkeypatch.delenv(var)
+        c.reload_tuning()
