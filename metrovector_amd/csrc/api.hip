@@ -172,6 +172,7 @@ struct mvfgpu_corpus {
     mutable DevBuf cand;                  // scratch: per-block candidate lists (K1)
     mutable DevBuf bq, bstate, bcand, xnorm;  // K2: padded queries + norms; tau/cnt/overflow; candidates; row norms
     mutable DevBuf blk;                   // K2 narrow types: per-block candidate regions + their counts (scan_mfma.h)
+    mutable const void* blk_armed_cnt = nullptr;  // the region counters at this address are all zero: the last batched search's scatters left them so
     mutable DevBuf repair;                // K2 overflow repair: gathered queries + their results
     mutable std::vector<std::pair<uint64_t, int>> occ_cache;  // (kernel, dynamic LDS) -> blocks per CU (scan_occupancy)
     mutable const unsigned char* bq_zeros = nullptr;  // where the prepared-query buffer's 64 zero bytes were last set ...
@@ -208,6 +209,7 @@ struct mvfgpu_corpus {
     // search the pending count belongs to used the folded pre-filter; fb_qs: it selected on the int8 shadow)
     mutable bool bias_disabled = false, fb_bias[2] = {false, false}, fb_qs[2] = {false, false};
     mutable const uint32_t* last_redo_cnt = nullptr;  // device: the count the newest repair pass produced
+    mutable const uint32_t* fb_mirrored = nullptr;    // the pinned slot flag_compact_kernel of the newest repair pass stored that count into itself (no copy then)
     mutable bool xnorm_ready = false;
     mutable uint32_t bstate_slots = 0;    // queries the K2 state arrays are armed for
     mutable DevBuf h_q, h_s, h_i, h_r;    // device mirrors for the host-buffer API
@@ -738,18 +740,37 @@ void qs_feedback_poll(const mvfgpu_corpus* c) {
                 bias_was != c->bias_disabled ? "folded pre-filter" : "int8-shadow selection");
 }
 
-// ... and the request for it: the repair count of the search just enqueued, copied to pinned memory behind an event.
+int feedback_slots(const mvfgpu_corpus* c) {
+    if (c->qs_redo_host) return MVF_OK;
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&c->qs_redo_host), 64, hipHostMallocDefault));
+    HIP_TRY(hipEventCreateWithFlags(&c->qs_redo_ev[0], hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&c->qs_redo_ev[1], hipEventDisableTiming));
+    return MVF_OK;
+}
+
+// The pinned slot the next post will use, for the repair pass's flag_compact_kernel to store its count into directly (round 5:
+// the 4-byte copy behind every batched search was a launch of its own, 4.1 us) -- NULL while that slot still holds a sample
+// nobody has consumed (the post will skip it too).
+uint32_t* feedback_mirror(const mvfgpu_corpus* c) {
+    c->fb_mirrored = nullptr;
+    if (feedback_slots(c) != MVF_OK || c->qs_redo_pending[c->qs_slot]) return nullptr;
+    c->fb_mirrored = c->qs_redo_host + c->qs_slot;
+    return c->qs_redo_host + c->qs_slot;
+}
+
+// ... and the request for it: the repair count of the search just enqueued, in pinned memory behind an event.
 int qs_feedback_post(const mvfgpu_corpus* c, uint32_t nq, hipStream_t s, bool used_bias = false, bool used_qs = true) {
     const uint32_t sl = c->qs_slot;
     if (c->qs_redo_pending[sl] || !c->repair.p) return MVF_OK;  // (pending: this search did not poll -- it took another path first)
-    if (!c->qs_redo_host) {
-        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&c->qs_redo_host), 64, hipHostMallocDefault));
-        HIP_TRY(hipEventCreateWithFlags(&c->qs_redo_ev[0], hipEventDisableTiming));
-        HIP_TRY(hipEventCreateWithFlags(&c->qs_redo_ev[1], hipEventDisableTiming));
+    {
+        int rc = feedback_slots(c);
+        if (rc != MVF_OK) return rc;
     }
     c->fb_bias[sl] = used_bias;
     c->fb_qs[sl] = used_qs;
-    HIP_TRY(hipMemcpyAsync(c->qs_redo_host + sl, c->last_redo_cnt, 4, hipMemcpyDeviceToHost, s));
+    if (c->fb_mirrored != c->qs_redo_host + sl)  // (the repair pass could not store it there itself)
+        HIP_TRY(hipMemcpyAsync(c->qs_redo_host + sl, c->last_redo_cnt, 4, hipMemcpyDeviceToHost, s));
+    c->fb_mirrored = nullptr;
     HIP_TRY(hipEventRecord(c->qs_redo_ev[sl], s));
     c->qs_redo_pending[sl] = true;
     c->qs_redo_nq[sl] = nq;
@@ -896,7 +917,7 @@ int repair_flagged_queries(const mvfgpu_corpus* c, uint8_t metric, const void* d
     uint64_t* lists = static_cast<uint64_t*>(c->repair.p);
     uint32_t* redo_cnt = reinterpret_cast<uint32_t*>(static_cast<unsigned char*>(c->repair.p) + (size_t)R * per_query);
     uint32_t* redo_list = redo_cnt + 4;
-    HIP_TRY(launch_flag_compact(overflow, nq, redo_list, redo_cnt, s));
+    HIP_TRY(launch_flag_compact(overflow, nq, redo_list, redo_cnt, feedback_mirror(c), s));
     c->last_redo_cnt = redo_cnt;
     for (uint32_t base = 0; base < nq; base += R) {
         ScanParams sp{};
@@ -1097,7 +1118,11 @@ int search_batched_range(const mvfgpu_corpus* c, uint8_t metric, const void* d_q
         if (c->tune.region_records)  // MVF_K2_REGION_RECORDS (tests: force the regions to overflow)
             blk_records = std::max<uint64_t>((uint64_t)kBlkMaxBlocks * kBlkWaves, c->tune.region_records);
         blk_records -= blk_records % ((uint64_t)kBlkMaxBlocks * kBlkWaves);
-        HIP_TRY(c->blk.reserve((size_t)blk_records * 16 + (size_t)kBlkMaxBlocks * kBlkWaves * 4));
+        {
+            const void* before = c->blk.p;
+            HIP_TRY(c->blk.reserve((size_t)blk_records * 16 + (size_t)kBlkMaxBlocks * kBlkWaves * 4));
+            if (c->blk.p != before) c->blk_armed_cnt = nullptr;  // fresh memory
+        }
         hp.blk_cand = static_cast<uint4*>(c->blk.p);
         hp.blk_cnt = reinterpret_cast<uint32_t*>(static_cast<unsigned char*>(c->blk.p) + (size_t)blk_records * 16);
         hp.blk_cap = (uint32_t)(blk_records / kBlkMaxBlocks);
@@ -1165,7 +1190,11 @@ int search_batched_range(const mvfgpu_corpus* c, uint8_t metric, const void* d_q
     }
     size_t bi = 0;
     uint64_t begin = 0, end = bounds[0];
-    bool regions_armed = false, used_bias = false;
+    // The region counters are zero when a search starts if the search before it on this handle left them so (every scatter re-arms
+    // what it has read) and they still sit at the same address: no fill kernel per search then (4.7 us: 1.6 % of a 16-query search
+    // on 1M rows).  The mark is taken down while this search runs: a search that fails half way leaves it down.
+    bool regions_armed = hp.blk_cnt != nullptr && c->blk_armed_cnt == hp.blk_cnt, used_bias = false;
+    c->blk_armed_cnt = nullptr;
     for (;;) {
         const bool last = end >= nr;
         if (end > begin) {
@@ -1244,6 +1273,7 @@ int search_batched_range(const mvfgpu_corpus* c, uint8_t metric, const void* d_q
         begin = end;
         end = bounds[++bi];
     }
+    if (hp.blk_cnt && nq_pad <= scatter_rearm_max_queries()) c->blk_armed_cnt = hp.blk_cnt;  // every phase's scatter has been enqueued
     if (approx) {  // exact scores of the kept candidates from the caller's f32 queries, final top-k
         if (refine && nr >= kRefineMinRows) {  // once more on the final lists: the re-scoring skips what falls outside
             RescoreParams fp{};
@@ -2001,6 +2031,7 @@ void mvfgpu_corpus_destroy(mvfgpu_corpus* c) {
         c->bstate.release();
         c->bcand.release();
         c->blk.release();
+        c->blk_armed_cnt = nullptr;
         c->xnorm.release();
         c->repair.release();
         c->floor1.release();

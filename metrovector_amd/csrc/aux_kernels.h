@@ -59,7 +59,8 @@ struct SelectParams {
 };
 
 // queries flagged by the K2 compactions -> a dense list + its length, flags cleared (one block)
-hipError_t launch_flag_compact(uint32_t* overflow, uint32_t nq, uint32_t* redo_list, uint32_t* redo_cnt, hipStream_t s);
+hipError_t launch_flag_compact(uint32_t* overflow, uint32_t nq, uint32_t* redo_list, uint32_t* redo_cnt, uint32_t* host_mirror /* pinned, or NULL */,
+                               hipStream_t s);
 
 struct ShardMergeParams {
     const float* scores;      // list l, query q, rank j at [l * ls_scores + q * k + j]

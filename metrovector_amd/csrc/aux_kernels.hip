@@ -252,7 +252,8 @@ __global__ void __launch_bounds__(256) write_sorted_kernel(SelectParams p, const
 
 // The K2 compactions flag queries whose candidate budget overflowed (overflow[q] != 0).  One block turns the flags into
 // a dense list for the repair launches and clears them.  Order within the list is irrelevant.
-__global__ void __launch_bounds__(1024) flag_compact_kernel(uint32_t* overflow, uint32_t nq, uint32_t* redo_list, uint32_t* redo_cnt) {
+__global__ void __launch_bounds__(1024) flag_compact_kernel(uint32_t* overflow, uint32_t nq, uint32_t* redo_list, uint32_t* redo_cnt,
+                                                             uint32_t* host_mirror) {
     __shared__ uint32_t n_s;
     if (threadIdx.x == 0) n_s = 0;
     __syncthreads();
@@ -263,7 +264,10 @@ __global__ void __launch_bounds__(1024) flag_compact_kernel(uint32_t* overflow, 
         }
     }
     __syncthreads();
-    if (threadIdx.x == 0) *redo_cnt = n_s;
+    if (threadIdx.x == 0) {
+        *redo_cnt = n_s;
+        if (host_mirror) *host_mirror = n_s;  // pinned host memory: the repair feedback reads it two searches later, behind an event
+    }
 }
 
 // Cross-shard merge of formatted results.  An entry is the u64 composite (order key << 32 | slot), slot = list * k +
@@ -445,8 +449,8 @@ hipError_t launch_merge_write(const ShardMergeParams& p, uint32_t q, const uint6
     return hipGetLastError();
 }
 
-hipError_t launch_flag_compact(uint32_t* overflow, uint32_t nq, uint32_t* redo_list, uint32_t* redo_cnt, hipStream_t s) {
-    hipLaunchKernelGGL(flag_compact_kernel, dim3(1), dim3(1024), 0, s, overflow, nq, redo_list, redo_cnt);
+hipError_t launch_flag_compact(uint32_t* overflow, uint32_t nq, uint32_t* redo_list, uint32_t* redo_cnt, uint32_t* host_mirror, hipStream_t s) {
+    hipLaunchKernelGGL(flag_compact_kernel, dim3(1), dim3(1024), 0, s, overflow, nq, redo_list, redo_cnt, host_mirror);
     return hipGetLastError();
 }
 
