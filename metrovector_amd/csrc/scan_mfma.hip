@@ -761,8 +761,8 @@ __global__ void __launch_bounds__(256) rescore_score_kernel(RescoreParams p, con
             const uint32_t ci = c0 + (uint32_t)wave * 4u + u;
             if (REFINE) {
                 if (lane == 0 && ci < m) atomicMax(&lkey[q], key_from_score(sc, METRIC));  // the worst of the exact scores
-            } else if (lane == 0 && ci < m) {
-                c[ci] = skip[u] ? kPadComposite : ((uint64_t)key_from_score(sc, METRIC) << 32) | r[u];
+            } else if (lane == 0 && ci < m) {  // (out of place: the list's free upper half -- see rescore_wave_kernel)
+                c[keep_cap + ci] = skip[u] ? kPadComposite : ((uint64_t)key_from_score(sc, METRIC) << 32) | r[u];
             }
         }
     }
@@ -818,7 +818,7 @@ __global__ void __launch_bounds__(256) rescore_wave_kernel(RescoreParams p, uint
             const uint64_t ce = ci < m ? c[ci] : kPadComposite;
             // outside the (possibly refined) threshold: cannot be in the top-k; not fetched, not scored
             const bool live = ci < m && (REFINE || tau_q == kNanKey || (uint32_t)(ce >> 32) <= tau_q);
-            if (!REFINE && part == 0 && ci < m && !live) c[ci] = kPadComposite;
+            if (!REFINE && part == 0 && ci < m && !live) c[keep_cap + ci] = kPadComposite;
             const uint32_t myrow = (uint32_t)ce;
             unsigned long long mask = __builtin_amdgcn_ballot_w64(live);
             for (uint32_t rnd = 0; mask; rnd++) {  // wave-uniform
@@ -886,7 +886,7 @@ __global__ void __launch_bounds__(256) rescore_wave_kernel(RescoreParams p, uint
                     if (REFINE) {
                         if (ok[u]) worst = max(worst, key);
                     } else if (ok[u] && lane == l[u]) {
-                        c[ci] = ((uint64_t)key << 32) | myrow;
+                        c[keep_cap + ci] = ((uint64_t)key << 32) | myrow;
                     }
                 }
             }
@@ -899,10 +899,13 @@ template <int METRIC, bool REFINE>
 bool launch_rescore_wave(const RescoreParams& p, uint32_t nq, uint32_t slices, const uint32_t* ntop, uint32_t* lkey, hipStream_t s) {
     const uint32_t V = p.pitch / 16, vpl = (V + 63u) / 64u;
     if (vpl == 0 || vpl > 4u || (p.dtype != MVF_DTYPE_FLOAT32 && p.dtype != MVF_DTYPE_FLOAT16)) return false;  // longer rows: the block kernel
-    // waves that share a slice: enough items to fill the chip with a small batch (a slice holds at most 16 rounds)
-    // REFINE only: the final pass writes the exact keys back into the list in place, and a wave that started late would
-    // read them as if they were the approximate ones (its ballot, and with it the partition of the rounds, would differ)
-    const uint32_t split = REFINE ? std::max(1u, std::min(16u, 4096u / std::max(1u, nq * slices))) : 1u;
+    // waves that share a slice: enough items to fill the chip with a small batch (a slice holds at most 16 rounds).  The final
+    // pass too since round 5: it writes the exact keys into the list's free UPPER half (a query keeps at most cap / 2 candidates;
+    // rescore_select_kernel reads them there), so a wave that starts late still finds the approximate keys its ballot needs.
+    // (In place, the final pass could not split: the k best sit at the head of the list -- the refinement's order -- so its first
+    // two slices were 16 dependent rounds of random row fetches each, 40 us whatever the batch: 16 queries on 1M x 768 spent a
+    // seventh of the search there.)
+    const uint32_t split = std::max(1u, std::min(16u, 16384u / std::max(1u, nq * slices)));
     const uint32_t items = nq * slices * split;
     const dim3 grid(std::max(1u, std::min((items + 3u) / 4u, 2048u)));
     const bool h = p.dtype == MVF_DTYPE_FLOAT16;
@@ -943,7 +946,7 @@ __global__ void __launch_bounds__(1024) rescore_select_kernel(RescoreParams p, i
     const uint32_t q = blockIdx.x;
     const uint32_t keep_cap = p.cap / 2;
     const uint32_t m0 = min(p.cnt[q], keep_cap);
-    const uint64_t* c = p.cand + (size_t)q * p.cap;
+    const uint64_t* c = p.cand + (size_t)q * p.cap + keep_cap;  // the scoring pass's output: the list's upper half
     // only the candidates the scoring pass kept (it pads the ones outside the refined threshold: four fifths of an
     // int8-selected list) are sorted: ~300 of ~1500 on cfg3, a 512-entry network instead of a 2048-entry one
     __shared__ uint32_t live_s;
