@@ -904,8 +904,9 @@ bool launch_rescore_wave(const RescoreParams& p, uint32_t nq, uint32_t slices, c
     // rescore_select_kernel reads them there), so a wave that starts late still finds the approximate keys its ballot needs.
     // (In place, the final pass could not split: the k best sit at the head of the list -- the refinement's order -- so its first
     // two slices were 16 dependent rounds of random row fetches each, 40 us whatever the batch: 16 queries on 1M x 768 spent a
-    // seventh of the search there.)
-    const uint32_t split = std::max(1u, std::min(16u, 16384u / std::max(1u, nq * slices)));
+    // seventh of the search there.)  Items to aim for: 8192 (final pass, us, 16 / 64 / 128 / 256 queries: 2048 -> 25 / 43 / 53 / 65; 4096 -> 19 / 43 / 51 / 63;
+    // 8192 -> 13 / 25 / 51 / 65; 16384 -> 18 / 28 / 54 / 64; 65536 -> 18 / 48 / 70 / 72: profiles/r05_k2_walk_and_phase_costs.txt 13).
+    const uint32_t split = std::max(1u, std::min(16u, 8192u / std::max(1u, nq * slices)));
     const uint32_t items = nq * slices * split;
     const dim3 grid(std::max(1u, std::min((items + 3u) / 4u, 2048u)));
     const bool h = p.dtype == MVF_DTYPE_FLOAT16;
