@@ -202,3 +202,23 @@ def test_phase_schedule_switches_do_not_change_the_results(oracle, monkeypatch, 
                 assert (r.scores.view(np.uint32) == base.scores.view(np.uint32)).all(), f"{var}={v}: other score bits"
             monkeypatch.delenv(var)
         c.reload_tuning()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Part 6 -- rows of more than 256 16-byte vectors (dim > 1024 Float32, > 2048 Float16): the final re-scoring takes the block
+# kernel there (rescore_score_kernel), which since round 5 writes its exact keys into the list's upper half like the wave kernel.
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dt,dim,metric,nq,k", [(0, 1536, 2, 70, 100), (0, 2048, 0, 300, 10), (1, 2560, 1, 130, 50)])
+def test_batched_search_on_rows_longer_than_256_vectors(oracle, dt, dim, metric, nq, k):
+    n = 60_000
+    q = oracle.synth_queries(SEED + 1, nq, dim, dt)
+    with G.GpuCorpus.synthetic(n, dim, dt, SEED) as c:
+        got = c.search(q, k, metric)
+        c.set_scan_path(1)  # the streaming kernel: exact, one pass per four queries
+        ref = c.search(q, k, metric)
+    assert (got.indices == ref.indices).all(), "batched route != streaming kernel"
+    sel = [0, nq - 1]
+    all_sc = oracle_scores_all_rows(oracle, SEED, 0, n, dim, dt, metric, q[sel], chunk=20_000)
+    rows = oracle.synth_rows(SEED, 0, n, dim, dt).astype(np.float32) if metric == 1 else None
+    for j, qi in enumerate(sel):
+        assert_float_topk(metric, got.scores[qi], got.indices[qi], all_sc[j], rows, q[qi], k)
