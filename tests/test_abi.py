@@ -185,7 +185,7 @@ def _route(rows, dim, dtype, metric, nq, k):
 def test_the_route_of_a_search_is_a_function_of_its_shape():
     """Which kernels serve a search (no GPU): 0 = the streaming kernel K1, 1 = the batched MFMA route, 2 = passes of K1 behind a
     floor (k > 1024), 3 = K1 as a dump + the whole-shard sort.  The BASELINE configs, the measured crossovers of
-    profiles/r04_small_corpora_crossover.txt and profiles/r04_any_k.txt -- a change of a threshold has to show up here."""
+    profiles/r04_small_corpora_crossover.txt (round 5: r05_small_corpora_crossover.txt) and profiles/r04_any_k.txt -- a change of a threshold has to show up here."""
     K1, K2, PASSES, SORT = 0, 1, 2, 3
     F32, F16, I8, U8 = 0, 1, 2, 3
     L2, IP, COS = 0, 1, 2
@@ -204,6 +204,12 @@ def test_the_route_of_a_search_is_a_function_of_its_shape():
     assert [_route(1_000_000, 768, F32, COS, nq, 100) for nq in (1, 2, 4)] == [K1, K2, K2]               # 3 GB: from two queries on
     assert [_route(300_000, 768, F16, COS, nq, 10) for nq in (4, 5)] == [K1, K2]                         # 461 MB
     assert [_route(10_000_000, 768, F32, COS, nq, 100) for nq in (2, 4, 16)] == [K2, K2, K2]
+    # ... unless such a small corpus is MANY short rows: K1's passes cost by the row there (round 5,
+    # profiles/r05_small_corpora_crossover.txt: 30k x 128 f16, 32 queries 154 -> 73 us; 100k x 128 int8, 16 queries 145 -> 96)
+    assert [_route(30_000, 128, F16, COS, nq, 10) for nq in (8, 12, 16, 32)] == [K1, K1, K2, K2]         # 7.7 MB, >= 24k f16 rows: from 16
+    assert [_route(20_000, 128, F16, COS, nq, 10) for nq in (16, 32, 33)] == [K1, K1, K2]                # fewer rows: as before
+    assert [_route(100_000, 128, I8, IP, nq, 10) for nq in (8, 11, 12, 16)] == [K1, K1, K2, K2]          # 12.8 MB, >= 64k rows: from 12
+    assert [_route(100_000, 32, F32, L2, nq, 10) for nq in (8, 12)] == [K1, K2]                          # 12.8 MB of 128-byte f32 rows
     # Int8 / UInt8 rows: K1's v_dot4 pass holds its own longer
     assert [_route(30_000, 768, I8, IP, nq, 10) for nq in (8, 16, 17)] == [K1, K1, K2]                   # 23 MB of 768-byte rows
     assert [_route(300_000, 768, U8, L2, nq, 10) for nq in (4, 8, 9)] == [K1, K1, K2]                    # 230 MB
