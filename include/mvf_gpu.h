@@ -476,6 +476,16 @@ int mvfgpu_selftest_feedback(const uint32_t* samples, uint32_t n_samples, uint32
 int mvfgpu_selftest_route(uint64_t rows, uint32_t dimension, uint8_t data_type, uint8_t metric, uint32_t nq, uint32_t k,
                           uint32_t* out_route);
 
+/*
+ * Self-test of a batched search's phase schedule (no GPU needed): the row boundaries R_1 .. R_last = rows of the geometric phases a
+ * batch of `nq` queries for `k` results runs over `rows` rows under the default tuning (int8_selection != 0: the lists of the
+ * int8-shadow selection, 8192 slots per query; 0: 4096), the growth factor between them, and in *out_refined_mask bit i set where the
+ * threshold is refined with exact scores BEHIND phase i (in front of phase i + 1).  DESIGN.md section 5; the constants come from
+ * the in-process A/B runs of profiles/r05_k2_walk_and_phase_costs.txt.  k <= MVFGPU_K_PER_PASS.
+ */
+int mvfgpu_selftest_schedule(uint64_t rows, uint32_t nq, uint32_t k, int int8_selection, uint64_t* out_bounds, uint32_t max_bounds,
+                             uint32_t* out_n_bounds, uint32_t* out_growth, uint32_t* out_refined_mask);
+
 #ifdef __cplusplus
 }
 #endif

@@ -141,6 +141,10 @@ def gpu() -> C.CDLL:
                  "mvfgpu_set_profiling", "mvfgpu_last_timing", "mvfgpu_set_scan_path", "mvfgpu_corpus_reload_tuning",
                  "mvfgpu_selftest_feedback", "mvfgpu_selftest_route"):
         getattr(lib, name).restype = C.c_int
+    sched = getattr(lib, "mvfgpu_selftest_schedule", None)  # added within ABI 3 (round 5): a diagnostic entry point, no layout changed
+    if sched is not None:
+        sched.argtypes = [u64, u32, u32, C.c_int, vp, u32, vp, vp, vp]
+        sched.restype = C.c_int
     _gpu = lib
     return lib
 

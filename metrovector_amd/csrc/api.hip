@@ -611,10 +611,34 @@ bool k2_pp_wanted(const mvfgpu_corpus* c, uint8_t kdtype, uint32_t ntiles, uint3
 // -4 % on 3M and 10M rows; 256 queries -2.4 % / -0.9 % / +1.4 % on three shapes, 384 and more: 4 wins.
 // Only where a phase's records stay near half of the list capacity: with the int8 selection's margin a phase files about
 // 7 k (g - 1) records per query (measured: 1800 at k = 100, g = 4), so g <= 1 + cap / (14 k) -- k <= 117 for g = 6 on 8192 slots.
-uint32_t k2_growth_for(const mvfgpu_corpus* c, uint32_t nq, uint32_t k, uint32_t cap) {
-    uint32_t g = std::min(c->tune.k2_growth, std::max(2u, cap / (2u * k)));
-    if (nq <= 128u) g = std::max(g, std::min(c->tune.k2_growth_small, 1u + cap / (14u * k)));
+uint32_t k2_growth_for(const Tuning& t, uint32_t nq, uint32_t k, uint32_t cap) {
+    uint32_t g = std::min(t.k2_growth, std::max(2u, cap / (2u * k)));
+    if (nq <= 128u) g = std::max(g, std::min(t.k2_growth_small, 1u + cap / (14u * k)));
     return g;
+}
+uint32_t k2_growth_for(const mvfgpu_corpus* c, uint32_t nq, uint32_t k, uint32_t cap) { return k2_growth_for(c->tune, nq, k, cap); }
+
+// The phase boundaries R_1 .. R_{P+1} = nr of a batched search over nr rows (a pure function: mvfgpu_selftest_schedule pins it
+// without a GPU).  Phase 0 passes everything (no threshold yet: R_1 <= cap rows, stored by row offset), later phases grow by g:
+// expected survivors per query k (g - 1) + k carried <= cap / 2.  The boundaries are laid out BACKWARDS from the range's end --
+// R_j = nr / g^(P - j), P the fewest steps that bring R_1 under cap -- so every phase, the last one included, scans (g - 1)
+// times what its threshold has seen, and the last phase is always the largest ((1 - 1/g) of the rows: the launch bench.py times
+// and prices).  Round 1 grew forwards from cap rows, which left a small odd phase at the end (and the one before it carrying
+// most of the corpus).
+std::vector<uint64_t> k2_phase_bounds(uint64_t nr, uint32_t cap, uint32_t g) {
+    std::vector<uint64_t> bounds;
+    uint32_t P = 0;
+    for (uint64_t f = nr; f > cap; f = (f + g - 1) / g) P++;
+    for (uint32_t j = 0; j <= P; j++) {
+        uint64_t div = 1;
+        for (uint32_t i = j; i < P; i++) div *= g;
+        uint64_t e = (nr + div - 1) / div;
+        e = std::min<uint64_t>(nr, (e + 255) / 256 * 256);
+        if (j == 0) e = std::min<uint64_t>(e, cap);  // the direct phase's slots are row offsets
+        if (bounds.empty() || e > bounds.back()) bounds.push_back(e);
+    }
+    if (bounds.empty() || bounds.back() < nr) bounds.push_back(nr);
+    return bounds;
 }
 
 // The folded pre-filter of the LDS-DMA kernel's i32-accumulator flavours (scan_mfma16_bias.inc); MVF_K2_BIAS=0 keeps
@@ -834,6 +858,12 @@ constexpr uint64_t kRefineMinRows = 200000;
 // profiles/r05_k2_walk_and_phase_costs.txt 8c): 16 / 64 queries on 1M x 768 -4 % without, 32 on 3M -1.3 %, 16 on 10M -1 %;
 // 64 on 10M +1 % without, 128 and more: with.
 constexpr uint64_t kRefineMinPairs = 256ull << 20;
+// is the threshold refined behind phase bi (rows [.., bounds[bi])), in front of the phase [bounds[bi], bounds[bi + 1])?
+bool k2_refine_before(const Tuning& t, const std::vector<uint64_t>& bounds, size_t bi, uint32_t nq) {
+    if (!t.qs_refine_phases || bi + 1 >= bounds.size()) return false;
+    const uint64_t next_rows = bounds[bi + 1] - bounds[bi];
+    return bi + t.qs_refine_phases >= bounds.size() - 1 && next_rows >= kRefineMinRows && (uint64_t)nq * next_rows >= kRefineMinPairs;
+}
 bool qs_refine_enabled(const mvfgpu_corpus* c) { return c->tune.qs_refine; }
 
 // K2 per-query state (threshold key, candidate count, overflow flag; for the refinement the number of best candidates
@@ -1167,27 +1197,9 @@ int search_batched_range(const mvfgpu_corpus* c, uint8_t metric, const void* d_q
         ps->scanned = false;
     }
 
-    // Phase p scans rows [R_p, R_{p+1}) of the range; phase 0 passes everything (no threshold yet: R_1 <= cap rows, stored by row
-    // offset), later phases grow by g: expected survivors per query k (g - 1) + k carried <= cap / 2.  The boundaries are
-    // laid out BACKWARDS from the corpus' end -- R_j = n / g^(P - j), P the fewest steps that bring R_1 under cap -- so every
-    // phase, the last one included, scans (g - 1) times what its threshold has seen, and the last phase is always the
-    // largest ((1 - 1/g) of the rows: the launch bench.py times and prices).  Round 1 grew forwards from cap rows, which
-    // left a small odd phase at the end (and the one before it carrying most of the corpus).
+    // Phase p scans rows [R_p, R_{p+1}) of the range (k2_phase_bounds above)
     const uint32_t g = k2_growth_for(c, nq, k, cap);
-    std::vector<uint64_t> bounds;  // R_1 .. R_{P+1} = n
-    {
-        uint32_t P = 0;
-        for (uint64_t f = nr; f > cap; f = (f + g - 1) / g) P++;
-        for (uint32_t j = 0; j <= P; j++) {
-            uint64_t div = 1;
-            for (uint32_t i = j; i < P; i++) div *= g;
-            uint64_t e = (nr + div - 1) / div;
-            e = std::min<uint64_t>(nr, (e + 255) / 256 * 256);
-            if (j == 0) e = std::min<uint64_t>(e, cap);  // the direct phase's slots are row offsets
-            if (bounds.empty() || e > bounds.back()) bounds.push_back(e);
-        }
-        if (bounds.empty() || bounds.back() < nr) bounds.push_back(nr);
-    }
+    const std::vector<uint64_t> bounds = k2_phase_bounds(nr, cap, g);  // R_1 .. R_{P+1} = nr
     size_t bi = 0;
     uint64_t begin = 0, end = bounds[0];
     // The region counters are zero when a search starts if the search before it on this handle left them so (every scatter re-arms
@@ -1255,8 +1267,7 @@ int search_batched_range(const mvfgpu_corpus* c, uint8_t metric, const void* d_q
         if (approx) HIP_TRY(launch_compact_margin(cp, nq, s));
         else HIP_TRY(launch_compact(cp, nq, last, s));
         if (last) break;
-        if (refine && c->tune.qs_refine_phases && bi + c->tune.qs_refine_phases >= bounds.size() - 1 && bounds[bi + 1] - end >= kRefineMinRows &&
-            (uint64_t)nq * (bounds[bi + 1] - end) >= kRefineMinPairs) {  // worth its ~0.07 ms in front of the last (largest) phases
+        if (refine && k2_refine_before(c->tune, bounds, bi, nq)) {  // worth its ~0.07 ms in front of the last (largest) phases
             RescoreParams rp{};
             rp.cand = bp.cand;
             rp.cnt = cnt;
@@ -2733,6 +2744,26 @@ int mvfgpu_selftest_feedback(const uint32_t* samples, uint32_t n_samples, uint32
     out_state[1] = redone;
     out_state[2] = bias_off;
     out_state[3] = qs_off;
+    return MVF_OK;
+}
+
+int mvfgpu_selftest_schedule(uint64_t rows, uint32_t nq, uint32_t k, int int8_selection, uint64_t* out_bounds, uint32_t max_bounds,
+                             uint32_t* out_n_bounds, uint32_t* out_growth, uint32_t* out_refined_mask) {
+    if (!out_bounds || !out_n_bounds || !out_growth || !out_refined_mask) return fail(MVF_ERR_INVALID_ARGUMENT, "NULL buffer");
+    if (rows == 0 || nq == 0 || k == 0 || k > MVFGPU_K_PER_PASS) return fail(MVF_ERR_INVALID_ARGUMENT, "empty corpus / batch, or k beyond one pass");
+    const Tuning t{};  // the DEFAULT tuning, not the environment
+    const uint32_t cap = int8_selection ? kBatchCapQS : kBatchCap;
+    const uint32_t g = k2_growth_for(t, nq, k, cap);
+    const std::vector<uint64_t> bounds = k2_phase_bounds(rows, cap, g);
+    if (bounds.size() > max_bounds) return fail(MVF_ERR_INVALID_ARGUMENT, "more phases than the buffer holds");
+    uint32_t mask = 0;
+    for (size_t i = 0; i < bounds.size(); i++) {
+        out_bounds[i] = bounds[i];
+        if (int8_selection && i < 32 && k2_refine_before(t, bounds, i, nq)) mask |= 1u << i;
+    }
+    *out_n_bounds = (uint32_t)bounds.size();
+    *out_growth = g;
+    *out_refined_mask = mask;
     return MVF_OK;
 }
 

@@ -159,6 +159,55 @@ def test_repair_feedback_blames_the_prefilter_first_and_drops_its_stale_sample()
     assert _feedback([[1, 1, 0, 1]] * 4)["qs_off"]
 
 
+def _schedule(rows, nq, k, int8_selection=1):
+    b = (C.c_uint64 * 32)()
+    n, g, mask = C.c_uint32(0), C.c_uint32(0), C.c_uint32(0)
+    _lib.gpu_check(_lib.gpu().mvfgpu_selftest_schedule(rows, nq, k, int8_selection, b, 32, C.byref(n), C.byref(g), C.byref(mask)))
+    return [int(b[i]) for i in range(n.value)], g.value, mask.value
+
+
+def test_the_phase_schedule_of_a_batched_search_is_a_function_of_its_shape():
+    """The geometric phases of a batched search, their growth and where the threshold is refined (no GPU).  Constants from the
+    in-process A/B runs of profiles/r05_k2_walk_and_phase_costs.txt (8b-8d): a change has to show up here."""
+    # cfg3: 10M rows, 1024 queries, top-100 on the int8 selection: growth 4 laid out backwards from the end, the direct phase
+    # under the list capacity, the threshold refined in front of the last TWO phases
+    b, g, mask = _schedule(10_000_000, 1024, 100)
+    assert g == 4 and b == [2560, 9984, 39168, 156416, 625152, 2500096, 10_000_000]
+    assert mask == 0b0110000                                     # behind phases 4 and 5 = in front of the last two
+    assert all(x % 256 == 0 for x in b[:-1]) and b[0] <= 8192
+    # the last phase is always (1 - 1/g) of the rows
+    assert abs((b[-1] - b[-2]) / b[-1] - 0.75) < 1e-3
+    # batches of up to 128 queries grow by 6 while a phase's records stay near half of the list capacity (k <= 117 on 8192 slots) ...
+    assert [_schedule(1_000_000, nq, 100)[1] for nq in (1, 16, 64, 128, 129, 256)] == [6, 6, 6, 6, 4, 4]
+    assert [_schedule(1_000_000, 16, k)[1] for k in (10, 100, 117, 118, 146, 147, 409)] == [6, 6, 6, 5, 5, 4, 4]
+    # ... on the exact-key lists (4096 slots) only for small k
+    assert [_schedule(1_000_000, 16, k, 0)[1] for k in (10, 58, 59, 100)] == [6, 6, 5, 4]
+    # large k: the growth that keeps k (g - 1) + k inside half a list
+    assert _schedule(1_000_000, 1024, 1024)[1] == 4 and _schedule(1_000_000, 1024, 1024, 0)[1] == 2
+    # a refinement is latency whatever the batch: only in front of a phase of >= 256M query x row pairs and >= 200k rows
+    assert _schedule(1_000_000, 16, 100)[2] == 0 and _schedule(1_000_000, 64, 100)[2] == 0
+    b, g, mask = _schedule(10_000_000, 64, 100)                  # 64 x 8.3M pairs: the last phase only
+    assert g == 6 and mask == 1 << (len(b) - 2)
+    b, g, mask = _schedule(10_000_000, 16, 100)                  # 16 x 8.3M = 133M pairs: none
+    assert mask == 0
+    b, g, mask = _schedule(1_200_000, 400, 100)                  # 400 x 900k = 360M: the last; 400 x 225k = 90M: not the one before
+    assert g == 4 and mask == 1 << (len(b) - 2)
+    assert _schedule(150_000, 1024, 100)[2] == 0                 # phases under 200k rows: never
+    assert _schedule(10_000_000, 1024, 100, 0)[2] == 0           # no int8 selection, no refinement
+    # small corpora: one direct phase, or a direct phase and one more
+    assert _schedule(5000, 1024, 10) == ([5000], 4, 0)
+    b, g, mask = _schedule(20_000, 300, 10)
+    assert b[-1] == 20_000 and b[0] <= 8192 and len(b) == 2
+    # refused
+    lib = _lib.gpu()
+    bb = (C.c_uint64 * 4)()
+    n, gg, mm = C.c_uint32(0), C.c_uint32(0), C.c_uint32(0)
+    assert lib.mvfgpu_selftest_schedule(0, 1, 1, 1, bb, 4, C.byref(n), C.byref(gg), C.byref(mm)) != 0
+    assert lib.mvfgpu_selftest_schedule(10, 1, 2000, 1, bb, 4, C.byref(n), C.byref(gg), C.byref(mm)) != 0       # k beyond one pass
+    assert lib.mvfgpu_selftest_schedule(10_000_000, 1024, 100, 1, bb, 4, C.byref(n), C.byref(gg), C.byref(mm)) != 0  # buffer too short
+    assert lib.mvfgpu_selftest_schedule(10, 1, 1, 1, None, 4, C.byref(n), C.byref(gg), C.byref(mm)) != 0
+
+
 def test_search_entry_points_refuse_null_arguments_before_touching_a_device():
     """mvfgpu_search / mvfgpu_search_fetch / mvfgpu_corpus_gather_rows: a NULL handle or buffer is MVF_ERR_INVALID_ARGUMENT
     (code 12) with a message, on a box without a GPU too (checked before any HIP call)."""
