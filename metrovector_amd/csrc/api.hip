@@ -1298,9 +1298,11 @@ int search_batched_range(const mvfgpu_corpus* c, uint8_t metric, const void* d_q
             fp.pitch = c->pitch;
             fp.dim = c->dim;
             fp.dtype = c->dtype;
+            fp.write_head = 1u;  // the exact composites of the head stay where the final pass would write them
             HIP_TRY(launch_refine_tau(fp, metric, nq, ntop, lkey, qdelta, s));
         }
         RescoreParams rp{};
+        rp.head_done = (refine && nr >= kRefineMinRows) ? ntop : nullptr;
         rp.cand = bp.cand;
         rp.cnt = cnt;
         rp.tau = tau;

@@ -133,6 +133,12 @@ struct RescoreParams {
     float* out_scores;
     uint64_t* out_indices;
     int32_t* out_raw;
+    // The exact scores of the head of the FINAL lists are computed once (round 5): the refinement pass over the final lists
+    // (write_head != 0) leaves the exact composites of the rows it scores -- the k best by approximate key and their ties, the
+    // final score's form -- in the upper half of the list, where the final pass writes its own; the final pass (head_done = the
+    // refinement's ntop[]) neither fetches nor writes those entries again.  A third fewer random row fetches in the final pass.
+    uint32_t write_head;
+    const uint32_t* head_done;
 };
 hipError_t launch_compact_margin(const CompactParams& p, uint32_t nq, hipStream_t s);
 hipError_t launch_rescore(const RescoreParams& p, int metric, uint32_t nq, hipStream_t s);

@@ -701,12 +701,13 @@ __global__ void __launch_bounds__(256) rescore_score_kernel(RescoreParams p, con
     uint64_t* c = p.cand + (size_t)q * p.cap;
     const uint32_t V = p.pitch / 16;
     const uint32_t tau_q = p.tau[q];
+    const uint32_t done = (!REFINE && p.head_done && p.head_done[q] >= p.k) ? min(p.head_done[q], keep_cap) : 0u;
     for (uint32_t c0 = blockIdx.x * 16u; c0 < m; c0 += gridDim.x * 16u) {
         // this wave's four candidates: c0 + wave * 4 + u (a row past the end repeats the slice's first; not written)
         uint32_t r[4];
         const unsigned char* rp[4];
         float s[4], xx[4];
-        bool skip[4];
+        bool skip[4], head[4];
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             const uint32_t ci = c0 + (uint32_t)wave * 4u + u;
@@ -714,6 +715,7 @@ __global__ void __launch_bounds__(256) rescore_score_kernel(RescoreParams p, con
             r[u] = (uint32_t)ce;
             // outside the (possibly refined) threshold: cannot be in the top-k; not fetched, not scored
             skip[u] = !REFINE && tau_q != kNanKey && (uint32_t)(ce >> 32) > tau_q;
+            head[u] = !REFINE && ci < done;  // scored by the refinement of the final lists already: not fetched, not written
             rp[u] = p.rows + (size_t)r[u] * p.pitch;
             s[u] = 0.f;
             xx[u] = 0.f;
@@ -721,7 +723,7 @@ __global__ void __launch_bounds__(256) rescore_score_kernel(RescoreParams p, con
         for (uint32_t v = lane; v < V; v += 64) {
             u32x4 x[4];
 #pragma unroll
-            for (int u = 0; u < 4; u++) x[u] = skip[u] ? u32x4{0, 0, 0, 0} : *reinterpret_cast<const u32x4*>(rp[u] + (size_t)v * 16);
+            for (int u = 0; u < 4; u++) x[u] = (skip[u] || head[u]) ? u32x4{0, 0, 0, 0} : *reinterpret_cast<const u32x4*>(rp[u] + (size_t)v * 16);
 #pragma unroll
             for (int u = 0; u < 4; u++) {
                 auto term = [&](float qv, float xv) __attribute__((always_inline)) {
@@ -760,8 +762,11 @@ __global__ void __launch_bounds__(256) rescore_score_kernel(RescoreParams p, con
             }
             const uint32_t ci = c0 + (uint32_t)wave * 4u + u;
             if (REFINE) {
-                if (lane == 0 && ci < m) atomicMax(&lkey[q], key_from_score(sc, METRIC));  // the worst of the exact scores
-            } else if (lane == 0 && ci < m) {  // (out of place: the list's free upper half -- see rescore_wave_kernel)
+                if (lane == 0 && ci < m) {
+                    atomicMax(&lkey[q], key_from_score(sc, METRIC));  // the worst of the exact scores
+                    if (p.write_head) c[keep_cap + ci] = ((uint64_t)key_from_score(METRIC == MVF_METRIC_L2 ? sqrtf(s[u]) : sc, METRIC) << 32) | r[u];
+                }
+            } else if (lane == 0 && ci < m && !head[u]) {  // (out of place: the list's free upper half -- see rescore_wave_kernel)
                 c[keep_cap + ci] = skip[u] ? kPadComposite : ((uint64_t)key_from_score(sc, METRIC) << 32) | r[u];
             }
         }
@@ -811,14 +816,16 @@ __global__ void __launch_bounds__(256) rescore_wave_kernel(RescoreParams p, uint
         if (METRIC == MVF_METRIC_COSINE)
             for (int off = 32; off > 0; off >>= 1) qq += __shfl_xor(qq, off, 64);
         const uint32_t tau_q = p.tau[q];
+        const uint32_t done = (!REFINE && p.head_done && p.head_done[q] >= p.k) ? min(p.head_done[q], keep_cap) : 0u;
         uint64_t* c = p.cand + (size_t)q * p.cap;
         uint32_t worst = 0;  // REFINE: the worst exact key of this wave's rows
         for (uint32_t sl = sl0; sl * 64u < m; sl += slices) {
             const uint32_t ci = sl * 64u + (uint32_t)lane;
             const uint64_t ce = ci < m ? c[ci] : kPadComposite;
             // outside the (possibly refined) threshold: cannot be in the top-k; not fetched, not scored
-            const bool live = ci < m && (REFINE || tau_q == kNanKey || (uint32_t)(ce >> 32) <= tau_q);
-            if (!REFINE && part == 0 && ci < m && !live) c[keep_cap + ci] = kPadComposite;
+            const bool head = !REFINE && ci < done;  // scored by the refinement of the final lists already: its exact composite is in place
+            const bool live = ci < m && !head && (REFINE || tau_q == kNanKey || (uint32_t)(ce >> 32) <= tau_q);
+            if (!REFINE && part == 0 && ci < m && !live && !head) c[keep_cap + ci] = kPadComposite;
             const uint32_t myrow = (uint32_t)ce;
             unsigned long long mask = __builtin_amdgcn_ballot_w64(live);
             for (uint32_t rnd = 0; mask; rnd++) {  // wave-uniform
@@ -885,6 +892,8 @@ __global__ void __launch_bounds__(256) rescore_wave_kernel(RescoreParams p, uint
                     const uint32_t key = key_from_score(sc, METRIC);
                     if (REFINE) {
                         if (ok[u]) worst = max(worst, key);
+                        if (p.write_head && ok[u] && lane == l[u])
+                            c[keep_cap + ci] = ((uint64_t)key_from_score(METRIC == MVF_METRIC_L2 ? sqrtf(s[u]) : sc, METRIC) << 32) | myrow;
                     } else if (ok[u] && lane == l[u]) {
                         c[keep_cap + ci] = ((uint64_t)key << 32) | myrow;
                     }
