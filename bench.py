@@ -1152,6 +1152,41 @@ def main():
             small["overlap_with_batched_q1024_f32_mfma_first_4_queries"] = float(
                 sum(len(set(x.tolist()) & set(y.tolist())) for x, y in zip(a, b)) / b.size)
             result["small_batches"] = small
+            # ---- ... and a small batch on a MID-SIZE corpus (VERDICT r4 item 6's case: 1M x 768 f32, 16 queries, top-100): every
+            # kernel between the scans is latency here -- the library's own first-to-last-kernel time per search beside the wall time
+            if world == 1:
+                import ctypes as C
+                mrows, mq = 1_000_000, 16
+                with G.GpuCorpus.synthetic(mrows, args.dim, args.dtype, SEED, device=local_rank) as mc:
+                    mds = torch.empty((mq, args.k), dtype=torch.float32, device=dev)
+                    mdi = torch.empty((mq, args.k), dtype=torch.int64, device=dev)
+                    lib = _lib.gpu()
+                    call = lambda: _lib.gpu_check(lib.mvfgpu_search_device(mc._h, args.metric, dqb.data_ptr(), 0, args.dim, mq, args.k,
+                                                                           mds.data_ptr(), mdi.data_ptr(), None, None))
+                    for _ in range(5):
+                        call()
+                    lib.mvfgpu_set_profiling(mc._h, 1)
+                    devms = []
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    for _ in range(30):
+                        call()
+                    torch.cuda.synchronize()
+                    wall = (time.perf_counter() - t0) / 30
+                    tmm = _lib.Timing()
+                    lib.mvfgpu_last_timing(mc._h, C.byref(tmm))
+                    lib.mvfgpu_set_profiling(mc._h, 0)
+                    mid = {"workload": f"{mrows} x {args.dim} f32 {M_NAME[args.metric]}, {mq} batched queries, top-{args.k} (device pointers)",
+                           "ms_per_search_wall": wall * 1e3, "ms_per_search_device": float(tmm.search_ms_avg),
+                           "device_covers": "first to last kernel of a search on its stream (HIP events), mean of the profiled searches",
+                           "value": float(mq) * mrows / wall, "unit": "distance-ops/s"}
+                    if not args.no_recall:
+                        msel = [0, 5, 10, 15]
+                        mosc, moidx, _ = oracle_topk_rows(oracle, 0, mrows, args.dim, args.dtype, args.metric, dqb[:mq].cpu().numpy()[msel], args.k)
+                        gi = mdi.cpu().numpy().view(np.uint64)[msel]
+                        mid["recall_at_k"] = recall_of(gi, moidx, mds.cpu().numpy()[msel], mosc, args.metric)
+                        mid["recall_queries_checked"] = len(msel)
+                result["small_batch_mid_corpus"] = mid
 
     corpus.close()
     del searcher
